@@ -1,0 +1,6 @@
+"""CPU oracle for the UC2 encoder hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``uc2_amd/`` may import this package;
+only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` use it, and only as the checker / the timed CPU baseline.
+"""

@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: takes about a minute on 8 host cores")
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests are skipped automatically when no device is present, so a bare `pytest tests`
+    # works on both kinds of machine; `-m gpu` / `-m "not gpu"` select explicitly.
+    try:
+        import torch
+        have = torch.cuda.is_available()
+    except Exception:
+        have = False
+    if have:
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)

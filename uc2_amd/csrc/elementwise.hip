@@ -1,0 +1,492 @@
+// HBM-bound helper kernels of the uc2 hot path: embedding lookups, the txt|img gather into the
+// compact sequence, row selection for the masked heads, bias-gradient column sums, the loss
+// heads (cross entropy with online softmax, KL, MSE, triplet) and casts.
+// Reference lines: model/model.py:280-335 (text embeddings), :412-425 (gather), :653-657
+// (masked rows), :583-596 (MLM CE), :697-732 (ITM CE), :668-688 (MRFR), :738-775 (MRC),
+// model/itm.py:45-53 (triplet).
+#include "common.h"
+
+#define EW_BLOCK 256
+static inline int ew_grid(size_t n, int per_thread = 1) {
+  size_t g = (n + (size_t)EW_BLOCK * per_thread - 1) / ((size_t)EW_BLOCK * per_thread);
+  if (g < 1) g = 1;
+  if (g > 4096) g = 4096;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------
+// position ids: pos = cumsum(id != pad) * (id != pad) + pad          (model/model.py:280-290)
+// ---------------------------------------------------------------------------------------
+__global__ void position_ids_kernel(int B, int T, const int64_t* __restrict__ ids, int64_t pad,
+                                    int64_t* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int64_t c = 0;
+  for (int t = 0; t < T; ++t) {
+    const bool nz = ids[(size_t)b * T + t] != pad;
+    c += nz ? 1 : 0;
+    out[(size_t)b * T + t] = (nz ? c : 0) + pad;
+  }
+}
+extern "C" int uc2_position_ids(int B, int T, const int64_t* ids, int64_t pad, int64_t* out, void* stream) {
+  if (B <= 0 || T <= 0) return 0;
+  UC2_CHECK_ARG(ids && out);
+  hipLaunchKernelGGL(position_ids_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, T, ids, pad, out);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// text embedding sum: out[r] = word[ids[r]] + pos[pos_ids[r]] + type[type_ids[r] or type_const]
+// one wave per row, 4 elements per lane per step; tables are the fp32 master weights
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(int rows, int H, const int64_t* __restrict__ ids,
+                                                        const int64_t* __restrict__ pos_ids,
+                                                        const int64_t* __restrict__ type_ids, int type_const,
+                                                        const float* __restrict__ word, const float* __restrict__ pos,
+                                                        const float* __restrict__ type, T* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* w = word + (size_t)ids[r] * H;
+  const float* p = pos + (size_t)pos_ids[r] * H;
+  const float* ty = type + (size_t)(type_ids ? type_ids[r] : type_const) * H;
+  for (int c = lane * 4; c < H; c += 256) {
+    float a[4], b[4], d[4], o[4];
+    Vec4<float>::load(w + c, a);
+    Vec4<float>::load(p + c, b);
+    Vec4<float>::load(ty + c, d);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = a[e] + b[e] + d[e];
+    Vec4<T>::store(out + (size_t)r * H + c, o);
+  }
+}
+// backward: scatter-add rows into the fp32 gradient tables (word, pos; type too when per-row ids)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(int rows, int H, const int64_t* __restrict__ ids,
+                                                        const int64_t* __restrict__ pos_ids,
+                                                        const int64_t* __restrict__ type_ids,
+                                                        const T* __restrict__ dpre, float* __restrict__ dword,
+                                                        float* __restrict__ dpos, float* __restrict__ dtype) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float* w = dword ? dword + (size_t)ids[r] * H : nullptr;
+  float* p = dpos ? dpos + (size_t)pos_ids[r] * H : nullptr;
+  float* ty = (dtype && type_ids) ? dtype + (size_t)type_ids[r] * H : nullptr;
+  for (int c = lane; c < H; c += 64) {           // one dword per lane: 256 contiguous bytes per wave-instruction
+    const float g = to_f<T>(dpre[(size_t)r * H + c]);
+    if (w) atomicAdd(w + c, g);
+    if (p) atomicAdd(p + c, g);
+    if (ty) atomicAdd(ty + c, g);
+  }
+}
+extern "C" int uc2_embed_fwd(int dtype, int rows, int H, const int64_t* ids, const int64_t* pos_ids,
+                             const int64_t* type_ids, int type_const, const float* word, const float* pos,
+                             const float* type, void* out, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  UC2_CHECK_ARG(H > 0 && (H % 4) == 0);
+  if (rows <= 0) return 0;
+  UC2_CHECK_ARG(ids && pos_ids && word && pos && type && out);
+  dim3 grid((rows + 3) / 4);
+  if (dtype == 0) hipLaunchKernelGGL(embed_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, rows, H, ids, pos_ids, type_ids, type_const, word, pos, type, (float*)out);
+  else hipLaunchKernelGGL(embed_fwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, rows, H, ids, pos_ids, type_ids, type_const, word, pos, type, (bf16*)out);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int uc2_embed_bwd(int dtype, int rows, int H, const int64_t* ids, const int64_t* pos_ids,
+                             const int64_t* type_ids, const void* dpre, float* dword, float* dpos, float* dtype_tab,
+                             void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  if (rows <= 0) return 0;
+  UC2_CHECK_ARG(ids && pos_ids && dpre);
+  dim3 grid((rows + 3) / 4);
+  if (dtype == 0) hipLaunchKernelGGL(embed_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, rows, H, ids, pos_ids, type_ids, (const float*)dpre, dword, dpos, dtype_tab);
+  else hipLaunchKernelGGL(embed_bwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, rows, H, ids, pos_ids, type_ids, (const bf16*)dpre, dword, dpos, dtype_tab);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// gather along dim 1: out[b, j, :] = src[b, index[b, j], :]      (model/model.py:420-425)
+// backward is a deterministic per-source scan (index may repeat in the padded tail)
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gather_fwd_kernel(int B, int S, int L, int H, const T* __restrict__ src,
+                                                         const int64_t* __restrict__ index, T* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= B * L) return;
+  const int b = r / L;
+  const T* s = src + ((size_t)b * S + index[r]) * H;
+  for (int c = lane * 4; c < H; c += 256) {
+    float v[4];
+    Vec4<T>::load(s + c, v);
+    Vec4<T>::store(out + (size_t)r * H + c, v);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gather_bwd_kernel(int B, int S, int L, int H, const T* __restrict__ dout,
+                                                         const int64_t* __restrict__ index, T* __restrict__ dsrc) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);          // r = b*S + s
+  if (r >= B * S) return;
+  const int b = r / S, s = r - b * S;
+  for (int c = lane * 4; c < H; c += 256) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < L; ++j) {
+      if (index[(size_t)b * L + j] == s) {
+        float v[4];
+        Vec4<T>::load(dout + ((size_t)b * L + j) * H + c, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+      }
+    }
+    Vec4<T>::store(dsrc + (size_t)r * H + c, acc);
+  }
+}
+extern "C" int uc2_gather_rows_fwd(int dtype, int B, int S, int L, int H, const void* src, const int64_t* index,
+                                   void* out, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  UC2_CHECK_ARG((H % 4) == 0);
+  if (B * L <= 0) return 0;
+  UC2_CHECK_ARG(src && index && out);
+  dim3 grid((B * L + 3) / 4);
+  if (dtype == 0) hipLaunchKernelGGL(gather_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, B, S, L, H, (const float*)src, index, (float*)out);
+  else hipLaunchKernelGGL(gather_fwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, B, S, L, H, (const bf16*)src, index, (bf16*)out);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int uc2_gather_rows_bwd(int dtype, int B, int S, int L, int H, const void* dout, const int64_t* index,
+                                   void* dsrc, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  UC2_CHECK_ARG((H % 4) == 0);
+  if (B * S <= 0) return 0;
+  UC2_CHECK_ARG(dout && index && dsrc);
+  dim3 grid((B * S + 3) / 4);
+  if (dtype == 0) hipLaunchKernelGGL(gather_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, B, S, L, H, (const float*)dout, index, (float*)dsrc);
+  else hipLaunchKernelGGL(gather_bwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, B, S, L, H, (const bf16*)dout, index, (bf16*)dsrc);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// row selection for the masked heads: out[i] = src[rows[i]]  /  dsrc[rows[i]] = dsel[i]
+// (rows are unique: they come from a boolean mask; dsrc must be zero-filled by the caller)
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void select_rows_kernel(int n, int H, const T* __restrict__ src, int ld_src,
+                                                          const int64_t* __restrict__ rows, T* __restrict__ dst,
+                                                          int ld_dst, int scatter) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int64_t r = rows[i];
+  const T* s = scatter ? src + (size_t)i * ld_src : src + (size_t)r * ld_src;
+  T* d = scatter ? dst + (size_t)r * ld_dst : dst + (size_t)i * ld_dst;
+  for (int c = lane * 4; c < H; c += 256) {
+    float v[4];
+    Vec4<T>::load(s + c, v);
+    Vec4<T>::store(d + c, v);
+  }
+}
+extern "C" int uc2_select_rows(int dtype, int n, int H, const void* src, int ld_src, const int64_t* rows, void* dst,
+                               int ld_dst, int scatter, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  UC2_CHECK_ARG((H % 4) == 0 && (ld_src % 4) == 0 && (ld_dst % 4) == 0);
+  if (n <= 0) return 0;
+  UC2_CHECK_ARG(src && rows && dst);
+  dim3 grid((n + 3) / 4);
+  if (dtype == 0) hipLaunchKernelGGL(select_rows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, n, H, (const float*)src, ld_src, rows, (float*)dst, ld_dst, scatter);
+  else hipLaunchKernelGGL(select_rows_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, n, H, (const bf16*)src, ld_src, rows, (bf16*)dst, ld_dst, scatter);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// column sum (bias gradients): out[n] += sum_m X[m, n]
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const T* __restrict__ X, int ldx,
+                                                     float* __restrict__ out, int rows_per_blk) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int m0 = blockIdx.y * rows_per_blk, m1 = min(M, m0 + rows_per_blk);
+  float s = 0.f;
+  for (int m = m0; m < m1; ++m) s += to_f<T>(X[(size_t)m * ldx + n]);
+  atomicAdd(out + n, s);
+}
+extern "C" int uc2_colsum_accum(int dtype, int M, int N, const void* X, int ldx, float* out, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  if (M <= 0 || N <= 0) return 0;
+  UC2_CHECK_ARG(X && out);
+  int splits = (M + 63) / 64;
+  if (splits > 256) splits = 256;
+  const int rpb = (M + splits - 1) / splits;
+  dim3 grid((N + 255) / 256, (M + rpb - 1) / rpb);
+  if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, M, N, (const float*)X, ldx, out, rpb);
+  else hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, M, N, (const bf16*)X, ldx, out, rpb);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// cross entropy over rows of logits (F.cross_entropy(reduction='none'), ignore_index):
+// one 256-thread workgroup per row, online (max, sum) so the row is read once; argmax is a
+// side output (first index of the maximum).  Backward rewrites logits in place:
+//   dlogits = (softmax - onehot) * gout[row]     (zero for ignored rows)
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(int V, const T* __restrict__ logits, int ld,
+                                                     const int64_t* __restrict__ labels, int64_t ignore_index,
+                                                     float* __restrict__ loss, float* __restrict__ lse_o,
+                                                     int64_t* __restrict__ argmax_o) {
+  __shared__ float sm_m[4], sm_s[4];
+  __shared__ int sm_i[4];
+  const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const T* x = logits + (size_t)row * ld;
+  float m = -INFINITY, s = 0.f;
+  int am = 0x7fffffff;
+  for (int c = t; c < V; c += 256) {
+    const float v = to_f<T>(x[c]);
+    if (v > m) { s = s * __expf(m - v) + 1.f; m = v; am = c; }
+    else s += __expf(v - m);
+  }
+  // wave reduce (max, sum, first argmax)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o), s2 = __shfl_xor(s, o);
+    const int a2 = __shfl_xor(am, o);
+    const float mn = fmaxf(m, m2);
+    const float sa = (m == -INFINITY) ? 0.f : s * __expf(m - mn);
+    const float sb = (m2 == -INFINITY) ? 0.f : s2 * __expf(m2 - mn);
+    am = (m2 > m || (m2 == m && a2 < am)) ? a2 : am;
+    s = sa + sb; m = mn;
+  }
+  if (lane == 0) { sm_m[wv] = m; sm_s[wv] = s; sm_i[wv] = am; }
+  __syncthreads();
+  if (t == 0) {
+    float M = sm_m[0], S = sm_s[0];
+    int A = sm_i[0];
+    for (int i = 1; i < 4; ++i) {
+      const float m2 = sm_m[i], s2 = sm_s[i];
+      const float mn = fmaxf(M, m2);
+      const float sa = (M == -INFINITY) ? 0.f : S * __expf(M - mn);
+      const float sb = (m2 == -INFINITY) ? 0.f : s2 * __expf(m2 - mn);
+      A = (m2 > M || (m2 == M && sm_i[i] < A)) ? sm_i[i] : A;
+      S = sa + sb; M = mn;
+    }
+    const float lse = M + __logf(S);
+    if (lse_o) lse_o[row] = lse;
+    if (argmax_o) argmax_o[row] = A;
+    if (loss) {
+      const int64_t lab = labels[row];
+      loss[row] = (lab == ignore_index) ? 0.f : lse - to_f<T>(x[lab]);
+    }
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(int V, T* __restrict__ logits, int ld,
+                                                     const int64_t* __restrict__ labels, int64_t ignore_index,
+                                                     const float* __restrict__ lse, const float* __restrict__ gout) {
+  const int row = blockIdx.y;
+  const int64_t lab = labels[row];
+  const float g = (lab == ignore_index) ? 0.f : gout[row];
+  const float l = lse[row];
+  T* x = logits + (size_t)row * ld;
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < V; c += gridDim.x * 256) {
+    const float p = __expf(to_f<T>(x[c]) - l);
+    x[c] = from_f<T>((p - (c == lab ? 1.f : 0.f)) * g);
+  }
+}
+extern "C" int uc2_ce_fwd(int dtype, int n, int V, const void* logits, int ld, const int64_t* labels,
+                          int64_t ignore_index, float* loss, float* lse, int64_t* argmax, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  if (n <= 0) return 0;
+  UC2_CHECK_ARG(V > 0 && logits && (labels || !loss));
+  if (dtype == 0) hipLaunchKernelGGL(ce_fwd_kernel<float>, dim3(n), dim3(256), 0, (hipStream_t)stream, V, (const float*)logits, ld, labels, ignore_index, loss, lse, argmax);
+  else hipLaunchKernelGGL(ce_fwd_kernel<bf16>, dim3(n), dim3(256), 0, (hipStream_t)stream, V, (const bf16*)logits, ld, labels, ignore_index, loss, lse, argmax);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int uc2_ce_bwd(int dtype, int n, int V, void* logits, int ld, const int64_t* labels, int64_t ignore_index,
+                          const float* lse, const float* gout, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  if (n <= 0) return 0;
+  UC2_CHECK_ARG(V > 0 && logits && labels && lse && gout);
+  int gx = (V + 255) / 256;
+  if (gx > 64) gx = 64;
+  dim3 grid(gx, n);
+  if (dtype == 0) hipLaunchKernelGGL(ce_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, V, (float*)logits, ld, labels, ignore_index, lse, gout);
+  else hipLaunchKernelGGL(ce_bwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, V, (bf16*)logits, ld, labels, ignore_index, lse, gout);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// KL(target || softmax(pred)) per element (F.kl_div(log_softmax(pred), target, 'none')),
+// model/model.py:764-768.  fwd needs lse per row (from ce_fwd with loss=null).
+//   loss[i,j] = t * (log t - (pred - lse))   (0 where t == 0)
+//   dpred[i,k] = p_k * sum_j g_j t_j - g_k t_k
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void kl_fwd_kernel(int V, const T* __restrict__ pred, int ld,
+                                                     const float* __restrict__ target, const float* __restrict__ lse,
+                                                     float* __restrict__ loss) {
+  const int row = blockIdx.y;
+  const float l = lse[row];
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < V; c += gridDim.x * 256) {
+    const float t = target[(size_t)row * V + c];
+    const float logp = to_f<T>(pred[(size_t)row * ld + c]) - l;
+    loss[(size_t)row * V + c] = (t > 0.f) ? t * (__logf(t) - logp) : 0.f;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void kl_bwd_kernel(int V, const T* __restrict__ pred, int ld,
+                                                     const float* __restrict__ target, const float* __restrict__ lse,
+                                                     const float* __restrict__ gout, T* __restrict__ dpred) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, t = threadIdx.x;
+  float s = 0.f;
+  for (int c = t; c < V; c += 256) s += gout[(size_t)row * V + c] * target[(size_t)row * V + c];
+  s = wave_sum(s);
+  if ((t & 63) == 0) red[t >> 6] = s;
+  __syncthreads();
+  const float tot = red[0] + red[1] + red[2] + red[3];
+  const float l = lse[row];
+  for (int c = t; c < V; c += 256) {
+    const float p = __expf(to_f<T>(pred[(size_t)row * ld + c]) - l);
+    dpred[(size_t)row * ld + c] = from_f<T>(p * tot - gout[(size_t)row * V + c] * target[(size_t)row * V + c]);
+  }
+}
+extern "C" int uc2_kl_fwd(int dtype, int n, int V, const void* pred, int ld, const float* target, const float* lse,
+                          float* loss, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  if (n <= 0) return 0;
+  UC2_CHECK_ARG(pred && target && lse && loss);
+  dim3 grid(min(8, (V + 255) / 256), n);
+  if (dtype == 0) hipLaunchKernelGGL(kl_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, V, (const float*)pred, ld, target, lse, loss);
+  else hipLaunchKernelGGL(kl_fwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, V, (const bf16*)pred, ld, target, lse, loss);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int uc2_kl_bwd(int dtype, int n, int V, const void* pred, int ld, const float* target, const float* lse,
+                          const float* gout, void* dpred, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  if (n <= 0) return 0;
+  UC2_CHECK_ARG(pred && target && lse && gout && dpred);
+  if (dtype == 0) hipLaunchKernelGGL(kl_bwd_kernel<float>, dim3(n), dim3(256), 0, (hipStream_t)stream, V, (const float*)pred, ld, target, lse, gout, (float*)dpred);
+  else hipLaunchKernelGGL(kl_bwd_kernel<bf16>, dim3(n), dim3(256), 0, (hipStream_t)stream, V, (const bf16*)pred, ld, target, lse, gout, (bf16*)dpred);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// MSE per element (F.mse_loss(reduction='none'), model/model.py:684-686)
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void mse_kernel(size_t n, const T* __restrict__ pred, const float* __restrict__ target,
+                           const float* __restrict__ gout, float* __restrict__ loss, T* __restrict__ dpred) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float d = to_f<T>(pred[i]) - target[i];
+    if (loss) loss[i] = d * d;
+    if (dpred) dpred[i] = from_f<T>(2.f * d * gout[i]);
+  }
+}
+extern "C" int uc2_mse(int dtype, size_t n, const void* pred, const float* target, const float* gout, float* loss,
+                       void* dpred, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  if (n == 0) return 0;
+  UC2_CHECK_ARG(pred && target && (loss || (dpred && gout)));
+  if (dtype == 0) hipLaunchKernelGGL(mse_kernel<float>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, n, (const float*)pred, target, gout, loss, (float*)dpred);
+  else hipLaunchKernelGGL(mse_kernel<bf16>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, n, (const bf16*)pred, target, gout, loss, (bf16*)dpred);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// triplet ranking loss (model/itm.py:45-53): s = sigmoid(score).view(-1, ss);
+//   loss[i, j-1] = max(margin + s[i,j] - s[i,0], 0),  j = 1..ss-1
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void triplet_kernel(int n, int ss, float margin, const T* __restrict__ score,
+                               const float* __restrict__ gout, float* __restrict__ loss, T* __restrict__ dscore) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float sp = 1.f / (1.f + __expf(-to_f<T>(score[(size_t)i * ss])));
+  float dpos = 0.f;
+  for (int j = 1; j < ss; ++j) {
+    const float sn = 1.f / (1.f + __expf(-to_f<T>(score[(size_t)i * ss + j])));
+    const float l = margin + sn - sp;
+    if (loss) loss[(size_t)i * (ss - 1) + j - 1] = l > 0.f ? l : 0.f;
+    if (dscore) {
+      const float g = (l > 0.f) ? gout[(size_t)i * (ss - 1) + j - 1] : 0.f;
+      dscore[(size_t)i * ss + j] = from_f<T>(g * sn * (1.f - sn));
+      dpos -= g;
+    }
+  }
+  if (dscore) dscore[(size_t)i * ss] = from_f<T>(dpos * sp * (1.f - sp));
+}
+extern "C" int uc2_triplet(int dtype, int n, int ss, float margin, const void* score, const float* gout, float* loss,
+                           void* dscore, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  UC2_CHECK_ARG(ss >= 2);
+  if (n <= 0) return 0;
+  UC2_CHECK_ARG(score && (loss || (dscore && gout)));
+  if (dtype == 0) hipLaunchKernelGGL(triplet_kernel<float>, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, ss, margin, (const float*)score, gout, loss, (float*)dscore);
+  else hipLaunchKernelGGL(triplet_kernel<bf16>, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, n, ss, margin, (const bf16*)score, gout, loss, (bf16*)dscore);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// dtanh for the pooler backward: dx = dy * (1 - y^2)   (model/layer.py:179-185)
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void dtanh_kernel(size_t n, const T* __restrict__ y, const T* __restrict__ dy, T* __restrict__ dx) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = to_f<T>(y[i]);
+    dx[i] = from_f<T>(to_f<T>(dy[i]) * (1.f - v * v));
+  }
+}
+extern "C" int uc2_dtanh(int dtype, size_t n, const void* y, const void* dy, void* dx, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  if (n == 0) return 0;
+  UC2_CHECK_ARG(y && dy && dx);
+  if (dtype == 0) hipLaunchKernelGGL(dtanh_kernel<float>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, n, (const float*)y, (const float*)dy, (float*)dx);
+  else hipLaunchKernelGGL(dtanh_kernel<bf16>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, n, (const bf16*)y, (const bf16*)dy, (bf16*)dx);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// casts between fp32 and bf16 (compute copies of the master weights; inputs)
+// ---------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ void cast_kernel(size_t n, const TI* __restrict__ in, TO* __restrict__ out) {
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float v[4];
+    Vec4<TI>::load(in + i * 4, v);
+    Vec4<TO>::store(out + i * 4, v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t i = (n4 << 2) + threadIdx.x;
+    out[i] = from_f<TO>(to_f<TI>(in[i]));
+  }
+}
+extern "C" int uc2_cast(int from_dtype, int to_dtype, size_t n, const void* in, void* out, void* stream) {
+  UC2_CHECK_ARG((from_dtype == 0 || from_dtype == 1) && (to_dtype == 0 || to_dtype == 1));
+  if (n == 0) return 0;
+  UC2_CHECK_ARG(in && out);
+  UC2_CHECK_ARG((((uintptr_t)in | (uintptr_t)out) & 15) == 0);
+  dim3 grid(ew_grid(n, 4)), block(EW_BLOCK);
+  hipStream_t st = (hipStream_t)stream;
+  if (from_dtype == 0 && to_dtype == 1) hipLaunchKernelGGL((cast_kernel<float, bf16>), grid, block, 0, st, n, (const float*)in, (bf16*)out);
+  else if (from_dtype == 1 && to_dtype == 0) hipLaunchKernelGGL((cast_kernel<bf16, float>), grid, block, 0, st, n, (const bf16*)in, (float*)out);
+  else if (from_dtype == 0) hipLaunchKernelGGL((cast_kernel<float, float>), grid, block, 0, st, n, (const float*)in, (float*)out);
+  else hipLaunchKernelGGL((cast_kernel<bf16, bf16>), grid, block, 0, st, n, (const bf16*)in, (bf16*)out);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,233 @@
+// Row LayerNorm fused with dropout + residual add (replaces apex FusedLayerNorm,
+// reference model/layer.py:25, and the dense->dropout->LN(x+res) tails at
+// model/layer.py:111-115,152-156; embeddings LN at model/model.py:331,358-362).
+//
+//   z = dropout(x) + residual ;  y = (z - mean) * rstd * gamma + beta      (biased variance)
+//
+// One 64-lane wave per row, 4 rows per 256-thread workgroup; statistics in fp32; the row lives
+// in registers (H <= 1024, H % 4 == 0), vector loads of 4 elements per lane.  HBM-bound:
+// algorithmic bytes per row = (2 or 3) * H * sizeof(T) forward.
+#include "common.h"
+
+#define LN_MAXC 4     // chunks of 4 elements per lane: H <= 64*4*4 = 1024
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int H, const T* __restrict__ x, const T* __restrict__ res,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, uint32_t thresh, float keep_scale, uint64_t seed,
+                                                     T* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = H >> 2;
+  float v[LN_MAXC][4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const size_t off = (size_t)row * H + c * 4;
+      Vec4<T>::load(x + off, v[i]);
+      if (thresh) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = drop_keep(seed, off + e, thresh) ? v[i][e] * keep_scale : 0.f;
+      }
+      if (res) {
+        float r[4];
+        Vec4<T>::load(res + off, r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] += r[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += v[i][e];
+    }
+  }
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+  const float var = wave_sum(q) / (float)H;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  if (lane == 0) {
+    if (mean_o) mean_o[row] = mean;
+    if (rstd_o) rstd_o[row] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      float g[4], b[4], o[4];
+      Vec4<float>::load(gamma + c * 4, g);
+      Vec4<float>::load(beta + c * 4, b);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+      Vec4<T>::store(y + (size_t)row * H + c * 4, o);
+    }
+  }
+}
+
+// backward.  dz = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+//   dres = dz ;  dx = dz * keep / (1-p)
+//   dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy   (per-workgroup partials -> ws, then reduced)
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const T* __restrict__ res, const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                     uint32_t thresh, float keep_scale, uint64_t seed,
+                                                     T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ ws) {
+  __shared__ float red[4][2][LN_MAXC * 4 * 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nch = H >> 2;
+  float dg[LN_MAXC][4], db[LN_MAXC][4];
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
+
+  for (int row = blockIdx.x * 4 + wv; row < M; row += gridDim.x * 4) {
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    float xh[LN_MAXC][4], g[LN_MAXC][4];
+    bool kp[LN_MAXC][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const size_t off = (size_t)row * H + c * 4;
+        float xv[4], dyv[4], gm[4];
+        Vec4<T>::load(x + off, xv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) kp[i][e] = true;
+        if (thresh) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            kp[i][e] = drop_keep(seed, off + e, thresh);
+            xv[e] = kp[i][e] ? xv[e] * keep_scale : 0.f;
+          }
+        }
+        if (res) {
+          float r[4];
+          Vec4<T>::load(res + off, r);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xv[e] += r[e];
+        }
+        Vec4<T>::load(dy + off, dyv);
+        Vec4<float>::load(gamma + c * 4, gm);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[i][e] = (xv[e] - mean) * rstd;
+          g[i][e] = dyv[e] * gm[e];
+          s1 += g[i][e];
+          s2 += g[i][e] * xh[i][e];
+          dg[i][e] += dyv[e] * xh[i][e];
+          db[i][e] += dyv[e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const size_t off = (size_t)row * H + c * 4;
+        float dz[4], dxv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dz[e] = rstd * (g[i][e] - s1 - xh[i][e] * s2);
+          dxv[e] = thresh ? (kp[i][e] ? dz[e] * keep_scale : 0.f) : dz[e];
+        }
+        if (dx) Vec4<T>::store(dx + off, dxv);
+        if (dres) Vec4<T>::store(dres + off, dz);
+      }
+    }
+  }
+  // reduce the 4 waves of this workgroup, write one partial row per workgroup
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[wv][0][(i * 64 + lane) * 4 + e] = dg[i][e];
+      red[wv][1][(i * 64 + lane) * 4 + e] = db[i][e];
+    }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * H; idx += 256) {
+    const int which = idx / H, col = idx - which * H;      // col = c*4 + e with c = lane + 64*i
+    const int c = col >> 2, e = col & 3, i = c >> 6, ln = c & 63;
+    const int a = (i * 64 + ln) * 4 + e;
+    const float sum = red[0][which][a] + red[1][which][a] + red[2][which][a] + red[3][which][a];
+    ws[(size_t)blockIdx.x * 2 * H + idx] = sum;
+  }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(int nblk, int H, const float* __restrict__ ws,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 2 * H) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += ws[(size_t)b * 2 * H + idx];
+  if (idx < H) { if (dgamma) dgamma[idx] += s; }
+  else { if (dbeta) dbeta[idx - H] += s; }
+}
+
+static int ln_bwd_blocks(int M) {
+  int nb = (M + 3) / 4;
+  return nb < 1 ? 1 : (nb > 512 ? 512 : nb);
+}
+
+extern "C" int uc2_ln_fwd(int dtype, int M, int H, const void* x, const void* residual, const float* gamma,
+                          const float* beta, float eps, float drop_p, uint64_t seed, void* y, float* mean,
+                          float* rstd, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  UC2_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= LN_MAXC * 256);
+  UC2_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
+  if (M <= 0) return 0;
+  UC2_CHECK_ARG(x && gamma && beta && y);
+  const uint32_t th = drop_thresh(drop_p);
+  const float ks = 1.0f / (1.0f - drop_p);
+  dim3 grid((M + 3) / 4), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0)
+    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, st, M, H, (const float*)x, (const float*)residual, gamma,
+                       beta, eps, th, ks, seed, (float*)y, mean, rstd);
+  else
+    hipLaunchKernelGGL(ln_fwd_kernel<bf16>, grid, block, 0, st, M, H, (const bf16*)x, (const bf16*)residual, gamma,
+                       beta, eps, th, ks, seed, (bf16*)y, mean, rstd);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t uc2_ln_bwd_workspace(int M, int H) { return (size_t)ln_bwd_blocks(M) * 2 * H * sizeof(float); }
+
+extern "C" int uc2_ln_bwd(int dtype, int M, int H, const void* dy, const void* x, const void* residual,
+                          const float* gamma, const float* mean, const float* rstd, float drop_p, uint64_t seed,
+                          void* dx, void* dres, float* dgamma, float* dbeta, void* ws, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  UC2_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= LN_MAXC * 256);
+  UC2_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
+  if (M <= 0) return 0;
+  UC2_CHECK_ARG(dy && x && gamma && mean && rstd && ws);
+  const uint32_t th = drop_thresh(drop_p);
+  const float ks = 1.0f / (1.0f - drop_p);
+  const int nb = ln_bwd_blocks(M);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0)
+    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, M, H, (const float*)dy, (const float*)x,
+                       (const float*)residual, gamma, mean, rstd, th, ks, seed, (float*)dx, (float*)dres, (float*)ws);
+  else
+    hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, M, H, (const bf16*)dy, (const bf16*)x,
+                       (const bf16*)residual, gamma, mean, rstd, th, ks, seed, (bf16*)dx, (bf16*)dres, (float*)ws);
+  UC2_LAUNCH_CHECK();
+  if (dgamma || dbeta) {
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * H + 255) / 256), dim3(256), 0, st, nb, H, (const float*)ws,
+                       dgamma, dbeta);
+    UC2_LAUNCH_CHECK();
+  }
+  return 0;
+}
