@@ -1,0 +1,280 @@
+"""Kernel-level parity on the GPU: every C-ABI kernel against a plain torch fp32 restatement of the
+same op on the same seeded inputs.  (Model-level parity against the oracle/golden vectors is in
+test_gpu_model.py.)  All calls go through the C-ABI (uc2_amd.ops -> libuc2_hip.so)."""
+import math
+
+import pytest
+import torch
+
+from uc2_amd import ops
+from uc2_amd.utils import synth
+from util import max_rel, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(shape, seed, scale=1.0, dtype=torch.float32):
+    return (synth.det_normal(shape, seed) * scale).to(DEV).to(dtype)
+
+
+def tol(dtype, f32=2e-5, bf16=2e-2):
+    return f32 if dtype == torch.float32 else bf16
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 72), (37, 1601, 128), (384, 768, 768), (96, 2, 128)])
+def test_gemm_layouts(dtype, ta, tb, M, N, K):
+    a = rnd((K, M) if ta else (M, K), 1, dtype=dtype)
+    b = rnd((K, N) if tb else (N, K), 2, dtype=dtype)
+    bias = rnd((N,), 3)
+    A = (a.t() if ta else a).float()
+    Bm = (b.t() if tb else b).float()
+    ref = A @ Bm.t() + bias
+    out = ops.gemm(a, b, M, N, K, ta=ta, tb=tb, bias=bias)
+    assert out.dtype == dtype
+    e = rel_err(out.float(), ref)
+    assert e < tol(dtype, 1e-5, 6e-3), "rel err %.3e" % e
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(dtype):
+    M, N, K = 260, 512, 128
+    a, w, bias = rnd((M, K), 1, dtype=dtype), rnd((N, K), 2, 0.1, dtype=dtype), rnd((N,), 3)
+    pre_ref = a.float() @ w.float().t() + bias
+    pre = torch.empty((M, N), dtype=dtype, device=DEV)
+    u = ops.gemm(a, w, M, N, K, bias=bias, epi=ops.EPI_GELU, aux_out=pre)
+    assert rel_err(pre.float(), pre_ref) < tol(dtype, 1e-5, 6e-3)
+    assert rel_err(u.float(), torch.nn.functional.gelu(pre_ref)) < tol(dtype, 1e-5, 8e-3)
+    t = ops.gemm(a, w, M, N, K, bias=bias, epi=ops.EPI_TANH)
+    assert rel_err(t.float(), torch.tanh(pre_ref)) < tol(dtype, 1e-5, 8e-3)
+    # dgrad with dgelu / add epilogues:  dX = dY W  (tb=True, B = W[N,K] read as [k=N][n=K])
+    dy = rnd((M, N), 4, dtype=dtype)
+    aux = rnd((M, K), 5, dtype=dtype)
+    dx_ref = dy.float() @ w.float()
+    d1 = ops.gemm(dy, w, M, K, N, tb=True, epi=ops.EPI_ADD, aux_in=aux)
+    assert rel_err(d1.float(), dx_ref + aux.float()) < tol(dtype, 1e-5, 8e-3)
+    x = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).backward(dx_ref)
+    d2 = ops.gemm(dy, w, M, K, N, tb=True, epi=ops.EPI_DGELU, aux_in=aux)
+    assert rel_err(d2.float(), x.grad) < tol(dtype, 1e-5, 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,split", [(300, 1), (1000, 4), (4100, 7)])
+def test_gemm_wgrad_accumulate(dtype, rows, split):
+    N, K = 384, 200
+    dy, x = rnd((rows, N), 1, dtype=dtype), rnd((rows, K), 2, dtype=dtype)
+    dw = rnd((N, K), 3)
+    ref = dw + dy.float().t() @ x.float()
+    ops.gemm(dy, x, N, K, rows, ta=True, tb=True, out=dw, accumulate=True, split_k=split)
+    assert rel_err(dw, ref) < tol(dtype, 1e-5, 6e-3)
+    db = rnd((N,), 4)
+    refb = db + dy.float().sum(0)
+    ops.colsum_accum(dy, db)
+    assert rel_err(db, refb) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,H", [(7, 128), (260, 768), (33, 1024)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_layernorm_fwd_bwd(dtype, M, H, with_res):
+    x = rnd((M, H), 1, dtype=dtype)
+    r = rnd((M, H), 2, dtype=dtype) if with_res else None
+    g, b = (1 + 0.1 * rnd((H,), 3)), rnd((H,), 4, 0.1)
+    dy = rnd((M, H), 5, dtype=dtype)
+    xs = x.float().requires_grad_(True)
+    rs = r.float().requires_grad_(True) if with_res else None
+    gs, bs = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    z = xs + rs if with_res else xs
+    ref = torch.nn.functional.layer_norm(z, (H,), gs, bs, 1e-12)
+    ref.backward(dy.float())
+    y, mean, rstd = ops.ln_fwd(x, r, g, b, 1e-12)
+    assert max_rel(y.float(), ref) < tol(dtype, 2e-5, 2e-2)
+    dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    dx, dres = ops.ln_bwd(dy, x, r, g, mean, rstd, dg, db)
+    assert dres is dx
+    assert rel_err(dx.float(), xs.grad) < tol(dtype, 2e-5, 1e-2)
+    assert rel_err(dg, gs.grad) < tol(dtype, 2e-5, 1e-2)
+    assert rel_err(db, bs.grad) < tol(dtype, 2e-5, 1e-2)
+
+
+def test_layernorm_dropout_consistency():
+    """dropout inside LN: mask is a pure function of (seed, index): fwd and bwd agree, rate is right"""
+    M, H, p = 512, 768, 0.1
+    x = rnd((M, H), 1)
+    g, b = torch.ones(H, device=DEV), torch.zeros(H, device=DEV)
+    seed = torch.tensor([1234], dtype=torch.int64, device=DEV)
+    zero = torch.zeros((M, H), device=DEV)
+    # with x = 1 and residual = 0, LN input is keep/(1-p): recover the mask from a second run on ones
+    ones = torch.ones((M, H), device=DEV)
+    y1, m1, r1 = ops.ln_fwd(ones, zero, g, b, 1e-12, p, seed, 7)
+    y2, _, _ = ops.ln_fwd(ones, zero, g, b, 1e-12, p, seed, 7)
+    assert torch.equal(y1, y2)
+    keep = (y1 > 0)                                   # kept entries are above the row mean
+    rate = 1.0 - keep.float().mean().item()
+    assert abs(rate - p) < 0.01, rate
+    y3, _, _ = ops.ln_fwd(ones, zero, g, b, 1e-12, p, seed, 8)
+    assert not torch.equal(y1, y3)                    # another site id -> another mask
+    # backward: gradient wrt x is zero exactly where the element was dropped
+    y, mean, rstd = ops.ln_fwd(x, zero, g, b, 1e-12, p, seed, 7)
+    dy = rnd((M, H), 3)
+    dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    dx, dres = ops.ln_bwd(dy, x, zero, g, mean, rstd, dg, db, p, seed, 7)
+    assert torch.equal(dx == 0, ~keep)
+    assert torch.allclose(dx[keep], dres[keep] / (1 - p), rtol=1e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attn_ref(qkv, mask, B, L, nh, D):
+    H = nh * D
+    q, k, v = [t.reshape(B, L, nh, D).permute(0, 2, 1, 3) for t in qkv.float().reshape(B, L, 3, H).unbind(2)]
+    s = q @ k.transpose(-1, -2) / math.sqrt(D) + mask[:, None, None, :]
+    p = torch.softmax(s, -1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B * L, H), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,L,nh,D", [(3, 68, 4, 32), (2, 96, 12, 64), (2, 130, 2, 64), (1, 33, 1, 64)])
+@pytest.mark.parametrize("impl", [1, 2])
+def test_attention_fwd_bwd(dtype, B, L, nh, D, impl):
+    lib = ops._lib.load()
+    if impl == 2 and (dtype != torch.bfloat16 or not lib.uc2_attn_mfma_supported(L, D)):
+        pytest.skip("MFMA attention: bf16 only / shape unsupported")
+    H = nh * D
+    qkv = rnd((B * L, 3 * H), 1, 0.7, dtype=dtype)
+    mask = torch.zeros(B, L, device=DEV)
+    mask[0, L - 5:] = -10000.0
+    if B > 1:
+        mask[1, L // 2:] = -10000.0
+    dctx = rnd((B * L, H), 2, dtype=dtype)
+    qs = qkv.float().requires_grad_(True)
+    ref, lse_ref = attn_ref(qs, mask, B, L, nh, D)
+    ref.backward(dctx.float())
+    ctx, lse = ops.attn_fwd(qkv, mask, B, L, nh, D, impl=impl)
+    assert rel_err(ctx.float(), ref) < tol(dtype, 1e-5, 8e-3)
+    assert rel_err(lse, lse_ref) < tol(dtype, 1e-5, 2e-3)
+    dqkv = ops.attn_bwd(qkv, mask, ctx, dctx, lse, B, L, nh, D, impl=impl)
+    assert rel_err(dqkv.float(), qs.grad) < tol(dtype, 2e-5, 1.5e-2)
+
+
+def test_attention_dropout_statistics():
+    """E[dropout(P) V] == P V: averaged over many seeds the dropped output approaches the clean one,
+    and backward with the same seed is the exact gradient of that forward (checked by linearity in dctx)."""
+    B, L, nh, D, p = 2, 96, 4, 64, 0.1
+    H = nh * D
+    qkv = rnd((B * L, 3 * H), 1, 0.5)
+    mask = torch.zeros(B, L, device=DEV)
+    clean, _ = ops.attn_fwd(qkv, mask, B, L, nh, D, impl=1)
+    acc = torch.zeros_like(clean)
+    n = 64
+    for i in range(n):
+        seed = torch.tensor([1000 + i], dtype=torch.int64, device=DEV)
+        c, _ = ops.attn_fwd(qkv, mask, B, L, nh, D, p, seed, 3, impl=1)
+        acc += c
+    assert rel_err(acc / n, clean) < 0.06
+    seed = torch.tensor([5], dtype=torch.int64, device=DEV)
+    c, lse = ops.attn_fwd(qkv, mask, B, L, nh, D, p, seed, 3, impl=1)
+    d1, d2 = rnd((B * L, H), 2), rnd((B * L, H), 3)
+    g1 = ops.attn_bwd(qkv, mask, c, d1, lse, B, L, nh, D, p, seed, 3, impl=1)
+    g2 = ops.attn_bwd(qkv, mask, c, d2, lse, B, L, nh, D, p, seed, 3, impl=1)
+    g12 = ops.attn_bwd(qkv, mask, c, d1 + d2, lse, B, L, nh, D, p, seed, 3, impl=1)
+    assert rel_err(g12, g1 + g2) < 1e-4
+    # directional derivative check of the dropped forward
+    eps = 1e-2
+    dirn = rnd(qkv.shape, 9)
+    cp, _ = ops.attn_fwd(qkv + eps * dirn, mask, B, L, nh, D, p, seed, 3, impl=1)
+    cm, _ = ops.attn_fwd(qkv - eps * dirn, mask, B, L, nh, D, p, seed, 3, impl=1)
+    fd = ((cp - cm) / (2 * eps) * d1).sum().item()
+    an = (g1 * dirn).sum().item()
+    assert abs(fd - an) < 2e-2 * max(1.0, abs(an)), (fd, an)
+
+
+# ------------------------------------------------------------------------------------------ heads etc.
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,V", [(5, 2), (33, 1601), (9, 250002)])
+def test_cross_entropy(dtype, n, V):
+    Vp = (V + 7) // 8 * 8
+    logits = torch.zeros((n, Vp), dtype=dtype, device=DEV)
+    logits[:, :V] = rnd((n, V), 1, 3.0, dtype=dtype)
+    labels = synth.det_randint((n,), 2, 0, V).to(DEV)
+    labels[0] = 0
+    ign = 0 if V == 1601 else -100
+    x = logits[:, :V].float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(x, labels, ignore_index=ign, reduction="none")
+    g = rnd((n,), 3)
+    ref.backward(g)
+    loss, am = ops.CrossEntropyFn.apply(logits.clone().requires_grad_(True), labels, ign, V)
+    assert rel_err(loss, ref.detach()) < 1e-5
+    assert torch.equal(am, x.argmax(-1))
+    lg = logits.clone().requires_grad_(True)
+    loss2, _ = ops.CrossEntropyFn.apply(lg, labels, ign, V)
+    loss2.backward(g)
+    assert rel_err(lg.grad[:, :V].float(), x.grad) < tol(dtype, 1e-5, 1e-2)
+
+
+def test_kl_mse_triplet():
+    n, V = 17, 1601
+    pred = rnd((n, V), 1, 2.0)
+    tgt = torch.softmax(rnd((n, V), 2, 3.0), -1)
+    tgt[:, 5] = 0
+    g = rnd((n, V), 3)
+    x = pred.clone().requires_grad_(True)
+    ref = torch.nn.functional.kl_div(torch.log_softmax(x, -1), tgt, reduction="none")
+    ref.backward(g)
+    y = pred.clone().requires_grad_(True)
+    out = ops.KLDivFn.apply(y, tgt, V)
+    out.backward(g)
+    assert rel_err(out, ref.detach()) < 1e-5 and rel_err(y.grad, x.grad) < 1e-5
+    a, t = rnd((33, 2048), 4), rnd((33, 2048), 5)
+    x = a.clone().requires_grad_(True)
+    ref = torch.nn.functional.mse_loss(x, t, reduction="none")
+    gg = rnd((33, 2048), 6)
+    ref.backward(gg)
+    y = a.clone().requires_grad_(True)
+    out = ops.MSEFn.apply(y, t)
+    out.backward(gg)
+    assert rel_err(out, ref.detach()) < 1e-6 and rel_err(y.grad, x.grad) < 1e-6
+    s = rnd((12, 1), 7)
+    x = s.clone().requires_grad_(True)
+    sg = torch.sigmoid(x).view(-1, 3)
+    ref = torch.clamp(0.2 + sg[:, 1:] - sg[:, :1], 0)
+    g3 = rnd((4, 2), 8)
+    ref.backward(g3)
+    y = s.clone().requires_grad_(True)
+    out = ops.TripletFn.apply(y, 3, 0.2)
+    out.backward(g3)
+    assert rel_err(out, ref.detach()) < 1e-6 and rel_err(y.grad, x.grad) < 1e-5
+
+
+def test_gather_select_embed():
+    B, S, L, H = 3, 14, 12, 128
+    src = rnd((B, S, H), 1)
+    idx = synth.det_randint((B, L), 2, 0, S).to(DEV)
+    x = src.clone().requires_grad_(True)
+    ref = torch.gather(x, 1, idx.unsqueeze(-1).expand(-1, -1, H))
+    g = rnd((B, L, H), 3)
+    ref.backward(g)
+    y = src.clone().requires_grad_(True)
+    out = ops.GatherRowsFn.apply(y, idx)
+    out.backward(g)
+    assert torch.equal(out, ref.detach()) and rel_err(y.grad, x.grad) < 1e-6
+    hid = rnd((40, H), 4)
+    rows = torch.tensor([0, 3, 7, 39], device=DEV)
+    y = hid.clone().requires_grad_(True)
+    out = ops.SelectRowsFn.apply(y, rows)
+    out.backward(rnd((4, H), 5))
+    assert torch.equal(out, hid[rows])
+    ref = torch.zeros_like(hid)
+    ref[rows] = rnd((4, H), 5)
+    assert torch.equal(y.grad, ref)
+
+
+def test_cast_roundtrip():
+    x = rnd((1000003,), 1)
+    b = ops.cast(x, torch.bfloat16)
+    assert torch.equal(b, x.to(torch.bfloat16))
+    assert torch.equal(ops.cast(b, torch.float32), b.float())

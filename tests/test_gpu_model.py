@@ -1,0 +1,290 @@
+"""Model-level parity on the GPU: the HIP path (through the reference-shaped modules) against
+  (1) the committed golden vectors produced by the reference itself, and
+  (2) the CPU oracle run on the box on the same seeded inputs.
+fp32 mode is held to the north-star tolerance (1e-3 relative, argmax bit-exact); bf16 mode is
+checked against the same vectors at bf16 resolution (SURVEY.md §7 'Tolerance vs bf16')."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+import uc2_amd
+from oracle import specs
+from oracle import uc2_oracle as O
+from uc2_amd import ops
+from uc2_amd.model.itm import VLXLMRForImageTextRetrieval
+from uc2_amd.model.layer import BertLayer
+from uc2_amd.model.model import VLXLMRConfig, VLXLMRForPretraining
+from uc2_amd.optim.adamw import AdamW, clip_grad_norm_
+from uc2_amd.optim.misc import param_groups
+from uc2_amd.store import set_compute_dtype
+from uc2_amd.utils import synth
+from util import check_against_golden, golden, max_rel, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL32 = 1e-3          # north_star: within 1e-3 relative fp32
+
+
+def make_cfg(geom, drop=0.0):
+    d = dict(hidden_act="gelu", hidden_dropout_prob=drop, attention_probs_dropout_prob=drop,
+             max_position_embeddings=514, type_vocab_size=2, initializer_range=0.02, layer_norm_eps=1e-5,
+             pad_token_id=1)
+    d.update(geom)
+    return VLXLMRConfig.from_dict(d)
+
+
+def strip(b):
+    return {k: v for k, v in b.items() if not k.startswith("_")}
+
+
+def to_dev(b):
+    return {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in strip(b).items()}
+
+
+def build_pretrain(geom, dtype):
+    model = VLXLMRForPretraining(make_cfg(geom), img_dim=2048, img_label_dim=1601)
+    synth.det_init_(model)
+    model.to(DEV).train()
+    set_compute_dtype(model, dtype)
+    return model
+
+
+# ------------------------------------------------------------------------------------------ one layer
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("geom,B,L", [(O.TINY, 5, 68), (O.BASE, 2, 96)])
+def test_bert_layer_vs_oracle(dtype, geom, B, L):
+    cfg = make_cfg(geom)
+    layer = BertLayer(cfg)
+    synth.det_init_(layer)
+    W = OrderedDict((n, p.detach().clone()) for n, p in layer.named_parameters())
+    layer.to(DEV).train()
+    set_compute_dtype(layer, dtype)
+    H = cfg.hidden_size
+    x = synth.det_normal((B, L, H), 11)
+    am = torch.ones(B, L, dtype=torch.long)
+    am[0, L - 7:] = 0
+    ext = O.extended_mask(am)
+    dy = synth.det_normal((B, L, H), 12)
+    # oracle (CPU, fp32 autograd over plain ops)
+    xo = x.clone().requires_grad_(True)
+    Wg = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in W.items())
+    yo = O.bert_layer(xo, ext, Wg, "", cfg.num_attention_heads)
+    yo.backward(dy)
+    # HIP path
+    xd = x.to(DEV).to(dtype).requires_grad_(True)
+    yd = layer(xd, ext.to(DEV))
+    yd.backward(dy.to(DEV).to(dtype))
+    t_out, t_grad = (TOL32, 2e-3) if dtype == torch.float32 else (3e-2, 4e-2)
+    assert max_rel(yd.float().cpu(), yo.detach()) < t_out
+    assert rel_err(xd.grad.float().cpu(), xo.grad) < t_grad
+    qb = Wg["attention.self.query.bias"].grad.norm().item()
+    for n, p in layer.named_parameters():
+        ref = Wg[n].grad
+        if n.endswith("key.bias"):          # mathematically zero (softmax is shift invariant): noise only
+            assert p.grad.norm().item() < 1e-3 * qb and ref.norm().item() < 1e-3 * qb
+            continue
+        e = rel_err(p.grad.cpu(), ref)
+        assert e < t_grad, "%s grad rel err %.3e" % (n, e)
+
+
+def test_bert_layer_dropout_runs_and_is_reproducible():
+    cfg = make_cfg(O.TINY, drop=0.1)
+    layer = BertLayer(cfg)
+    synth.det_init_(layer)
+    layer.to(DEV).train()
+    x = synth.det_normal((4, 68, 128), 3).to(DEV)
+    ext = torch.zeros(4, 1, 1, 68, device=DEV)
+    ops.rng.manual_seed(77)
+    y1 = layer(x, ext)
+    ops.rng.manual_seed(77)
+    y2 = layer(x, ext)
+    y3 = layer(x, ext)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    layer.eval()
+    assert torch.equal(layer(x, ext), layer(x, ext))
+
+
+# ------------------------------------------------------------------------------------------ whole model vs golden
+def run_task(model, batch, task):
+    b = to_dev(batch)
+    model.zero_grad()
+    seq = model.roberta(b["input_ids"], None, b["img_feat"], b["img_pos_feat"], b["attn_masks"], b["gather_index"],
+                        img_masks=b.get("img_masks"), output_all_encoded_layers=False)
+    scores = model(b, task, compute_loss=False)
+    scores = scores[0] if isinstance(scores, tuple) else scores
+    model.zero_grad()
+    loss = model(b, task, compute_loss=True)
+    loss = loss[0] if isinstance(loss, tuple) else loss
+    loss.mean().backward()
+    return seq, scores, loss
+
+
+@pytest.mark.parametrize("tag,B,var,tasks", [("tiny8", 8, False, ["itm", "mlm", "mrfr", "mrc", "mrc-kl", "vmlm"]),
+                                             ("tiny8var", 8, True, ["itm", "mlm"]),
+                                             ("tiny64", 64, False, ["itm", "mlm"])])
+def test_pretrain_fp32_vs_golden(tag, B, var, tasks):
+    g = golden("tiny")
+    model = build_pretrain(O.TINY, torch.float32)
+    for task in tasks:
+        batch = synth.make_batch(1000, B, 32, 36, task=task, seed=1, variable_len=var)
+        seq, scores, loss = run_task(model, batch, task)
+        key = "%s/%s" % (tag, task)
+        check_against_golden(g, key + "/seq", seq, TOL32)
+        check_against_golden(g, key + "/scores", scores, TOL32)
+        check_against_golden(g, key + "/loss", loss, TOL32)
+        if key + "/argmax" in g.files:
+            assert np.array_equal(scores.argmax(-1).cpu().numpy(), g[key + "/argmax"])    # bit-exact labels
+        n = 0
+        for name, p in model.named_parameters():
+            k = "%s/grad/%s" % (key, name)
+            if k + "/sum3" not in g.files:
+                continue
+            if float(g[k + "/sum3"][2]) < 1e-7:
+                assert p.grad is None or p.grad.norm().item() < 1e-5
+            else:
+                assert p.grad is not None, name
+                check_against_golden(g, k, p.grad, 3e-3, what=task)
+            n += 1
+        assert n > 40
+
+
+def test_itm_rank_fp32_vs_golden():
+    g = golden("tiny")
+    model = VLXLMRForImageTextRetrieval(make_cfg(O.TINY), img_dim=2048, margin=0.2)
+    synth.det_init_(model)
+    model.to(DEV).train()
+    b = to_dev(synth.make_batch(1000, 12, 32, 36, task="rank", seed=2, variable_len=True, sample_size=3))
+    check_against_golden(g, "rank/scores", model(b, compute_loss=False), TOL32)
+    loss = model(b, compute_loss=True)
+    check_against_golden(g, "rank/loss", loss, TOL32)
+    loss.mean().backward()
+    for name, p in model.named_parameters():
+        k = "rank/grad/%s" % name
+        if k + "/sum3" in g.files and float(g[k + "/sum3"][2]) > 1e-7:
+            check_against_golden(g, k, p.grad, 1e-2)
+
+
+@pytest.mark.parametrize("task", ["itm", "mlm"])
+def test_pretrain_bf16_vs_golden(task):
+    """throughput mode (bf16 MFMA GEMMs, fp32 statistics) against the fp32 reference at bf16 resolution"""
+    g = golden("tiny")
+    model = build_pretrain(O.TINY, torch.bfloat16)
+    batch = synth.make_batch(1000, 8, 32, 36, task=task, seed=1)
+    seq, scores, loss = run_task(model, batch, task)
+    key = "tiny8/%s" % task
+    check_against_golden(g, key + "/seq", seq, 6e-2)
+    check_against_golden(g, key + "/loss", loss, 3e-2)
+    ref_lm = float(g[key + "/loss/sum3"][0]) / loss.numel()
+    assert abs(loss.mean().item() - ref_lm) < 5e-3 * abs(ref_lm)
+    for name in ("roberta.encoder.layer.0.attention.self.query.weight", "roberta.encoder.layer.1.output.dense.weight",
+                 "roberta.img_embeddings.img_linear.weight"):
+        p = dict(model.named_parameters())[name]
+        check_against_golden(g, "%s/grad/%s" % (key, name), p.grad, 6e-2, metric="l2")
+
+
+@pytest.mark.parametrize("task", ["itm", "mlm"])
+def test_pretrain_base_geometry_fp32_vs_golden(task):
+    """BASELINE.json configs[1] geometry (12L/768H, vocab 250002, 60 tokens + 36 regions), B=4"""
+    g = golden("base")
+    model = build_pretrain(O.BASE, torch.float32)
+    batch = synth.make_batch(250002, 4, 60, 36, task=task, seed=1)
+    seq, scores, loss = run_task(model, batch, task)
+    key = "base4/%s" % task
+    check_against_golden(g, key + "/seq", seq, TOL32)
+    check_against_golden(g, key + "/loss", loss, TOL32)
+    assert np.array_equal(scores.argmax(-1).cpu().numpy(), g[key + "/argmax"])
+    P = dict(model.named_parameters())
+    for name in ("roberta.encoder.layer.0.attention.self.query.weight", "roberta.encoder.layer.11.output.dense.weight",
+                 "roberta.img_embeddings.img_linear.weight", "roberta.embeddings.LayerNorm.weight"):
+        check_against_golden(g, "%s/grad/%s" % (key, name), P[name].grad, 3e-3)
+    del model
+    torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------ optimizer
+def test_adamw_clip_vs_golden():
+    """3 optimizer steps x 3 summed micro-batches, both param groups, clipping, per-parameter step
+    counts (heads untouched by a task keep grad None and are skipped) -- against the reference's AdamW."""
+    g = golden("adamw")
+    model = build_pretrain(O.TINY, torch.float32)
+    groups = param_groups(model, 0.01)
+    names = dict((id(p), n) for n, p in model.named_parameters())
+    assert [names[id(p)] for p in groups[1]["params"]] == list(g["adamw/no_decay_names"])
+    opt = AdamW(groups, lr=4e-5, betas=(0.9, 0.98))
+    P = dict(model.named_parameters())
+    for step in range(1, 4):
+        lr = O.warmup_linear(step, 2, 10) * 4e-5 + 1e-5
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        task = ["itm", "mlm", "mrfr"][step - 1]
+        opt.zero_grad()
+        for micro in range(3):
+            b = to_dev(synth.make_batch(1000, 4, 32, 36, task=task, seed=10 * step + micro))
+            loss = model(b, task, compute_loss=True)
+            loss = loss[0] if isinstance(loss, tuple) else loss
+            loss.mean().backward()
+        gn = clip_grad_norm_([p for p in model.parameters() if p.grad is not None], 5.0 if step > 1 else 0.05)
+        ref_gn = float(g["adamw/step%d/grad_norm" % step][0])
+        assert abs(gn.item() - ref_gn) < 2e-3 * ref_gn
+        opt.step()
+        pre = "adamw/step%d/" % step
+        for key in g.files:
+            if key.startswith(pre) and key.endswith("/sum3") and "_norm" not in key:
+                n = key[len(pre):-len("/sum3")]
+                check_against_golden(g, pre + n, P[n].data, 2e-5)
+        tot = torch.sqrt(sum((p.data.double() ** 2).sum() for p in model.parameters())).item()
+        assert abs(tot - float(g[pre + "param_norm"][0])) < 2e-6 * tot
+    # state_dict surface of the reference optimizer
+    sd = opt.state_dict()
+    some = next(iter(sd["state"].values()))
+    assert set(some.keys()) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_adamw_bf16_shadow_and_fused_clip():
+    model = build_pretrain(O.TINY, torch.bfloat16)
+    opt = AdamW(param_groups(model, 0.01), lr=1e-3, betas=(0.9, 0.98))
+    b = to_dev(synth.make_batch(1000, 4, 32, 36, task="itm", seed=3))
+    loss, _ = model(b, "itm")
+    loss.mean().backward()
+    st = uc2_amd.store.store_of(model)
+    norm, coef = clip_grad_norm_([p for p in model.parameters() if p.grad is not None], 1e-3, fused=True)
+    before = st.data.clone()
+    opt.step(grad_scale=coef, zero_grad=True)
+    assert not torch.equal(before, st.data)
+    assert st.shadow_version == st.version
+    w = model.roberta.encoder.layer[0].output.dense.weight
+    assert torch.equal(st.view(st.shadow, w), w.data.to(torch.bfloat16))
+    assert all(p.grad is None for p in model.parameters())
+    assert st.grad.abs().max().item() == 0.0
+
+
+# ------------------------------------------------------------------------------------------ full-size properties
+def test_base_geometry_bf16_properties():
+    """size-independent properties at the bench geometry: batch rows are independent (permutation
+    equivariance), padded keys do not influence valid rows, eval is deterministic"""
+    model = build_pretrain(O.BASE, torch.bfloat16).eval()
+    B = 16
+    batch = to_dev(synth.make_batch(250002, B, 60, 36, task="itm", seed=5))
+    with torch.no_grad():
+        s1, _ = model(batch, "itm", compute_loss=False)
+        perm = torch.randperm(B, device=DEV)
+        pb = {k: (v[perm] if torch.is_tensor(v) and v.shape[0] == B else v) for k, v in batch.items()}
+        s2, _ = model(pb, "itm", compute_loss=False)
+        assert torch.equal(s1[perm], s2)
+        s3, _ = model(batch, "itm", compute_loss=False)
+        assert torch.equal(s1, s3)
+        # mask the last 6 regions of every pair and perturb them: valid-row outputs must not move
+        am = batch["attn_masks"].clone()
+        am[:, -6:] = 0
+        b2 = dict(batch, attn_masks=am)
+        h1 = model.roberta(b2["input_ids"], None, b2["img_feat"], b2["img_pos_feat"], am, b2["gather_index"],
+                           output_all_encoded_layers=False)
+        f2 = b2["img_feat"].clone()
+        f2[:, -6:] += 3.0
+        h2 = model.roberta(b2["input_ids"], None, f2, b2["img_pos_feat"], am, b2["gather_index"],
+                           output_all_encoded_layers=False)
+        assert torch.equal(h1[:, :-6], h2[:, :-6])
+    del model
+    torch.cuda.empty_cache()

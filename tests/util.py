@@ -28,26 +28,26 @@ def max_rel(a, b, floor=None):
     a = torch.as_tensor(a).double().flatten()
     b = torch.as_tensor(b).double().flatten()
     if floor is None:
-        floor = float(b.pow(2).mean().sqrt()) + 1e-30
+        floor = float(b.detach().pow(2).mean().sqrt()) + 1e-30
     return ((a - b).abs() / b.abs().clamp_min(floor)).max().item()
 
 
-def check_against_golden(g, key, t, tol, what=""):
+def check_against_golden(g, key, t, tol, what="", metric="max"):
     """t (tensor) vs golden entry `key`: full tensor if stored, else the 64-point slice and
     the three checksums (sum, abs-sum, l2)."""
     t = t.detach().float().cpu()
     if key + "/full" in g.files:
         ref = torch.from_numpy(g[key + "/full"])
         assert tuple(ref.shape) == tuple(t.shape), (key, ref.shape, t.shape)
-        e = max_rel(t, ref)
-        assert e < tol, "%s %s: max rel err %.3e >= %.1e" % (what, key, e, tol)
+        e = max_rel(t, ref) if metric == "max" else rel_err(t, ref)
+        assert e < tol, "%s %s: %s rel err %.3e >= %.1e" % (what, key, metric, e, tol)
         return e
     sl = torch.from_numpy(g[key + "/slice"])
     idx = synth.slice_idx(t.numel())
     mine = t.flatten()[idx]
     floor = float(g[key + "/sum3"][2]) / max(1.0, t.numel() ** 0.5) + 1e-30     # rms of the full tensor
-    e = max_rel(mine, sl, floor=floor)
-    assert e < tol, "%s %s: slice max rel err %.3e >= %.1e" % (what, key, e, tol)
+    e = max_rel(mine, sl, floor=floor) if metric == "max" else rel_err(mine, sl)
+    assert e < tol, "%s %s: slice %s rel err %.3e >= %.1e" % (what, key, metric, e, tol)
     s = g[key + "/sum3"]
     td = t.double()
     l2 = td.pow(2).sum().sqrt().item()

@@ -6,4 +6,7 @@ HIP behind the C-ABI declared in include/uc2_hip.h (uc2_amd/csrc).
 Importing this package never loads the shared library; the first compute call
 does, and raises if it is missing -- there is no CPU fallback.
 """
+from . import store  # noqa: F401
+from .store import mark_all_dirty, set_compute_dtype  # noqa: F401
+
 __version__ = "0.1.0"

@@ -1,0 +1,105 @@
+"""ctypes binding of libuc2_hip.so (the C-ABI declared in include/uc2_hip.h).
+
+The library is loaded on first use.  If it is missing or a symbol is absent this
+raises: there is NO CPU fallback anywhere in uc2_amd (the oracle under oracle/ is
+test infrastructure and is never imported from here).
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuc2_hip.so")
+_lib = None
+
+P, I, F, U64, I64, SZ = c_void_p, c_int, c_float, c_uint64, c_int64, c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/uc2_hip.h
+SIGNATURES = {
+    "uc2_abi_version": (I, []),
+    "uc2_last_error": (c_char_p, []),
+    "uc2_device_info": (I, [P, P, P, I]),
+    "uc2_gemm": (I, [I, I, I, I, I, I, P, I, P, I, P, I, I, P, I, P, P, I, I, I, P]),
+    "uc2_ln_fwd": (I, [I, I, I, P, P, P, P, F, F, P, U64, P, P, P, P]),
+    "uc2_ln_bwd_workspace": (SZ, [I, I]),
+    "uc2_ln_bwd": (I, [I, I, I, P, P, P, P, P, P, F, P, U64, P, P, P, P, P, P]),
+    "uc2_attn_fwd": (I, [I, I, I, I, I, I, P, P, F, F, P, U64, P, P, P]),
+    "uc2_attn_bwd": (I, [I, I, I, I, I, I, P, P, F, F, P, U64, P, P, P, P, P]),
+    "uc2_attn_mfma_supported": (I, [I, I]),
+    "uc2_position_ids": (I, [I, I, P, I64, P, P]),
+    "uc2_embed_fwd": (I, [I, I, I, P, P, P, I, P, P, P, P, P]),
+    "uc2_embed_bwd": (I, [I, I, I, P, P, P, P, P, P, P, P]),
+    "uc2_gather_rows_fwd": (I, [I, I, I, I, I, P, P, P, P]),
+    "uc2_gather_rows_bwd": (I, [I, I, I, I, I, P, P, P, P]),
+    "uc2_select_rows": (I, [I, I, I, P, I, P, P, I, I, P]),
+    "uc2_colsum_accum": (I, [I, I, I, P, I, P, P, P]),
+    "uc2_add_rowvec": (I, [I, I, I, I, P, P, P, P, P, P]),
+    "uc2_ce_fwd": (I, [I, I, I, P, I, P, I64, P, P, P, P]),
+    "uc2_ce_bwd": (I, [I, I, I, P, I, P, I64, P, P, P]),
+    "uc2_kl_fwd": (I, [I, I, I, P, I, P, P, P, P]),
+    "uc2_kl_bwd": (I, [I, I, I, P, I, P, P, P, P, P]),
+    "uc2_mse": (I, [I, SZ, P, P, P, P, P, P]),
+    "uc2_triplet": (I, [I, I, I, F, P, P, P, P, P]),
+    "uc2_dtanh": (I, [I, SZ, P, P, P, P]),
+    "uc2_dgelu": (I, [I, SZ, P, P, P, P]),
+    "uc2_cast": (I, [I, I, SZ, P, P, P]),
+    "uc2_adamw_chunk_bytes": (SZ, []),
+    "uc2_adamw_step": (I, [P, I, I, I, P, P, P, P, P, P, P, P, P, I, P]),
+    "uc2_sumsq_accum": (I, [SZ, P, P, P]),
+    "uc2_clip_coef": (I, [P, F, P, P, P]),
+    "uc2_scale": (I, [SZ, P, P, F, P]),
+}
+
+
+class Uc2Error(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library and declare every signature; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Uc2Error(
+            "uc2_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C uc2_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise Uc2Error("uc2_amd: symbol %s missing from %s" % (name, LIB_PATH)) from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().uc2_last_error()
+        raise Uc2Error("uc2 kernel call failed (rc=%d): %s" % (rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """raw device pointer of a tensor (None -> NULL)"""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt(dtype):
+    if dtype == torch.float32:
+        return 0
+    if dtype == torch.bfloat16:
+        return 1
+    raise Uc2Error("uc2_amd supports float32 and bfloat16 compute, got %s" % dtype)
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))

@@ -29,13 +29,14 @@ __device__ __forceinline__ void stage_rows(float* dst, const T* __restrict__ src
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_fwd_simple(int B, int L, int nh, const T* __restrict__ qkv,
                                                        const float* __restrict__ mask, float scale,
-                                                       uint32_t thresh, float keep_scale, uint64_t seed,
+                                                       uint32_t thresh, float keep_scale, const uint64_t* __restrict__ seed_ptr, uint64_t seed_imm,
                                                        T* __restrict__ ctx, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Ks = sm;
   float* Vs = sm + L * (D + AT_PAD);
   float* Ms = Vs + L * (D + AT_PAD);
   const int bh = blockIdx.x, b = bh / nh, h = bh - b * nh;
+  const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
   const int H = nh * D, ld = 3 * H;
   const T* base = qkv + (size_t)b * L * ld + h * D;
   stage_rows<T, D>(Ks, base + H, L, ld, threadIdx.x, 256);
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void attn_fwd_simple(int B, int L, int nh, con
 template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_bwd_simple(int B, int L, int nh, const T* __restrict__ qkv,
                                                        const float* __restrict__ mask, float scale,
-                                                       uint32_t thresh, float keep_scale, uint64_t seed,
+                                                       uint32_t thresh, float keep_scale, const uint64_t* __restrict__ seed_ptr, uint64_t seed_imm,
                                                        const T* __restrict__ ctx, const T* __restrict__ dctx,
                                                        const float* __restrict__ lse, T* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256) void attn_bwd_simple(int B, int L, int nh, con
   float* Ls = Ms + L;                          // lse[L]
   float* Ds = Ls + L;                          // delta[L]
   const int bh = blockIdx.x, b = bh / nh, h = bh - b * nh;
+  const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
   const int H = nh * D, ld = 3 * H;
   const T* base = qkv + (size_t)b * L * ld + h * D;
   const T* dob = dctx + (size_t)b * L * H + h * D;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256) void attn_bwd_simple(int B, int L, int nh, con
 
 template <typename T, int D>
 static int launch_fwd(int B, int L, int nh, const void* qkv, const float* mask, float scale, float drop_p,
-                      uint64_t seed, void* ctx, float* lse, hipStream_t st) {
+                      const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse, hipStream_t st) {
   const size_t smem = (size_t)(2 * L * (D + AT_PAD) + L) * sizeof(float);
   auto kern = attn_fwd_simple<T, D>;
   if (smem > 48 * 1024) {
@@ -248,14 +250,14 @@ static int launch_fwd(int B, int L, int nh, const void* qkv, const float* mask, 
     if (e != hipSuccess) { uc2_set_error(__FILE__, __LINE__, hipGetErrorString(e)); return (int)e; }
   }
   hipLaunchKernelGGL(kern, dim3(B * nh), dim3(256), smem, st, B, L, nh, (const T*)qkv, mask, scale,
-                     drop_thresh(drop_p), 1.0f / (1.0f - drop_p), seed, (T*)ctx, lse);
+                     drop_thresh(drop_p), 1.0f / (1.0f - drop_p), seed_ptr, seed_imm, (T*)ctx, lse);
   UC2_LAUNCH_CHECK();
   return 0;
 }
 
 template <typename T, int D>
 static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, float scale, float drop_p,
-                      uint64_t seed, const void* ctx, const void* dctx, const float* lse, void* dqkv,
+                      const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx, const void* dctx, const float* lse, void* dqkv,
                       hipStream_t st) {
   const size_t smem = (size_t)(2 * L * (D + AT_PAD) + 3 * L) * sizeof(float);
   auto kern = attn_bwd_simple<T, D>;
@@ -264,14 +266,14 @@ static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, 
     if (e != hipSuccess) { uc2_set_error(__FILE__, __LINE__, hipGetErrorString(e)); return (int)e; }
   }
   hipLaunchKernelGGL(kern, dim3(B * nh), dim3(256), smem, st, B, L, nh, (const T*)qkv, mask, scale,
-                     drop_thresh(drop_p), 1.0f / (1.0f - drop_p), seed, (const T*)ctx, (const T*)dctx, lse,
+                     drop_thresh(drop_p), 1.0f / (1.0f - drop_p), seed_ptr, seed_imm, (const T*)ctx, (const T*)dctx, lse,
                      (T*)dqkv);
   UC2_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int uc2_attn_fwd_simple(int dtype, int B, int L, int nh, int D, const void* qkv, const float* mask,
-                                   float scale, float drop_p, uint64_t seed, void* ctx, float* lse, void* stream) {
+                                   float scale, float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse, void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
   UC2_CHECK_ARG(D == 32 || D == 64);
   UC2_CHECK_ARG(L >= 1 && L <= 512 && B >= 0 && nh >= 1);
@@ -281,15 +283,15 @@ extern "C" int uc2_attn_fwd_simple(int dtype, int B, int L, int nh, int D, const
   UC2_CHECK_ARG(qkv && ctx);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == 0) {
-    if (D == 32) return launch_fwd<float, 32>(B, L, nh, qkv, mask, scale, drop_p, seed, ctx, lse, st);
-    return launch_fwd<float, 64>(B, L, nh, qkv, mask, scale, drop_p, seed, ctx, lse, st);
+    if (D == 32) return launch_fwd<float, 32>(B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, lse, st);
+    return launch_fwd<float, 64>(B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, lse, st);
   }
-  if (D == 32) return launch_fwd<bf16, 32>(B, L, nh, qkv, mask, scale, drop_p, seed, ctx, lse, st);
-  return launch_fwd<bf16, 64>(B, L, nh, qkv, mask, scale, drop_p, seed, ctx, lse, st);
+  if (D == 32) return launch_fwd<bf16, 32>(B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, lse, st);
+  return launch_fwd<bf16, 64>(B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, lse, st);
 }
 
 extern "C" int uc2_attn_bwd_simple(int dtype, int B, int L, int nh, int D, const void* qkv, const float* mask,
-                                   float scale, float drop_p, uint64_t seed, const void* ctx, const void* dctx,
+                                   float scale, float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx, const void* dctx,
                                    const float* lse, void* dqkv, void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
   UC2_CHECK_ARG(D == 32 || D == 64);
@@ -300,9 +302,42 @@ extern "C" int uc2_attn_bwd_simple(int dtype, int B, int L, int nh, int D, const
   UC2_CHECK_ARG(qkv && ctx && dctx && lse && dqkv);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == 0) {
-    if (D == 32) return launch_bwd<float, 32>(B, L, nh, qkv, mask, scale, drop_p, seed, ctx, dctx, lse, dqkv, st);
-    return launch_bwd<float, 64>(B, L, nh, qkv, mask, scale, drop_p, seed, ctx, dctx, lse, dqkv, st);
+    if (D == 32) return launch_bwd<float, 32>(B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv, st);
+    return launch_bwd<float, 64>(B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv, st);
   }
-  if (D == 32) return launch_bwd<bf16, 32>(B, L, nh, qkv, mask, scale, drop_p, seed, ctx, dctx, lse, dqkv, st);
-  return launch_bwd<bf16, 64>(B, L, nh, qkv, mask, scale, drop_p, seed, ctx, dctx, lse, dqkv, st);
+  if (D == 32) return launch_bwd<bf16, 32>(B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv, st);
+  return launch_bwd<bf16, 64>(B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv, st);
+}
+
+// ---- public dispatch: impl 0 = auto, 1 = simple (fp32 math), 2 = MFMA (bf16 only) ----
+extern "C" int uc2_attn_fwd_mfma(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
+                                 float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse,
+                                 void* stream);
+extern "C" int uc2_attn_bwd_mfma(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
+                                 float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx,
+                                 const void* dctx, const float* lse, void* dqkv, void* stream);
+extern "C" int uc2_attn_mfma_supported(int L, int D);
+
+extern "C" int uc2_attn_fwd(int dtype, int impl, int B, int L, int nh, int D, const void* qkv, const float* mask,
+                            float scale, float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx,
+                            float* lse, void* stream) {
+  UC2_CHECK_ARG(impl >= 0 && impl <= 2);
+  const bool mfma = (impl == 2) || (impl == 0 && dtype == 1 && uc2_attn_mfma_supported(L, D));
+  if (mfma) {
+    UC2_CHECK_ARG(dtype == 1 && uc2_attn_mfma_supported(L, D));
+    return uc2_attn_fwd_mfma(B, L, nh, D, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, lse, stream);
+  }
+  return uc2_attn_fwd_simple(dtype, B, L, nh, D, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, lse, stream);
+}
+extern "C" int uc2_attn_bwd(int dtype, int impl, int B, int L, int nh, int D, const void* qkv, const float* mask,
+                            float scale, float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx,
+                            const void* dctx, const float* lse, void* dqkv, void* stream) {
+  UC2_CHECK_ARG(impl >= 0 && impl <= 2);
+  const bool mfma = (impl == 2) || (impl == 0 && dtype == 1 && uc2_attn_mfma_supported(L, D));
+  if (mfma) {
+    UC2_CHECK_ARG(dtype == 1 && uc2_attn_mfma_supported(L, D));
+    return uc2_attn_bwd_mfma(B, L, nh, D, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv, stream);
+  }
+  return uc2_attn_bwd_simple(dtype, B, L, nh, D, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv,
+                             stream);
 }

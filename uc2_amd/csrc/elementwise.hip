@@ -205,19 +205,22 @@ extern "C" int uc2_select_rows(int dtype, int n, int H, const void* src, int ld_
 }
 
 // ---------------------------------------------------------------------------------------
-// column sum (bias gradients): out[n] += sum_m X[m, n]
+// column sum (bias gradients): out[n] += sum_{m : rowmask[m]} X[m, n]   (rowmask optional)
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const T* __restrict__ X, int ldx,
-                                                     float* __restrict__ out, int rows_per_blk) {
+                                                     const uint8_t* __restrict__ rowmask, float* __restrict__ out,
+                                                     int rows_per_blk) {
   const int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= N) return;
   const int m0 = blockIdx.y * rows_per_blk, m1 = min(M, m0 + rows_per_blk);
   float s = 0.f;
-  for (int m = m0; m < m1; ++m) s += to_f<T>(X[(size_t)m * ldx + n]);
+  for (int m = m0; m < m1; ++m)
+    if (!rowmask || rowmask[m]) s += to_f<T>(X[(size_t)m * ldx + n]);
   atomicAdd(out + n, s);
 }
-extern "C" int uc2_colsum_accum(int dtype, int M, int N, const void* X, int ldx, float* out, void* stream) {
+extern "C" int uc2_colsum_accum(int dtype, int M, int N, const void* X, int ldx, const uint8_t* rowmask, float* out,
+                                void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
   if (M <= 0 || N <= 0) return 0;
   UC2_CHECK_ARG(X && out);
@@ -225,8 +228,54 @@ extern "C" int uc2_colsum_accum(int dtype, int M, int N, const void* X, int ldx,
   if (splits > 256) splits = 256;
   const int rpb = (M + splits - 1) / splits;
   dim3 grid((N + 255) / 256, (M + rpb - 1) / rpb);
-  if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, M, N, (const float*)X, ldx, out, rpb);
-  else hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, M, N, (const bf16*)X, ldx, out, rpb);
+  if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, M, N, (const float*)X, ldx, rowmask, out, rpb);
+  else hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, M, N, (const bf16*)X, ldx, rowmask, out, rpb);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// out[r] = a[r] + b[r] + (rowmask[r] ? vec : 0)     (b, vec, rowmask optional; vec is fp32 [H])
+// image embeddings: feat + mask_embedding (model/model.py:355-356), ti + tp + type row (:360)
+// ---------------------------------------------------------------------------------------
+template <typename TI, typename T>
+__global__ __launch_bounds__(256) void add_rowvec_kernel(int rows, int H, const TI* __restrict__ a,
+                                                         const T* __restrict__ b, const float* __restrict__ vec,
+                                                         const uint8_t* __restrict__ rowmask, T* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const bool use_vec = vec && (!rowmask || rowmask[r]);
+  for (int c = lane * 4; c < H; c += 256) {
+    float v[4];
+    Vec4<TI>::load(a + (size_t)r * H + c, v);
+    if (b) {
+      float w[4];
+      Vec4<T>::load(b + (size_t)r * H + c, w);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += w[e];
+    }
+    if (use_vec) {
+      float w[4];
+      Vec4<float>::load(vec + c, w);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += w[e];
+    }
+    Vec4<T>::store(out + (size_t)r * H + c, v);
+  }
+}
+extern "C" int uc2_add_rowvec(int a_dtype, int dtype, int rows, int H, const void* a, const void* b, const float* vec,
+                              const uint8_t* rowmask, void* out, void* stream) {
+  UC2_CHECK_ARG((a_dtype == 0 || a_dtype == 1) && (dtype == 0 || dtype == 1));
+  UC2_CHECK_ARG((H % 4) == 0);
+  if (rows <= 0) return 0;
+  UC2_CHECK_ARG(a && out);
+  dim3 grid((rows + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (a_dtype == 0 && dtype == 0) hipLaunchKernelGGL((add_rowvec_kernel<float, float>), grid, dim3(256), 0, st, rows, H, (const float*)a, (const float*)b, vec, rowmask, (float*)out);
+  else if (a_dtype == 0 && dtype == 1) hipLaunchKernelGGL((add_rowvec_kernel<float, bf16>), grid, dim3(256), 0, st, rows, H, (const float*)a, (const bf16*)b, vec, rowmask, (bf16*)out);
+  else if (a_dtype == 1 && dtype == 1) hipLaunchKernelGGL((add_rowvec_kernel<bf16, bf16>), grid, dim3(256), 0, st, rows, H, (const bf16*)a, (const bf16*)b, vec, rowmask, (bf16*)out);
+  else hipLaunchKernelGGL((add_rowvec_kernel<bf16, float>), grid, dim3(256), 0, st, rows, H, (const bf16*)a, (const float*)b, vec, rowmask, (float*)out);
   UC2_LAUNCH_CHECK();
   return 0;
 }
@@ -456,6 +505,22 @@ extern "C" int uc2_dtanh(int dtype, size_t n, const void* y, const void* dy, voi
   UC2_CHECK_ARG(y && dy && dx);
   if (dtype == 0) hipLaunchKernelGGL(dtanh_kernel<float>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, n, (const float*)y, (const float*)dy, (float*)dx);
   else hipLaunchKernelGGL(dtanh_kernel<bf16>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, n, (const bf16*)y, (const bf16*)dy, (bf16*)dx);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+// dgelu for head transforms: dx = dy * gelu'(pre)   (model/layer.py:31-37)
+template <typename T>
+__global__ void dgelu_kernel(size_t n, const T* __restrict__ pre, const T* __restrict__ dy, T* __restrict__ dx) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dx[i] = from_f<T>(to_f<T>(dy[i]) * dgelu_f(to_f<T>(pre[i])));
+}
+extern "C" int uc2_dgelu(int dtype, size_t n, const void* pre, const void* dy, void* dx, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  if (n == 0) return 0;
+  UC2_CHECK_ARG(pre && dy && dx);
+  if (dtype == 0) hipLaunchKernelGGL(dgelu_kernel<float>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, n, (const float*)pre, (const float*)dy, (float*)dx);
+  else hipLaunchKernelGGL(dgelu_kernel<bf16>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, n, (const bf16*)pre, (const bf16*)dy, (bf16*)dx);
   UC2_LAUNCH_CHECK();
   return 0;
 }

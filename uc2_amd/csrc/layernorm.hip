@@ -14,12 +14,13 @@
 template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int H, const T* __restrict__ x, const T* __restrict__ res,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float eps, uint32_t thresh, float keep_scale, uint64_t seed,
-                                                     T* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+                                                     float eps, uint32_t thresh, float keep_scale, const uint64_t* __restrict__ seed_ptr,
+                                                     uint64_t seed_imm, T* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int nch = H >> 2;
+  const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
   float v[LN_MAXC][4];
   float s = 0.f;
 #pragma unroll
@@ -79,11 +80,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __restrict__ dy, const T* __restrict__ x,
                                                      const T* __restrict__ res, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
-                                                     uint32_t thresh, float keep_scale, uint64_t seed,
-                                                     T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ ws) {
+                                                     uint32_t thresh, float keep_scale, const uint64_t* __restrict__ seed_ptr,
+                                                     uint64_t seed_imm, T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ ws) {
   __shared__ float red[4][2][LN_MAXC * 4 * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nch = H >> 2;
+  const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
   float dg[LN_MAXC][4], db[LN_MAXC][4];
 #pragma unroll
   for (int i = 0; i < LN_MAXC; ++i)
@@ -182,7 +184,7 @@ static int ln_bwd_blocks(int M) {
 }
 
 extern "C" int uc2_ln_fwd(int dtype, int M, int H, const void* x, const void* residual, const float* gamma,
-                          const float* beta, float eps, float drop_p, uint64_t seed, void* y, float* mean,
+                          const float* beta, float eps, float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, void* y, float* mean,
                           float* rstd, void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
   UC2_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= LN_MAXC * 256);
@@ -195,10 +197,10 @@ extern "C" int uc2_ln_fwd(int dtype, int M, int H, const void* x, const void* re
   hipStream_t st = (hipStream_t)stream;
   if (dtype == 0)
     hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, st, M, H, (const float*)x, (const float*)residual, gamma,
-                       beta, eps, th, ks, seed, (float*)y, mean, rstd);
+                       beta, eps, th, ks, seed_ptr, seed_imm, (float*)y, mean, rstd);
   else
     hipLaunchKernelGGL(ln_fwd_kernel<bf16>, grid, block, 0, st, M, H, (const bf16*)x, (const bf16*)residual, gamma,
-                       beta, eps, th, ks, seed, (bf16*)y, mean, rstd);
+                       beta, eps, th, ks, seed_ptr, seed_imm, (bf16*)y, mean, rstd);
   UC2_LAUNCH_CHECK();
   return 0;
 }
@@ -206,8 +208,8 @@ extern "C" int uc2_ln_fwd(int dtype, int M, int H, const void* x, const void* re
 extern "C" size_t uc2_ln_bwd_workspace(int M, int H) { return (size_t)ln_bwd_blocks(M) * 2 * H * sizeof(float); }
 
 extern "C" int uc2_ln_bwd(int dtype, int M, int H, const void* dy, const void* x, const void* residual,
-                          const float* gamma, const float* mean, const float* rstd, float drop_p, uint64_t seed,
-                          void* dx, void* dres, float* dgamma, float* dbeta, void* ws, void* stream) {
+                          const float* gamma, const float* mean, const float* rstd, float drop_p, const uint64_t* seed_ptr,
+                          uint64_t seed_imm, void* dx, void* dres, float* dgamma, float* dbeta, void* ws, void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
   UC2_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= LN_MAXC * 256);
   UC2_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
@@ -219,10 +221,10 @@ extern "C" int uc2_ln_bwd(int dtype, int M, int H, const void* dy, const void* x
   hipStream_t st = (hipStream_t)stream;
   if (dtype == 0)
     hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, M, H, (const float*)dy, (const float*)x,
-                       (const float*)residual, gamma, mean, rstd, th, ks, seed, (float*)dx, (float*)dres, (float*)ws);
+                       (const float*)residual, gamma, mean, rstd, th, ks, seed_ptr, seed_imm, (float*)dx, (float*)dres, (float*)ws);
   else
     hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, M, H, (const bf16*)dy, (const bf16*)x,
-                       (const bf16*)residual, gamma, mean, rstd, th, ks, seed, (bf16*)dx, (bf16*)dres, (float*)ws);
+                       (const bf16*)residual, gamma, mean, rstd, th, ks, seed_ptr, seed_imm, (bf16*)dx, (bf16*)dres, (float*)ws);
   UC2_LAUNCH_CHECK();
   if (dgamma || dbeta) {
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * H + 255) / 256), dim3(256), 0, st, nb, H, (const float*)ws,

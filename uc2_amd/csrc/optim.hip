@@ -12,21 +12,30 @@
 
 #define UC2_ADAM_MAX_GROUPS 8
 
-struct AdamChunk {
+struct AdamChunk {            // mirrored by uc2_amd/optim/adamw.py (48 bytes)
   float* p; float* g; float* m; float* v; bf16* p16;
-  uint32_t n; uint32_t group;
+  uint32_t n; uint16_t group; uint16_t param;
 };
 struct AdamGroups {
   float lr[UC2_ADAM_MAX_GROUPS], beta1[UC2_ADAM_MAX_GROUPS], beta2[UC2_ADAM_MAX_GROUPS];
-  float eps[UC2_ADAM_MAX_GROUPS], wd[UC2_ADAM_MAX_GROUPS], step_size[UC2_ADAM_MAX_GROUPS];
+  float eps[UC2_ADAM_MAX_GROUPS], wd[UC2_ADAM_MAX_GROUPS];
+  int correct_bias[UC2_ADAM_MAX_GROUPS];
 };
 
+// steps[param] holds the number of updates already applied to that parameter (per-parameter, like
+// state['step'] at adamw.py:74); active[param] == 0 means "p.grad is None": skipped entirely (adamw.py:52-53).
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict__ chunks, AdamGroups gs,
+                                                    const int* __restrict__ active, const int* __restrict__ steps,
                                                     const float* __restrict__ gscale, int zero_grad) {
   const AdamChunk c = chunks[blockIdx.x];
+  if (active && !active[c.param]) return;
   const int gi = c.group;
   const float lr = gs.lr[gi], b1 = gs.beta1[gi], b2 = gs.beta2[gi], eps = gs.eps[gi], wd = gs.wd[gi];
-  const float ss = gs.step_size[gi];
+  float ss = lr;
+  if (gs.correct_bias[gi]) {
+    const double t = (double)(steps[c.param] + 1);
+    ss = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+  }
   const float sc = gscale ? *gscale : 1.0f;
   const bool vec = (((uintptr_t)c.p | (uintptr_t)c.g | (uintptr_t)c.m | (uintptr_t)c.v) & 15) == 0 &&
                    (((uintptr_t)c.p16 & 7) == 0);
@@ -62,24 +71,32 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict_
     if (zero_grad) c.g[i] = 0.f;
   }
 }
+__global__ void adamw_bump_kernel(int n_params, const int* __restrict__ active, int* __restrict__ steps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_params && (!active || active[i])) steps[i] += 1;
+}
 
 extern "C" size_t uc2_adamw_chunk_bytes(void) { return sizeof(AdamChunk); }
 
-// chunks: DEVICE pointer to n_chunks AdamChunk records (layout = include/uc2_hip.h uc2_adam_chunk)
-extern "C" int uc2_adamw_step(const void* chunks, int n_chunks, int n_groups, const float* lr, const float* beta1,
-                              const float* beta2, const float* eps, const float* weight_decay,
-                              const float* step_size, const float* grad_scale_dev, int zero_grad, void* stream) {
+// chunks: DEVICE pointer to n_chunks AdamChunk records; active/steps: DEVICE int32 [n_params]
+extern "C" int uc2_adamw_step(const void* chunks, int n_chunks, int n_params, int n_groups, const float* lr,
+                              const float* beta1, const float* beta2, const float* eps, const float* weight_decay,
+                              const int* correct_bias, const int* active_dev, int* steps_dev,
+                              const float* grad_scale_dev, int zero_grad, void* stream) {
   UC2_CHECK_ARG(n_groups >= 1 && n_groups <= UC2_ADAM_MAX_GROUPS);
   if (n_chunks <= 0) return 0;
-  UC2_CHECK_ARG(chunks && lr && beta1 && beta2 && eps && weight_decay && step_size);
+  UC2_CHECK_ARG(chunks && lr && beta1 && beta2 && eps && weight_decay && correct_bias && steps_dev);
   AdamGroups gs;
   for (int i = 0; i < UC2_ADAM_MAX_GROUPS; ++i) {
     const int j = i < n_groups ? i : 0;
     gs.lr[i] = lr[j]; gs.beta1[i] = beta1[j]; gs.beta2[i] = beta2[j]; gs.eps[i] = eps[j];
-    gs.wd[i] = weight_decay[j]; gs.step_size[i] = step_size[j];
+    gs.wd[i] = weight_decay[j]; gs.correct_bias[i] = correct_bias[j];
   }
   hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)chunks, gs,
-                     grad_scale_dev, zero_grad);
+                     active_dev, (const int*)steps_dev, grad_scale_dev, zero_grad);
+  UC2_LAUNCH_CHECK();
+  hipLaunchKernelGGL(adamw_bump_kernel, dim3((n_params + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_params,
+                     active_dev, steps_dev);
   UC2_LAUNCH_CHECK();
   return 0;
 }

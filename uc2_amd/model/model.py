@@ -1,0 +1,484 @@
+"""VL-XLM-R model shells with the reference's names, signatures, batch-dict keys and state_dict
+layout (reference model/model.py:1-776, 1143-1169), computing on the uc2 HIP kernels.
+
+Drop-in for:  VLXLMRConfig, VLXLMRPreTrainedModel (from_pretrained / init_weights),
+VLXLMRTextEmbeddings, VLXLMRImageEmbeddings, VLXLMREncoder, VLXLMRModel,
+VLXLMRForPretraining, RegionFeatureRegression, RegionClassification, pad_tensor_to_mul.
+Out of the hot path and not provided: the OT regulariser (ot_inputs) and the *-soft tasks
+(SURVEY.md §2.1, §8a a17).
+"""
+import copy
+import json
+import logging
+from collections import defaultdict
+from io import open
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..store import compute_dtype_of, mark_all_dirty, store_of
+from .layer import (GELU, BertLayer, BertLayerNorm, BertPooler, Linear, RobertaLMHead, VisualRobertaLMHead)
+
+logger = logging.getLogger(__name__)
+LayerNorm = BertLayerNorm
+
+# the reference derives this list from the XLM-R tokenizer at import time (model/const_variable.py);
+# it only sizes the never-called vis_cls head.  Override before constructing a model if needed.
+VALID_XLMR_TOKEN_IDS = list(range(5, 50))
+
+
+def xlmr_sublayer_loading(state_dict, load_embedding_only=False, load_layer=0):
+    """model/model.py:24-41"""
+    old_keys, new_keys = [], []
+    if load_embedding_only:
+        for key in state_dict.keys():
+            if "roberta.embeddings" not in key:
+                old_keys.append(key)
+                new_keys.append("not_load." + key)
+    elif load_layer:
+        assert isinstance(load_layer, int) and load_layer > 0
+        for key in state_dict.keys():
+            if "roberta.encoder" in key and int(key.split('.')[3]) > load_layer:
+                old_keys.append(key)
+                new_keys.append("not_load." + key)
+    for new_key, old_key in zip(new_keys, old_keys):
+        state_dict[new_key] = state_dict.pop(old_key)
+
+
+class VLXLMRConfig(object):
+    """model/model.py:45-141 (same fields, same constructors)."""
+
+    def __init__(self, vocab_size_or_config_json_file, hidden_size=768, num_hidden_layers=12,
+                 num_attention_heads=12, intermediate_size=3072, hidden_act="gelu",
+                 hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, max_position_embeddings=514,
+                 type_vocab_size=2, initializer_range=0.02, output_past=True, layer_norm_eps=1e-5,
+                 pad_token_id=1):
+        if isinstance(vocab_size_or_config_json_file, str):
+            with open(vocab_size_or_config_json_file, "r", encoding='utf-8') as reader:
+                json_config = json.loads(reader.read())
+            for key, value in json_config.items():
+                self.__dict__[key] = value
+        elif isinstance(vocab_size_or_config_json_file, int):
+            self.vocab_size = vocab_size_or_config_json_file
+            self.hidden_size = hidden_size
+            self.num_hidden_layers = num_hidden_layers
+            self.num_attention_heads = num_attention_heads
+            self.hidden_act = hidden_act
+            self.intermediate_size = intermediate_size
+            self.hidden_dropout_prob = hidden_dropout_prob
+            self.attention_probs_dropout_prob = attention_probs_dropout_prob
+            self.max_position_embeddings = max_position_embeddings
+            self.type_vocab_size = type_vocab_size
+            self.initializer_range = initializer_range
+            self.layer_norm_eps = layer_norm_eps
+            self.pad_token_id = pad_token_id
+        else:
+            raise ValueError("First argument must be either a vocabulary size (int) or the path to a "
+                             "pretrained model config file (str)")
+
+    @classmethod
+    def from_dict(cls, json_object):
+        config = VLXLMRConfig(vocab_size_or_config_json_file=-1)
+        for key, value in json_object.items():
+            config.__dict__[key] = value
+        return config
+
+    @classmethod
+    def from_json_file(cls, json_file):
+        with open(json_file, "r", encoding='utf-8') as reader:
+            text = reader.read()
+        return cls.from_dict(json.loads(text))
+
+    def __repr__(self):
+        return str(self.to_json_string())
+
+    def to_dict(self):
+        return copy.deepcopy(self.__dict__)
+
+    def to_json_string(self):
+        return json.dumps(self.to_dict(), indent=2, sort_keys=True) + "\n"
+
+
+class VLXLMRPreTrainedModel(nn.Module):
+    """model/model.py:143-278: weight init and from_pretrained key surgery."""
+
+    def __init__(self, config, *inputs, **kwargs):
+        super().__init__()
+        if not isinstance(config, VLXLMRConfig):
+            raise ValueError("Parameter config in `{}(config)` should be an instance of class `VLXLMRConfig`."
+                             .format(self.__class__.__name__))
+        self.config = config
+
+    def init_weights(self, module):
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            module.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
+        elif isinstance(module, BertLayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+        if isinstance(module, nn.Linear) and module.bias is not None:
+            module.bias.data.zero_()
+
+    def zero_grad(self, set_to_none=True):
+        st = store_of(self)
+        if st is not None:
+            st.zero_grad()
+        else:
+            super().zero_grad(set_to_none)
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        mark_all_dirty()
+        return r
+
+    @classmethod
+    def from_pretrained(cls, config_file, state_dict, load_embedding_only=False, load_layer=None, *inputs, **kwargs):
+        config = VLXLMRConfig.from_json_file(config_file)
+        logger.info("Model config {}".format(config))
+        model = cls(config, *inputs, **kwargs)
+        old_keys, new_keys = [], []
+        if load_embedding_only:
+            xlmr_sublayer_loading(state_dict, load_embedding_only=True)
+        elif load_layer is not None:
+            xlmr_sublayer_loading(state_dict, load_layer=load_layer)
+        else:
+            for key in state_dict.keys():
+                new_key = None
+                if 'gamma' in key:
+                    new_key = key.replace('gamma', 'weight')
+                if 'beta' in key:
+                    new_key = key.replace('beta', 'bias')
+                if new_key:
+                    old_keys.append(key)
+                    new_keys.append(new_key)
+            for old_key, new_key in zip(old_keys, new_keys):
+                state_dict[new_key] = state_dict.pop(old_key)
+        missing_keys, unexpected_keys, error_msgs = [], [], []
+        metadata = getattr(state_dict, '_metadata', None)
+        state_dict = state_dict.copy()
+        if metadata is not None:
+            state_dict._metadata = metadata
+
+        def load(module, prefix=''):
+            local_metadata = ({} if metadata is None else metadata.get(prefix[:-1], {}))
+            module._load_from_state_dict(state_dict, prefix, local_metadata, True, missing_keys,
+                                         unexpected_keys, error_msgs)
+            for name, child in module._modules.items():
+                if child is not None:
+                    load(child, prefix + name + '.')
+        start_prefix = ''
+        if not hasattr(model, 'roberta.bert.') and any(s.startswith('roberta.bert.') for s in state_dict.keys()):
+            start_prefix = 'roberta.bert.'
+        load(model, prefix=start_prefix)
+        if len(missing_keys) > 0:
+            logger.info("Weights of {} not initialized from pretrained model: {}".format(
+                model.__class__.__name__, missing_keys))
+        if len(unexpected_keys) > 0:
+            logger.info("Weights from pretrained model not used in {}: {}".format(
+                model.__class__.__name__, unexpected_keys))
+        if len(error_msgs) > 0:
+            raise RuntimeError('Error(s) in loading state_dict for {}:\n\t{}'.format(
+                model.__class__.__name__, "\n\t".join(error_msgs)))
+        mark_all_dirty()
+        return model
+
+
+def create_position_ids_from_input_ids(input_ids, padding_idx):
+    """model/model.py:280-290 on the device: cumsum of non-pad tokens (+ pad id)."""
+    ids = input_ids.contiguous()
+    out = torch.empty_like(ids)
+    B, T = ids.shape
+    ops.call("uc2_position_ids", B, T, ops.ptr(ids), int(padding_idx), ops.ptr(out), ops.stream())
+    return out
+
+
+class VLXLMRTextEmbeddings(nn.Module):
+    """model/model.py:292-335"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.padding_idx = config.pad_token_id
+        self.word_embeddings = nn.Embedding(config.vocab_size, config.hidden_size, padding_idx=config.pad_token_id)
+        self.position_embeddings = nn.Embedding(config.max_position_embeddings, config.hidden_size,
+                                                padding_idx=config.pad_token_id)
+        self.new_token_type_embeddings = nn.Embedding(config.type_vocab_size, config.hidden_size)
+        self.LayerNorm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def forward(self, input_ids=None, position_ids=None, token_type_ids=None):
+        if position_ids is None:
+            position_ids = create_position_ids_from_input_ids(input_ids, self.padding_idx)
+        elif position_ids.shape != input_ids.shape:
+            position_ids = position_ids.expand_as(input_ids)
+        e = ops.EmbedTextFn.apply(self, compute_dtype_of(self), input_ids, position_ids, token_type_ids,
+                                  self.word_embeddings.weight, self.position_embeddings.weight,
+                                  self.new_token_type_embeddings.weight)
+        p = self.dropout.p if self.training else 0.0
+        return self.LayerNorm(e, None, p, 0x7E01)
+
+
+class VLXLMRImageEmbeddings(nn.Module):
+    """model/model.py:339-364"""
+
+    def __init__(self, config, img_dim):
+        super().__init__()
+        self.img_linear = Linear(img_dim, config.hidden_size)
+        self.img_layer_norm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.pos_layer_norm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.pos_linear = Linear(7, config.hidden_size)
+        self.mask_embedding = nn.Embedding(2, img_dim, padding_idx=0)
+        self.LayerNorm = LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def forward(self, img_feat, img_pos_feat, type_embeddings, img_masks=None):
+        """type_embeddings: the new_token_type_embeddings Parameter (image rows use row 1,
+        model/model.py:404) or an explicit [B,R,H] tensor when img_type_ids were given."""
+        cd = compute_dtype_of(self)
+        if img_masks is not None:
+            self.mask_embedding.weight.data[0, :].fill_(0)            # model/model.py:354 (in place)
+            img_feat = ops.MaskEmbedFn.apply(self, img_feat, img_masks, self.mask_embedding.weight, cd)
+        ti = self.img_layer_norm(self.img_linear(ops.cast(img_feat, cd)))
+        tp = self.pos_layer_norm(self.pos_linear(ops.cast(img_pos_feat, cd)))
+        p = self.dropout.p if self.training else 0.0
+        if isinstance(type_embeddings, nn.Parameter):
+            # + type row 1 for every region == a constant added to the affine shift of the last LN input
+            s = ops.AddRowFn.apply(ti, tp, type_embeddings, 1)
+        else:
+            s = ti + tp + ops.cast(type_embeddings, cd)
+        return self.LayerNorm(s, None, p, 0x7E02)
+
+
+class VLXLMREncoder(nn.Module):
+    """model/model.py:366-383"""
+
+    def __init__(self, config):
+        super().__init__()
+        layer = BertLayer(config)
+        self.layer = nn.ModuleList([copy.deepcopy(layer) for _ in range(config.num_hidden_layers)])
+
+    def forward(self, input_, attention_mask, output_all_encoded_layers=True):
+        all_encoder_layers = []
+        hidden_states = input_
+        for layer_module in self.layer:
+            hidden_states = layer_module(hidden_states, attention_mask)
+            if output_all_encoded_layers:
+                all_encoder_layers.append(hidden_states)
+        if not output_all_encoded_layers:
+            all_encoder_layers.append(hidden_states)
+        return all_encoder_layers
+
+
+class VLXLMRModel(VLXLMRPreTrainedModel):
+    """model/model.py:385-458"""
+
+    def __init__(self, config, img_dim):
+        super().__init__(config)
+        self.embeddings = VLXLMRTextEmbeddings(config)
+        self.img_embeddings = VLXLMRImageEmbeddings(config, img_dim)
+        self.encoder = VLXLMREncoder(config)
+        self.pooler = BertPooler(config)
+        self.apply(self.init_weights)
+
+    def _compute_txt_embeddings(self, input_ids, position_ids, txt_type_ids=None):
+        return self.embeddings(input_ids, position_ids, txt_type_ids)
+
+    def _compute_img_embeddings(self, img_feat, img_pos_feat, img_masks=None, img_type_ids=None):
+        if img_type_ids is None:
+            type_emb = self.embeddings.new_token_type_embeddings.weight
+        else:
+            # explicit per-region type ids: an API corner no entry point uses (always None upstream)
+            type_emb = nn.functional.embedding(img_type_ids, self.embeddings.new_token_type_embeddings.weight)
+        return self.img_embeddings(img_feat, img_pos_feat, type_emb, img_masks)
+
+    def _compute_img_txt_embeddings(self, input_ids, position_ids, img_feat, img_pos_feat, gather_index,
+                                    img_masks=None, txt_type_ids=None, img_type_ids=None):
+        txt_emb = self._compute_txt_embeddings(input_ids, position_ids, txt_type_ids)
+        img_emb = self._compute_img_embeddings(img_feat, img_pos_feat, img_masks, img_type_ids)
+        return ops.GatherRowsFn.apply(torch.cat([txt_emb, img_emb], dim=1), gather_index)
+
+    def forward(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index=None,
+                img_masks=None, output_all_encoded_layers=True, txt_type_ids=None, img_type_ids=None):
+        st = store_of(self)
+        if st.auto_sync and compute_dtype_of(self) == torch.bfloat16:
+            st.mark_dirty()
+        # additive key mask, fp32 (the parameters are fp32 masters): model/model.py:433-436
+        extended_attention_mask = attention_mask.unsqueeze(1).unsqueeze(2).to(dtype=torch.float32)
+        extended_attention_mask = (1.0 - extended_attention_mask) * -10000.0
+        if input_ids is None:
+            embedding_output = self._compute_img_embeddings(img_feat, img_pos_feat, img_masks, img_type_ids)
+        elif img_feat is None:
+            embedding_output = self._compute_txt_embeddings(input_ids, position_ids, txt_type_ids)
+        else:
+            embedding_output = self._compute_img_txt_embeddings(input_ids, position_ids, img_feat, img_pos_feat,
+                                                                gather_index, img_masks, txt_type_ids, img_type_ids)
+        encoded_layers = self.encoder(embedding_output, extended_attention_mask,
+                                      output_all_encoded_layers=output_all_encoded_layers)
+        if not output_all_encoded_layers:
+            encoded_layers = encoded_layers[-1]
+        return encoded_layers
+
+
+def pad_tensor_to_mul(tensor, dim=0, mul=8):
+    """model/model.py:1051-1054: returns immediately in the reference (padding disabled)."""
+    return tensor, 0
+
+
+class RegionFeatureRegression(nn.Module):
+    """model/model.py:1143-1156: Linear-GELU-LN(1e-12) then F.linear(h, W_img^T, bias) (weight tied to img_linear)"""
+
+    def __init__(self, hidden_size, feat_dim, img_linear_weight):
+        super().__init__()
+        self.net = nn.Sequential(Linear(hidden_size, hidden_size), GELU(), LayerNorm(hidden_size, eps=1e-12))
+        self.weight = img_linear_weight
+        self.bias = nn.Parameter(torch.zeros(feat_dim))
+
+    def forward(self, input_):
+        hidden = self.net[2](self.net[0](input_, act=ops.EPI_GELU))
+        return ops.LinearFn.apply(hidden, self, ops.EPI_NONE, True, self.weight, self.bias)
+
+
+class RegionClassification(nn.Module):
+    """model/model.py:1159-1169"""
+
+    def __init__(self, hidden_size, label_dim):
+        super().__init__()
+        self.net = nn.Sequential(Linear(hidden_size, hidden_size), GELU(), LayerNorm(hidden_size, eps=1e-12),
+                                 Linear(hidden_size, label_dim))
+
+    def forward(self, input_):
+        return self.net[3](self.net[2](self.net[0](input_, act=ops.EPI_GELU)))
+
+
+class VLXLMRForPretraining(VLXLMRPreTrainedModel):
+    """model/model.py:460-775: MLM / TLM / VMLM / MRFR / MRC / ITM heads; returns UNREDUCED losses
+    (fp32) or raw scores exactly like the reference."""
+
+    def __init__(self, config, img_dim, img_label_dim, nce_temp=1, ot_pos_only=False):
+        super().__init__(config)
+        self.roberta = VLXLMRModel(config, img_dim)
+        self.cls = RobertaLMHead(config, self.roberta.embeddings.word_embeddings.weight)
+        self.vis_cls = VisualRobertaLMHead(config, self.roberta.embeddings.word_embeddings.weight,
+                                           VALID_XLMR_TOKEN_IDS)
+        self.feat_regress = RegionFeatureRegression(config.hidden_size, img_dim,
+                                                    self.roberta.img_embeddings.img_linear.weight)
+        self.region_classifier = RegionClassification(config.hidden_size, img_label_dim)
+        self.itm_output = Linear(config.hidden_size, 2)
+        self.ot_pos_only = ot_pos_only
+        self.apply(self.init_weights)
+        self.vocab_pad = 0
+
+    def pad_vocab(self):
+        """model/model.py:486-493: padding is a no-op in the reference; only the tie is re-established."""
+        self.cls.decoder.weight = self.roberta.embeddings.word_embeddings.weight
+        self.vocab_pad = 0
+
+    # ------------------------------------------------------------------ dispatch
+    def forward(self, batch, task, compute_loss=True):
+        store_of(self)                      # one arena for the whole model
+        batch = defaultdict(lambda: None, batch)
+        input_ids = batch['input_ids']
+        position_ids = batch['position_ids'] if task == 'tlm' else None
+        img_feat = batch['img_feat']
+        img_pos_feat = batch['img_pos_feat']
+        attention_mask = batch['attn_masks']
+        gather_index = batch['gather_index']
+        if task in ['mlm', 'tlm']:
+            return self.forward_mlm(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
+                                    batch['txt_labels'], compute_loss)
+        elif task == 'tlm-ni':
+            return self.forward_mlm(input_ids, position_ids, None, None, attention_mask, None,
+                                    batch['txt_labels'], compute_loss)
+        elif task in ['mmxlm', 'vmlm']:
+            return self.forward_mmxlm(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
+                                      batch['img_masks'], batch['txt_labels'], compute_loss)
+        elif task in ["mmxlm-soft", 'vmlm-soft']:
+            raise NotImplementedError("the *-soft tasks need the tokenizer-derived id list and are outside "
+                                      "the hot path (SURVEY.md §8a a17)")
+        elif task == 'mrfr':
+            return self.forward_mrfr(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
+                                     batch['img_masks'], batch['img_mask_tgt'], batch['feat_targets'], compute_loss)
+        elif task == 'itm':
+            return self.forward_itm(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
+                                    batch['targets'], batch['ot_inputs'], compute_loss)
+        elif task.startswith('mrc'):
+            return self.forward_mrc(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
+                                    batch['img_masks'], batch['img_mask_tgt'], batch['label_targets'], task,
+                                    compute_loss)
+        else:
+            raise ValueError('invalid task')
+
+    # ------------------------------------------------------------------ heads
+    def _compute_masked_hidden(self, hidden, mask):
+        """model/model.py:653-657: rows of `hidden` where mask is set (row compaction kernel)"""
+        H = hidden.size(-1)
+        rows = torch.nonzero(mask.reshape(-1), as_tuple=False).view(-1)
+        return ops.SelectRowsFn.apply(hidden.reshape(-1, H), rows)
+
+    def _pad_layer_unpad(self, input_, layer):
+        return layer(input_)
+
+    def _mlm_scores_or_loss(self, masked_output, labels_flat, compute_loss):
+        z = self.cls.transform(masked_output)
+        if compute_loss:
+            loss, _ = ops.DecoderCEFn.apply(z, self.cls, self.cls.decoder.weight, self.cls.bias, labels_flat, -100)
+            return loss
+        return self.cls.decoder(z)
+
+    def forward_mlm(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
+                    txt_labels, compute_loss=True):
+        if gather_index is not None:
+            sequence_output = self.roberta(input_ids, position_ids, img_feat, img_pos_feat, attention_mask,
+                                           gather_index, output_all_encoded_layers=False)
+        else:
+            sequence_output = self.roberta(input_ids, position_ids, img_feat, img_pos_feat, attention_mask,
+                                           output_all_encoded_layers=False)
+        sequence_output = sequence_output[:, :input_ids.size(1), :]
+        masked_output = self._compute_masked_hidden(sequence_output, txt_labels != -1)
+        return self._mlm_scores_or_loss(masked_output, txt_labels[txt_labels != -1], compute_loss)
+
+    def forward_mmxlm(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
+                      img_masks, txt_labels, compute_loss=True):
+        sequence_output = self.roberta(input_ids, position_ids, img_feat, img_pos_feat, attention_mask,
+                                       gather_index, output_all_encoded_layers=False, img_masks=img_masks)
+        masked_output = self._compute_masked_hidden(sequence_output, txt_labels != -1)
+        return self._mlm_scores_or_loss(masked_output, txt_labels[txt_labels != -1], compute_loss)
+
+    def forward_mrfr(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
+                     img_masks, img_mask_tgt, feat_targets, compute_loss=True):
+        sequence_output = self.roberta(input_ids, position_ids, img_feat, img_pos_feat, attention_mask,
+                                       gather_index, output_all_encoded_layers=False, img_masks=img_masks)
+        masked_output = self._compute_masked_hidden(sequence_output, img_mask_tgt)
+        prediction_feat = self.feat_regress(masked_output)
+        if compute_loss:
+            return ops.MSEFn.apply(prediction_feat, feat_targets)
+        return prediction_feat
+
+    def forward_itm(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
+                    targets, ot_inputs, compute_loss=True):
+        if ot_inputs is not None:
+            raise NotImplementedError("the OT regulariser (itm_ot_lambda > 0) is outside the hot path "
+                                      "(SURVEY.md §8f rank 4); the shipped configs use ot_inputs=None")
+        sequence_output = self.roberta(input_ids, position_ids, img_feat, img_pos_feat, attention_mask,
+                                       gather_index, output_all_encoded_layers=False)
+        pooled_output = self.roberta.pooler(sequence_output)
+        rank_scores = self.itm_output(pooled_output)
+        if compute_loss:
+            itm_loss, _ = ops.CrossEntropyFn.apply(rank_scores, targets, -100, rank_scores.shape[-1])
+            return itm_loss, None
+        return rank_scores, None
+
+    def forward_mrc(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
+                    img_masks, img_mask_tgt, label_targets, task, compute_loss=True):
+        sequence_output = self.roberta(input_ids, position_ids, img_feat, img_pos_feat, attention_mask,
+                                       gather_index, output_all_encoded_layers=False, img_masks=img_masks)
+        masked_output = self._compute_masked_hidden(sequence_output, img_mask_tgt)
+        prediction_soft_label = self.region_classifier(masked_output)
+        if compute_loss:
+            if "kl" in task:
+                return ops.KLDivFn.apply(prediction_soft_label, label_targets, prediction_soft_label.shape[-1])
+            # background class should not be the target (model/model.py:770)
+            label_targets = torch.max(label_targets[:, 1:], dim=-1)[1] + 1
+            loss, _ = ops.CrossEntropyFn.apply(prediction_soft_label, label_targets, 0,
+                                               prediction_soft_label.shape[-1])
+            return loss
+        return prediction_soft_label

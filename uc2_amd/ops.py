@@ -1,0 +1,680 @@
+"""Thin Python wrappers over the C-ABI kernels + the autograd Functions built from them.
+
+Every function here enqueues HIP kernels from libuc2_hip.so on torch's current stream.
+torch is used only for device memory (torch.empty), streams and autograd graph edges.
+"""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import call, dt, ptr, stream
+from .store import store_of
+
+EPI_NONE, EPI_GELU, EPI_DGELU, EPI_ADD, EPI_TANH = 0, 1, 2, 3, 4
+ATTN_IMPL = 0          # 0 auto, 1 fp32-math kernels, 2 MFMA kernels (tests flip this)
+
+
+def _require_cuda(t):
+    if not t.is_cuda:
+        raise _lib.Uc2Error("uc2_amd kernels run on the GPU only (tensor on %s); there is no CPU fallback" % t.device)
+
+
+# --------------------------------------------------------------------------------------
+# dropout seed state (device side, so a captured hipGraph draws fresh masks on every replay)
+# --------------------------------------------------------------------------------------
+class _Rng:
+    def __init__(self):
+        self.state = {}
+
+    def buf(self, device):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        key = str(device)
+        if key not in self.state:
+            self.state[key] = torch.full((1,), torch.initial_seed() & 0x7FFFFFFFFFFF, dtype=torch.int64, device=device)
+        return self.state[key]
+
+    def snapshot(self, device):
+        """advance the stream and return a private copy for one forward/backward pair"""
+        b = self.buf(device)
+        b.add_(0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFF)
+        return b.clone()
+
+    def manual_seed(self, seed, device="cuda"):
+        self.buf(torch.device(device)).fill_(seed & 0x7FFFFFFFFFFF)
+
+
+rng = _Rng()
+
+
+# --------------------------------------------------------------------------------------
+# raw kernel wrappers
+# --------------------------------------------------------------------------------------
+def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=None, epi=EPI_NONE,
+         aux_in=None, aux_out=None, accumulate=False, split_k=1, lda=None, ldb=None, ldc=None):
+    """C[M,N] (=|+=) epi(sum_k A(m,k) B(n,k) + bias[n]); see uc2_amd/csrc/gemm.hip."""
+    _require_cuda(a)
+    dtype = a.dtype
+    assert b.dtype == dtype
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else dtype, device=a.device)
+    c_f32 = out.dtype == torch.float32
+    lda = lda if lda is not None else a.stride(0)
+    ldb = ldb if ldb is not None else b.stride(0)
+    ldc = ldc if ldc is not None else out.stride(0)
+    ldaux = 0
+    for x in (aux_in, aux_out):
+        if x is not None:
+            ldaux = x.stride(0)
+    call("uc2_gemm", dt(dtype), int(ta), int(tb), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc, int(c_f32),
+         ptr(bias), epi, ptr(aux_in), ptr(aux_out), ldaux, int(accumulate), split_k, stream())
+    return out
+
+
+def _wgrad_split(dtype, n_out, n_in, rows):
+    """split-K factor for a weight-gradient GEMM (contraction over `rows` tokens): aim for >= 2 workgroups per CU"""
+    tile = 64 if dtype == torch.float32 else 128
+    tiles = ((n_out + tile - 1) // tile) * ((n_in + tile - 1) // tile)
+    s = max(1, min(512 // max(tiles, 1), (rows + 255) // 256))
+    return s
+
+
+def linear_fwd(x2, w, bias, epi=EPI_NONE, aux_out=None):
+    M, K = x2.shape
+    N = w.shape[0]
+    return gemm(x2, w, M, N, K, bias=bias, epi=epi, aux_out=aux_out)
+
+
+def linear_dgrad(dy2, w, epi=EPI_NONE, aux_in=None):
+    """dX[M,K] = dY[M,N] @ W[N,K]  (W in nn.Linear layout)"""
+    M, N = dy2.shape
+    K = w.shape[1]
+    return gemm(dy2, w, M, K, N, tb=True, epi=epi, aux_in=aux_in)
+
+
+def linear_wgrad(dy2, x2, dw, db):
+    """dW[N,K] += dY^T X ; db[N] += colsum(dY)  (fp32 accumulation buffers)"""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    gemm(dy2, x2, N, K, M, ta=True, tb=True, out=dw, accumulate=True, split_k=_wgrad_split(dy2.dtype, N, K, M))
+    if db is not None:
+        colsum_accum(dy2, db)
+
+
+def colsum_accum(x2, out, rowmask=None):
+    """out[n] += sum over (masked) rows of x2[:, n]; out is fp32"""
+    M, N = x2.shape
+    call("uc2_colsum_accum", dt(x2.dtype), M, N, ptr(x2), x2.stride(0), ptr(rowmask), ptr(out), stream())
+
+
+def ln_fwd(x2, res2, gamma, beta, eps, drop_p=0.0, seed=None, seed_imm=0, want_stats=True):
+    M, H = x2.shape
+    y = torch.empty_like(x2)
+    mean = torch.empty(M, dtype=torch.float32, device=x2.device) if want_stats else None
+    rstd = torch.empty(M, dtype=torch.float32, device=x2.device) if want_stats else None
+    call("uc2_ln_fwd", dt(x2.dtype), M, H, ptr(x2), ptr(res2), ptr(gamma), ptr(beta), eps, drop_p, ptr(seed), seed_imm,
+         ptr(y), ptr(mean), ptr(rstd), stream())
+    return y, mean, rstd
+
+
+def ln_bwd(dy2, x2, res2, gamma, mean, rstd, dgamma, dbeta, drop_p=0.0, seed=None, seed_imm=0, need_dres=True):
+    """returns (dx, dres); with drop_p == 0 they are the same tensor"""
+    M, H = x2.shape
+    lib = _lib.load()
+    ws = torch.empty(lib.uc2_ln_bwd_workspace(M, H) // 4, dtype=torch.float32, device=x2.device)
+    dx = torch.empty_like(x2)
+    dres = torch.empty_like(x2) if (drop_p > 0.0 and need_dres) else None
+    call("uc2_ln_bwd", dt(x2.dtype), M, H, ptr(dy2), ptr(x2), ptr(res2), ptr(gamma), ptr(mean), ptr(rstd), drop_p,
+         ptr(seed), seed_imm, ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), ptr(ws), stream())
+    return dx, (dres if dres is not None else dx)
+
+
+def attn_fwd(qkv, mask2d, B, L, nh, D, drop_p=0.0, seed=None, seed_imm=0, impl=None):
+    H = nh * D
+    ctx = torch.empty((B * L, H), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, nh, L), dtype=torch.float32, device=qkv.device)
+    call("uc2_attn_fwd", dt(qkv.dtype), ATTN_IMPL if impl is None else impl, B, L, nh, D, ptr(qkv), ptr(mask2d),
+         1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(lse), stream())
+    return ctx, lse
+
+
+def attn_bwd(qkv, mask2d, ctx, dctx, lse, B, L, nh, D, drop_p=0.0, seed=None, seed_imm=0, impl=None):
+    dqkv = torch.empty_like(qkv)
+    call("uc2_attn_bwd", dt(qkv.dtype), ATTN_IMPL if impl is None else impl, B, L, nh, D, ptr(qkv), ptr(mask2d),
+         1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), stream())
+    return dqkv
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    call("uc2_cast", dt(x.dtype), dt(dtype), x.numel(), ptr(x), ptr(out), stream())
+    return out
+
+
+def _mask2d(attention_mask, B, L):
+    """[B,1,1,L] additive float mask (model/model.py:433-436) -> contiguous fp32 [B, L]"""
+    m = attention_mask
+    if m.dim() == 4:
+        if m.shape[1] != 1 or m.shape[2] != 1:
+            raise _lib.Uc2Error("only key masks of shape [B,1,1,L] are supported, got %s" % (tuple(m.shape),))
+        m = m.reshape(m.shape[0], m.shape[3])
+    if m.shape != (B, L):
+        raise _lib.Uc2Error("attention mask shape %s does not match hidden states [%d,%d]" % (tuple(m.shape), B, L))
+    if m.dtype != torch.float32:
+        m = m.float()
+    return m.contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# one BertLayer = one autograd node (reference model/layer.py:159-170)
+# --------------------------------------------------------------------------------------
+_P_NAMES = ("qw", "qb", "kw", "kb", "vw", "vb", "ow", "ob", "g1", "b1", "iw", "ib", "fw", "fb", "g2", "b2")
+
+
+def layer_params(layer):
+    a, it, o = layer.attention, layer.intermediate, layer.output
+    s = a.self
+    return (s.query.weight, s.query.bias, s.key.weight, s.key.bias, s.value.weight, s.value.bias,
+            a.output.dense.weight, a.output.dense.bias, a.output.LayerNorm.weight, a.output.LayerNorm.bias,
+            it.dense.weight, it.dense.bias, o.dense.weight, o.dense.bias, o.LayerNorm.weight, o.LayerNorm.bias)
+
+
+class BertLayerFn(torch.autograd.Function):
+    """x -> LN(x + Wo.Attn(x)) -> LN(a + W2.gelu(W1.a)).  10 kernel launches forward, 21 backward.
+    Weight/bias/LN gradients are accumulated by the kernels directly into the fp32 gradient arena
+    (installed as .grad); autograd only carries dx."""
+
+    @staticmethod
+    def forward(ctx, x, mask2d, layer, cfg, *params):
+        st = store_of(layer)
+        dtype = x.dtype
+        if dtype == torch.bfloat16:
+            st.sync_shadow()
+        P = dict(zip(_P_NAMES, params))
+        B, L, H = x.shape
+        nh = cfg["nh"]
+        D = H // nh
+        M = B * L
+        x2 = x.reshape(M, H)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        training = cfg["training"]
+        p_h = cfg["p_hidden"] if training else 0.0
+        p_a = cfg["p_attn"] if training else 0.0
+        seed = rng.snapshot(x.device) if (p_h > 0 or p_a > 0) else None
+        sid = cfg["layer_id"] * 16
+
+        wqkv = st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype)
+        bqkv = st.span(st.data, P["qb"], P["vb"], (3 * H,))
+        qkv = linear_fwd(x2, wqkv, bqkv)
+        ctxv, lse = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, sid + 1)
+        o1 = linear_fwd(ctxv, st.compute(P["ow"], dtype), P["ob"].data)
+        a, mean1, rstd1 = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, sid + 2)
+        pre = torch.empty((M, P["iw"].shape[0]), dtype=dtype, device=x.device)
+        u = linear_fwd(a, st.compute(P["iw"], dtype), P["ib"].data, EPI_GELU, pre)
+        o2 = linear_fwd(u, st.compute(P["fw"], dtype), P["fb"].data)
+        y, mean2, rstd2 = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, sid + 3)
+
+        ctx.save_for_backward(x2, mask2d, qkv, ctxv, lse, o1, mean1, rstd1, a, pre, u, o2, mean2, rstd2, seed)
+        ctx.layer, ctx.cfg, ctx.shape, ctx.p = layer, cfg, (B, L, H, nh, D), (p_h, p_a, sid)
+        ctx.params = params
+        return y.view(B, L, H)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mask2d, qkv, ctxv, lse, o1, mean1, rstd1, a, pre, u, o2, mean2, rstd2, seed = ctx.saved_tensors
+        B, L, H, nh, D = ctx.shape
+        p_h, p_a, sid = ctx.p
+        P = dict(zip(_P_NAMES, ctx.params))
+        st = store_of(ctx.layer)
+        dtype = x2.dtype
+        M = B * L
+        dy2 = dy.reshape(M, H)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        G = st.grad_buf
+
+        # LN2 and FFN
+        d_o2, dz2 = ln_bwd(dy2, o2, a, P["g2"].data, mean2, rstd2, G(P["g2"]), G(P["b2"]), p_h, seed, sid + 3)
+        linear_wgrad(d_o2, u, G(P["fw"]), G(P["fb"]))
+        d_pre = linear_dgrad(d_o2, st.compute(P["fw"], dtype), EPI_DGELU, pre)
+        linear_wgrad(d_pre, a, G(P["iw"]), G(P["ib"]))
+        da = linear_dgrad(d_pre, st.compute(P["iw"], dtype), EPI_ADD, dz2)
+        # LN1, output projection, attention, fused QKV
+        d_o1, dz1 = ln_bwd(da, o1, x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, sid + 2)
+        linear_wgrad(d_o1, ctxv, G(P["ow"]), G(P["ob"]))
+        dctx = linear_dgrad(d_o1, st.compute(P["ow"], dtype))
+        dqkv = attn_bwd(qkv, mask2d, ctxv, dctx, lse, B, L, nh, D, p_a, seed, sid + 1)
+        dwqkv = st.grad_span(P["qw"], P["vw"], (3 * H, H))
+        dbqkv = st.grad_span(P["qb"], P["vb"], (3 * H,))
+        linear_wgrad(dqkv, x2, dwqkv, dbqkv)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = linear_dgrad(dqkv, st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype), EPI_ADD, dz1).view(B, L, H)
+        hook = ctx.cfg.get("grad_ready_hook")
+        if hook is not None:
+            hook(ctx.layer)
+        return (dx, None, None, None) + (None,) * len(ctx.params)
+
+
+# --------------------------------------------------------------------------------------
+# generic building blocks for embeddings and heads
+# --------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b); `owner` is the module that owns weight/bias (for the store lookup).
+    act: EPI_NONE | EPI_GELU | EPI_TANH.  weight_t=True means `weight` is stored [in, out] and used
+    transposed (RegionFeatureRegression: F.linear(h, W_img^T), model/model.py:1155)."""
+
+    @staticmethod
+    def forward(ctx, x, owner, act, weight_t, weight, bias):
+        st = store_of(owner)
+        dtype = x.dtype
+        if dtype == torch.bfloat16:
+            st.sync_shadow()
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        w = st.compute(weight, dtype)
+        M, K = x2.shape
+        N = weight.shape[1] if weight_t else weight.shape[0]
+        pre = torch.empty((M, N), dtype=dtype, device=x.device) if act == EPI_GELU else None
+        b = bias.data if bias is not None else None
+        if weight_t:
+            y = gemm(x2, w, M, N, K, tb=True, bias=b, epi=act, aux_out=pre)
+        else:
+            y = gemm(x2, w, M, N, K, bias=b, epi=act, aux_out=pre)
+        ctx.save_for_backward(x2, pre if act == EPI_GELU else (y if act == EPI_TANH else None))
+        ctx.owner, ctx.act, ctx.weight_t, ctx.wb, ctx.shp = owner, act, weight_t, (weight, bias), shp
+        return y.view(*shp[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, aux = ctx.saved_tensors
+        weight, bias = ctx.wb
+        st = store_of(ctx.owner)
+        dtype = x2.dtype
+        M, K = x2.shape
+        N = dy.shape[-1]
+        dy2 = dy.reshape(M, N)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        if ctx.act == EPI_GELU:                 # dpre = dy * gelu'(pre)
+            dpre = _dgelu(dy2, aux)
+        elif ctx.act == EPI_TANH:
+            dpre = torch.empty_like(dy2)
+            call("uc2_dtanh", dt(dtype), dy2.numel(), ptr(aux), ptr(dy2), ptr(dpre), stream())
+        else:
+            dpre = dy2
+        w = st.compute(weight, dtype)
+        dw = st.grad_buf(weight)
+        db = st.grad_buf(bias) if bias is not None else None
+        if ctx.weight_t:                        # weight [K_in, N_out]: dW[K,N] += X^T dPre
+            gemm(x2, dpre, K, N, M, ta=True, tb=True, out=dw, accumulate=True,
+                 split_k=_wgrad_split(dtype, K, N, M))
+            if db is not None:
+                colsum_accum(dpre, db)
+        else:
+            linear_wgrad(dpre, x2, dw, db)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.weight_t:                    # dX[M,K] = dPre[M,N] W[K,N]^T
+                dx = gemm(dpre, w, M, K, N)
+            else:
+                dx = linear_dgrad(dpre, w)
+            dx = dx.view(ctx.shp)
+        return dx, None, None, None, None, None
+
+
+def _dgelu(dy2, pre):
+    """dy * gelu'(pre), elementwise (head transforms; the encoder FFN fuses this into its dgrad GEMM)"""
+    out = torch.empty_like(dy2)
+    call("uc2_dgelu", dt(dy2.dtype), dy2.numel(), ptr(pre), ptr(dy2), ptr(out), stream())
+    return out
+
+
+class LayerNormFn(torch.autograd.Function):
+    """y = LN(dropout(x) + residual) * gamma + beta   (residual optional)"""
+
+    @staticmethod
+    def forward(ctx, x, residual, owner, eps, drop_p, seed_imm, gamma, beta, beta_extra):
+        st = store_of(owner)
+        shp = x.shape
+        H = shp[-1]
+        x2 = x.reshape(-1, H)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        r2 = None
+        if residual is not None:
+            r2 = residual.reshape(-1, H)
+            if not r2.is_contiguous():
+                r2 = r2.contiguous()
+        seed = rng.snapshot(x.device) if drop_p > 0 else None
+        b = beta.data if beta_extra is None else (beta.data + beta_extra.data)
+        y, mean, rstd = ln_fwd(x2, r2, gamma.data, b, eps, drop_p, seed, seed_imm)
+        ctx.save_for_backward(x2, r2, mean, rstd, seed)
+        ctx.owner, ctx.gb, ctx.cfg, ctx.shp = owner, (gamma, beta, beta_extra), (drop_p, seed_imm), shp
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, r2, mean, rstd, seed = ctx.saved_tensors
+        gamma, beta, beta_extra = ctx.gb
+        drop_p, seed_imm = ctx.cfg
+        st = store_of(ctx.owner)
+        H = x2.shape[1]
+        dy2 = dy.reshape(-1, H)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dbeta = st.grad_buf(beta)
+        dx, dres = ln_bwd(dy2, x2, r2, gamma.data, mean, rstd, st.grad_buf(gamma), dbeta, drop_p, seed, seed_imm,
+                          need_dres=r2 is not None)
+        dextra = None
+        if beta_extra is not None and ctx.needs_input_grad[8]:
+            # d(beta + extra) flows to both; beta got it through the arena, extra gets a fresh column sum
+            dextra = torch.zeros(H, dtype=torch.float32, device=dy.device)
+            colsum_accum(dy2, dextra)
+        return (dx.view(ctx.shp) if ctx.needs_input_grad[0] else None,
+                dres.view(ctx.shp) if (r2 is not None and ctx.needs_input_grad[1]) else None,
+                None, None, None, None, None, None, dextra)
+
+
+class EmbedTextFn(torch.autograd.Function):
+    """word[ids] + pos[pos_ids] + type[type_ids or 0]  (model/model.py:322-330), output in compute dtype"""
+
+    @staticmethod
+    def forward(ctx, owner, dtype, ids, pos_ids, type_ids, word, pos, typ):
+        B, T = ids.shape
+        H = word.shape[1]
+        out = torch.empty((B, T, H), dtype=dtype, device=ids.device)
+        ids_c, pos_c = ids.contiguous(), pos_ids.contiguous()
+        ty_c = type_ids.contiguous() if type_ids is not None else None
+        call("uc2_embed_fwd", dt(dtype), B * T, H, ptr(ids_c), ptr(pos_c), ptr(ty_c), 0, ptr(word.data), ptr(pos.data),
+             ptr(typ.data), ptr(out), stream())
+        ctx.save_for_backward(ids_c, pos_c, ty_c)
+        ctx.owner, ctx.tabs, ctx.H = owner, (word, pos, typ), H
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids, pos_ids, type_ids = ctx.saved_tensors
+        word, pos, typ = ctx.tabs
+        st = store_of(ctx.owner)
+        H = ctx.H
+        d2 = dout.reshape(-1, H)
+        if not d2.is_contiguous():
+            d2 = d2.contiguous()
+        rows = d2.shape[0]
+        dtyp = st.grad_buf(typ)
+        call("uc2_embed_bwd", dt(d2.dtype), rows, H, ptr(ids), ptr(pos_ids), ptr(type_ids), ptr(d2),
+             ptr(st.grad_buf(word)), ptr(st.grad_buf(pos)), ptr(dtyp), stream())
+        if type_ids is None:         # constant type 0: its row gets the column sum (no atomic pile-up on one row)
+            colsum_accum(d2, dtyp[0])
+        return (None,) * 8
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """torch.gather(src, 1, index[..., None].expand(H)) (model/model.py:420-425)"""
+
+    @staticmethod
+    def forward(ctx, src, index):
+        B, S, H = src.shape
+        L = index.shape[1]
+        src = src.contiguous()
+        idx = index.contiguous()
+        out = torch.empty((B, L, H), dtype=src.dtype, device=src.device)
+        call("uc2_gather_rows_fwd", dt(src.dtype), B, S, L, H, ptr(src), ptr(idx), ptr(out), stream())
+        ctx.save_for_backward(idx)
+        ctx.S = S
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        B, L, H = dout.shape
+        dout = dout.contiguous()
+        dsrc = torch.empty((B, ctx.S, H), dtype=dout.dtype, device=dout.device)
+        call("uc2_gather_rows_bwd", dt(dout.dtype), B, ctx.S, L, H, ptr(dout), ptr(idx), ptr(dsrc), stream())
+        return dsrc, None
+
+
+class SelectRowsFn(torch.autograd.Function):
+    """hidden[mask] for a boolean mask over rows (model/model.py:653-657); rows = flat row indices"""
+
+    @staticmethod
+    def forward(ctx, hidden2, rows):
+        R, H = hidden2.shape
+        n = rows.numel()
+        out = torch.empty((n, H), dtype=hidden2.dtype, device=hidden2.device)
+        call("uc2_select_rows", dt(hidden2.dtype), n, H, ptr(hidden2), hidden2.stride(0), ptr(rows), ptr(out), H, 0,
+             stream())
+        ctx.save_for_backward(rows)
+        ctx.R = R
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (rows,) = ctx.saved_tensors
+        n, H = dout.shape
+        dout = dout.contiguous()
+        dsrc = torch.zeros((ctx.R, H), dtype=dout.dtype, device=dout.device)
+        call("uc2_select_rows", dt(dout.dtype), n, H, ptr(dout), H, ptr(rows), ptr(dsrc), H, 1, stream())
+        return dsrc, None
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """F.cross_entropy(logits, labels, ignore_index, reduction='none'); logits are consumed (overwritten
+    by dlogits in backward).  Also returns argmax (int64) as a non-differentiable side output."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index, n_valid_cols):
+        n = logits.shape[0]
+        V = n_valid_cols
+        labels = labels.contiguous()
+        loss = torch.empty(n, dtype=torch.float32, device=logits.device)
+        lse = torch.empty(n, dtype=torch.float32, device=logits.device)
+        am = torch.empty(n, dtype=torch.int64, device=logits.device)
+        call("uc2_ce_fwd", dt(logits.dtype), n, V, ptr(logits), logits.stride(0), ptr(labels), ignore_index, ptr(loss),
+             ptr(lse), ptr(am), stream())
+        ctx.save_for_backward(logits, labels, lse)
+        ctx.cfg = (ignore_index, V)
+        ctx.mark_non_differentiable(am)
+        return loss, am
+
+    @staticmethod
+    def backward(ctx, gloss, _gam):
+        logits, labels, lse = ctx.saved_tensors
+        ignore_index, V = ctx.cfg
+        n = logits.shape[0]
+        g = gloss.contiguous().float()
+        dlog = logits            # in place: the logits buffer becomes dlogits
+        call("uc2_ce_bwd", dt(logits.dtype), n, V, ptr(dlog), dlog.stride(0), ptr(labels), ignore_index, ptr(lse),
+             ptr(g), stream())
+        return dlog, None, None, None
+
+
+class KLDivFn(torch.autograd.Function):
+    """F.kl_div(F.log_softmax(pred, -1), target, reduction='none') (model/model.py:764-768)"""
+
+    @staticmethod
+    def forward(ctx, pred, target, n_valid_cols):
+        n, V = pred.shape[0], n_valid_cols
+        target = target.contiguous().float()
+        lse = torch.empty(n, dtype=torch.float32, device=pred.device)
+        call("uc2_ce_fwd", dt(pred.dtype), n, V, ptr(pred), pred.stride(0), None, -100, None, ptr(lse), None, stream())
+        loss = torch.empty((n, V), dtype=torch.float32, device=pred.device)
+        call("uc2_kl_fwd", dt(pred.dtype), n, V, ptr(pred), pred.stride(0), ptr(target), ptr(lse), ptr(loss), stream())
+        ctx.save_for_backward(pred, target, lse)
+        ctx.V = V
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        pred, target, lse = ctx.saved_tensors
+        n, V = pred.shape[0], ctx.V
+        g = gloss.contiguous().float()
+        dpred = torch.zeros_like(pred) if pred.shape[1] > V else torch.empty_like(pred)
+        call("uc2_kl_bwd", dt(pred.dtype), n, V, ptr(pred), pred.stride(0), ptr(target), ptr(lse), ptr(g), ptr(dpred),
+             stream())
+        return dpred, None, None
+
+
+class MSEFn(torch.autograd.Function):
+    """F.mse_loss(pred, target, reduction='none') (model/model.py:684-686)"""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        pred = pred.contiguous()
+        target = target.contiguous().float()
+        loss = torch.empty(pred.shape, dtype=torch.float32, device=pred.device)
+        call("uc2_mse", dt(pred.dtype), pred.numel(), ptr(pred), ptr(target), None, ptr(loss), None, stream())
+        ctx.save_for_backward(pred, target)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        pred, target = ctx.saved_tensors
+        g = gloss.contiguous().float()
+        dpred = torch.empty_like(pred)
+        call("uc2_mse", dt(pred.dtype), pred.numel(), ptr(pred), ptr(target), ptr(g), None, ptr(dpred), stream())
+        return dpred, None
+
+
+class TripletFn(torch.autograd.Function):
+    """sigmoid -> view(-1, sample_size) -> clamp(margin + neg - pos, 0) (model/itm.py:45-53)"""
+
+    @staticmethod
+    def forward(ctx, scores, sample_size, margin):
+        s = scores.contiguous().view(-1)
+        n = s.numel() // sample_size
+        loss = torch.empty((n, sample_size - 1), dtype=torch.float32, device=s.device)
+        call("uc2_triplet", dt(s.dtype), n, sample_size, margin, ptr(s), None, ptr(loss), None, stream())
+        ctx.save_for_backward(s)
+        ctx.cfg = (n, sample_size, margin, scores.shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (s,) = ctx.saved_tensors
+        n, ss, margin, shp = ctx.cfg
+        g = gloss.contiguous().float()
+        ds = torch.empty_like(s)
+        call("uc2_triplet", dt(s.dtype), n, ss, margin, ptr(s), ptr(g), None, ptr(ds), stream())
+        return ds.view(shp), None, None
+
+
+def add_rowvec(a, b, vec, rowmask, out_dtype):
+    """out = a + b + (rowmask ? vec : 0) row-wise; a may be fp32 while out is the compute dtype"""
+    H = a.shape[-1]
+    a2 = a.reshape(-1, H)
+    if not a2.is_contiguous():
+        a2 = a2.contiguous()
+    b2 = None
+    if b is not None:
+        b2 = b.reshape(-1, H)
+        if not b2.is_contiguous():
+            b2 = b2.contiguous()
+        assert b2.dtype == out_dtype
+    out = torch.empty(a2.shape, dtype=out_dtype, device=a.device)
+    call("uc2_add_rowvec", dt(a2.dtype), dt(out_dtype), a2.shape[0], H, ptr(a2), ptr(b2), ptr(vec), ptr(rowmask),
+         ptr(out), stream())
+    return out.view(a.shape)
+
+
+class MaskEmbedFn(torch.autograd.Function):
+    """cast(img_feat) + mask_embedding(img_masks) with row 0 == 0 and no gradient to row 0
+    (nn.Embedding(2, img_dim, padding_idx=0), model/model.py:347,353-356)"""
+
+    @staticmethod
+    def forward(ctx, owner, img_feat, img_masks, weight, out_dtype):
+        m8 = img_masks.reshape(-1).to(torch.uint8).contiguous()
+        out = add_rowvec(img_feat, None, weight.data[1], m8, out_dtype)
+        ctx.save_for_backward(m8)
+        ctx.owner, ctx.weight = owner, weight
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (m8,) = ctx.saved_tensors
+        st = store_of(ctx.owner)
+        d2 = dout.reshape(-1, dout.shape[-1])
+        if not d2.is_contiguous():
+            d2 = d2.contiguous()
+        colsum_accum(d2, st.grad_buf(ctx.weight)[1], m8)
+        return None, None, None, None, None
+
+
+class AddRowFn(torch.autograd.Function):
+    """a + b + table[row]  (transformed_im + transformed_pos + type embedding, model/model.py:360)"""
+
+    @staticmethod
+    def forward(ctx, a, b, table, row):
+        out = add_rowvec(a, b, table.data[row], None, a.dtype)
+        ctx.table, ctx.row = table, row
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        st = getattr(ctx.table, "_uc2_store", None)
+        d2 = dout.reshape(-1, dout.shape[-1])
+        if not d2.is_contiguous():
+            d2 = d2.contiguous()
+        if st is not None:
+            colsum_accum(d2, st.grad_buf(ctx.table)[ctx.row])
+            dtab = None
+        else:
+            dtab = torch.zeros_like(ctx.table.data)
+            colsum_accum(d2, dtab[ctx.row])
+        return dout, dout, dtab, None
+
+
+class DecoderCEFn(torch.autograd.Function):
+    """tied-decoder logits + cross entropy in one node (model/layer.py:257-265, model/model.py:590-596):
+    logits = z E^T + bias live in ONE [n, V_pad] buffer that the backward overwrites with dlogits;
+    dE += dlogits^T z goes straight into the word-embedding gradient arena."""
+
+    @staticmethod
+    def forward(ctx, z, owner, weight, bias, labels, ignore_index):
+        st = store_of(owner)
+        dtype = z.dtype
+        if dtype == torch.bfloat16:
+            st.sync_shadow()
+        n, H = z.shape
+        V = weight.shape[0]
+        Vp = (V + 7) // 8 * 8
+        z = z.contiguous()
+        labels = labels.contiguous()
+        logits = torch.empty((n, Vp), dtype=dtype, device=z.device)
+        gemm(z, st.compute(weight, dtype), n, V, H, out=logits, bias=bias.data)
+        loss = torch.empty(n, dtype=torch.float32, device=z.device)
+        lse = torch.empty(n, dtype=torch.float32, device=z.device)
+        am = torch.empty(n, dtype=torch.int64, device=z.device)
+        call("uc2_ce_fwd", dt(dtype), n, V, ptr(logits), Vp, ptr(labels), ignore_index, ptr(loss), ptr(lse), ptr(am),
+             stream())
+        ctx.save_for_backward(z, logits, labels, lse)
+        ctx.owner, ctx.wb, ctx.cfg = owner, (weight, bias), (ignore_index, V, Vp)
+        ctx.mark_non_differentiable(am)
+        return loss, am
+
+    @staticmethod
+    def backward(ctx, gloss, _g):
+        z, logits, labels, lse = ctx.saved_tensors
+        weight, bias = ctx.wb
+        ignore_index, V, Vp = ctx.cfg
+        st = store_of(ctx.owner)
+        dtype = z.dtype
+        n, H = z.shape
+        g = gloss.contiguous().float()
+        call("uc2_ce_bwd", dt(dtype), n, V, ptr(logits), Vp, ptr(labels), ignore_index, ptr(lse), ptr(g), stream())
+        dlog = logits
+        # dE[V,H] += dlogits^T z ; dbias[V] += colsum(dlogits) ; dz = dlogits E
+        gemm(dlog, z, V, H, n, ta=True, tb=True, out=st.grad_buf(weight), accumulate=True, lda=Vp,
+             split_k=_wgrad_split(dtype, V, H, n))
+        call("uc2_colsum_accum", dt(dtype), n, V, ptr(dlog), Vp, None, ptr(st.grad_buf(bias)), stream())
+        dz = gemm(dlog, st.compute(weight, dtype), n, H, V, tb=True, lda=Vp)
+        return dz, None, None, None, None, None

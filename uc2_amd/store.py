@@ -1,0 +1,205 @@
+"""Flat parameter / gradient / compute-copy arenas.
+
+One ParamStore re-homes every parameter of a module tree into ONE contiguous fp32
+buffer (the master weights the reference keeps under apex amp O2, pretrain.py:463-465),
+with a same-layout fp32 gradient arena and, for bf16 compute, a bf16 shadow arena.
+nn.Parameters stay ordinary tensors (views), so `state_dict()` keys and shapes are exactly
+the reference's; what the arena buys on MI355X:
+
+  * query/key/value weights (and biases) of a layer are adjacent -> the fused-QKV GEMM and
+    its weight-gradient GEMM use a zero-copy [3H, H] view (model/layer.py:76-78 runs three GEMMs);
+  * weight-gradient kernels accumulate straight into the arena (no per-tensor .grad allocs, no
+    flatten/unflatten copies in the all-reduce: utils/distributed.py:23-42 does both every step);
+  * AdamW is one launch over the arena and writes the bf16 compute copy in the same pass.
+"""
+import weakref
+
+import torch
+
+from . import _lib
+
+_ALIGN = 64                      # elements; keeps every view 16-byte aligned in fp32 and bf16
+_STORES = weakref.WeakSet()
+
+
+def _unique_named_params(module):
+    seen, out = set(), []
+    for n, p in module.named_parameters():
+        if id(p) not in seen:
+            seen.add(id(p))
+            out.append((n, p))
+    return out
+
+
+def _pack_groups(named):
+    """reorder so that q/k/v weights, and q/k/v biases, of each attention block are adjacent"""
+    by_name = dict(named)
+    used, order = set(), []
+    for n, p in named:
+        if n in used:
+            continue
+        if n.endswith("attention.self.query.weight") or n.endswith("self.query.weight"):
+            base = n[:-len("query.weight")]
+            grp_w = [base + k + ".weight" for k in ("query", "key", "value")]
+            grp_b = [base + k + ".bias" for k in ("query", "key", "value")]
+            if all(g in by_name for g in grp_w + grp_b):
+                order.append([(g, by_name[g]) for g in grp_w])
+                order.append([(g, by_name[g]) for g in grp_b])
+                used.update(grp_w + grp_b)
+                continue
+        order.append([(n, p)])
+        used.add(n)
+    return order
+
+
+class ParamStore:
+    def __init__(self, module):
+        named = _unique_named_params(module)
+        assert named, "module has no parameters"
+        dev = named[0][1].device
+        for n, p in named:
+            if p.dtype != torch.float32:
+                raise _lib.Uc2Error("uc2_amd keeps fp32 master weights; parameter %s is %s "
+                                    "(set compute dtype with uc2_amd.set_compute_dtype, do not .half()/.bfloat16() "
+                                    "the module)" % (n, p.dtype))
+            if p.device != dev:
+                raise _lib.Uc2Error("all parameters of one module tree must live on one device")
+        groups = _pack_groups(named)
+        self.offsets, self.names, self.params = {}, [], []
+        off = 0
+        for grp in groups:
+            off = (off + _ALIGN - 1) // _ALIGN * _ALIGN
+            for n, p in grp:
+                self.offsets[id(p)] = off
+                self.names.append(n)
+                self.params.append(p)
+                off += p.numel()
+        self.total = (off + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.pos = {id(p): i for i, p in enumerate(self.params)}
+        self.device = dev
+        self.data = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.grad = None
+        self.grad_epoch = 0
+        with torch.no_grad():
+            for p in self.params:
+                v = self.view(self.data, p)
+                v.copy_(p.data)
+                p.data = v
+                p._uc2_store = self
+                p._uc2_gepoch = -1
+                if p.grad is not None:            # keep an existing gradient (folded into the arena)
+                    self.grad_buf(p)
+        self.shadow = None
+        self.version = 1
+        self.shadow_version = 0
+        self.auto_sync = True         # re-cast the bf16 copies at every top-level forward (safe default)
+        _STORES.add(self)
+
+    # ---- views ----
+    def view(self, flat, p):
+        o = self.offsets[id(p)]
+        return flat[o:o + p.numel()].view(p.shape)
+
+    def owns(self, p):
+        return getattr(p, "_uc2_store", None) is self and id(p) in self.offsets and \
+            p.data_ptr() == self.data.data_ptr() + 4 * self.offsets[id(p)]
+
+    def span(self, flat, p_first, p_last, shape):
+        """zero-copy view over adjacent parameters p_first..p_last (e.g. q,k,v -> [3H, H])"""
+        o0 = self.offsets[id(p_first)]
+        o1 = self.offsets[id(p_last)] + p_last.numel()
+        return flat[o0:o1].view(shape)
+
+    # ---- gradients ----
+    def _ensure_grad(self):
+        if self.grad is None:
+            self.grad = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+            for p in self.params:
+                p._uc2_gepoch = self.grad_epoch
+
+    def grad_buf(self, p):
+        """fp32 accumulation buffer for p (a view of the gradient arena), installed as p.grad"""
+        self._ensure_grad()
+        v = self.view(self.grad, p)
+        g = p.grad
+        if g is None:
+            if p._uc2_gepoch != self.grad_epoch:      # slice not known to be zero
+                v.zero_()
+            p.grad = v
+            p._uc2_gepoch = -1
+        elif g.data_ptr() != v.data_ptr():            # foreign gradient tensor: fold it in
+            v.copy_(g)
+            p.grad = v
+            p._uc2_gepoch = -1
+        return v
+
+    def grad_span(self, p_first, p_last, shape):
+        for p in self.params[self.pos[id(p_first)]: self.pos[id(p_last)] + 1]:
+            self.grad_buf(p)
+        return self.span(self.grad, p_first, p_last, shape)
+
+    def zero_grad(self):
+        if self.grad is not None:
+            self.grad.zero_()
+        self.grad_epoch += 1
+        for p in self.params:
+            p.grad = None
+            p._uc2_gepoch = self.grad_epoch
+
+    # ---- bf16 compute copies ----
+    def mark_dirty(self):
+        self.version += 1
+
+    def sync_shadow(self):
+        if self.shadow is None:
+            self.shadow = torch.empty(self.total, dtype=torch.bfloat16, device=self.device)
+            self.shadow_version = 0
+        if self.shadow_version != self.version:
+            _lib.call("uc2_cast", 0, 1, self.total, _lib.ptr(self.data), _lib.ptr(self.shadow), _lib.stream())
+            self.shadow_version = self.version
+
+    def compute(self, p, dtype):
+        if dtype == torch.float32:
+            return p.data
+        return self.view(self.shadow, p)
+
+    def compute_span(self, p_first, p_last, shape, dtype):
+        return self.span(self.data if dtype == torch.float32 else self.shadow, p_first, p_last, shape)
+
+
+def store_of(module):
+    """the store that owns `module`'s parameters, built (or rebuilt after .to()/.cuda()) on demand"""
+    st = getattr(module, "_uc2_store_cache", None)
+    first = next(module.parameters(), None)
+    if first is None:
+        return None
+    if st is not None and st.owns(first):
+        return st
+    st = getattr(first, "_uc2_store", None)
+    if st is not None and st.owns(first):
+        # parameters already re-homed by a parent module's store
+        ps = [p for _, p in _unique_named_params(module)]
+        if all(st.owns(p) for p in ps):
+            module.__dict__["_uc2_store_cache"] = st
+            return st
+    st = ParamStore(module)
+    module.__dict__["_uc2_store_cache"] = st
+    return st
+
+
+def mark_all_dirty():
+    """call after changing parameter values outside AdamW.step (load_state_dict, broadcast, manual edits)"""
+    for st in list(_STORES):
+        st.mark_dirty()
+
+
+def set_compute_dtype(module, dtype):
+    """float32 = parity mode, bfloat16 = throughput mode (fp32 masters, bf16 MFMA GEMMs, fp32 statistics)"""
+    assert dtype in (torch.float32, torch.bfloat16)
+    for m in module.modules():
+        m.__dict__["compute_dtype"] = dtype
+    return module
+
+
+def compute_dtype_of(module):
+    return module.__dict__.get("compute_dtype", torch.float32)

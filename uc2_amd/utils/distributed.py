@@ -1,0 +1,241 @@
+"""Data-parallel communication with the reference's function names (utils/distributed.py), on
+torch.distributed: backend "nccl" IS RCCL on ROCm (xGMI inside a node); "gloo" for CPU tests.
+One process per GPU, launched by torch.distributed.run (the reference uses horovodrun -np N).
+
+What changes relative to the reference (utils/distributed.py:15-42):
+  * no flatten/unflatten: gradients already live in one contiguous fp32 arena (uc2_amd/store.py),
+    so the collective runs in place on views of it;
+  * bucketed and overlapped: GradSync launches one async all-reduce per encoder layer as soon as that
+    layer's backward has finished (layers finish last-to-first), so only the embedding/head tail is
+    exposed; RCCL picks the multi-link algorithm (7 xGMI links per GPU), nothing forces a ring;
+  * the mean over ranks (Horovod's default) and `/ rescale_denom` are one scaling pass.
+"""
+import math
+import pickle
+
+import torch
+import torch.distributed as dist
+
+from .. import _lib
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def _scale_(t, s):
+    """t *= s in place (HIP kernel on the GPU; CPU tensors only occur in the gloo tests)"""
+    if s == 1.0:
+        return
+    if t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+        _lib.call("uc2_scale", t.numel(), _lib.ptr(t), None, float(s), _lib.stream())
+    else:
+        t.mul_(s)
+
+
+def _flat_spans(tensors):
+    """group tensors into maximal spans that are contiguous in memory inside one gradient arena;
+    returns (list of flat views, list of leftover tensors that are not arena-backed)"""
+    by_store, loose = {}, []
+    for t in tensors:
+        st = getattr(t, "_uc2_arena", None)
+        if st is None:
+            loose.append(t)
+        else:
+            by_store.setdefault(id(st), (st, []))[1].append(t)
+    return by_store, loose
+
+
+def arena_of(params):
+    """{store: [(elem_offset, numel)]} for parameters whose gradients live in a store arena"""
+    out = {}
+    for p in params:
+        st = getattr(p, "_uc2_store", None)
+        if st is not None and st.owns(p) and st.grad is not None:
+            out.setdefault(id(st), (st, []))[1].append((st.offsets[id(p)], p.numel()))
+    return out
+
+
+def _merge(ranges, gap=64):
+    ranges = sorted(ranges)
+    merged = []
+    for o, n in ranges:
+        if merged and o - (merged[-1][0] + merged[-1][1]) <= gap:
+            merged[-1][1] = max(merged[-1][1], o + n - merged[-1][0])
+        else:
+            merged.append([o, n])
+    return merged
+
+
+def all_reduce_and_rescale_tensors(tensors, rescale_denom):
+    """All-reduce (mean over ranks) and divide by rescale_denom, in place (utils/distributed.py:15-42).
+
+    `tensors` is what the reference passes: [p.grad.data for p in model.parameters() if p.grad is not None].
+    Views of a gradient arena are reduced in place as a few large contiguous spans; anything else is
+    flattened into a temporary buffer exactly like the reference does."""
+    tensors = list(tensors)
+    if not tensors:
+        return
+    W = _world()
+    scale = 1.0 / (W * rescale_denom)
+    # find arena-backed spans by address
+    from ..store import _STORES
+    spans, loose = [], []
+    stores = [st for st in list(_STORES) if st.grad is not None]
+    for t in tensors:
+        hit = None
+        for st in stores:
+            lo = st.grad.data_ptr()
+            if t.device == st.grad.device and lo <= t.data_ptr() < lo + 4 * st.total and t.dtype == torch.float32 \
+                    and t.is_contiguous():
+                hit = (st, (t.data_ptr() - lo) // 4, t.numel())
+                break
+        if hit is None:
+            loose.append(t)
+        else:
+            spans.append(hit)
+    works = []
+    by_store = {}
+    for st, o, n in spans:
+        by_store.setdefault(id(st), (st, []))[1].append((o, n))
+    views = []
+    for st, ranges in by_store.values():
+        sync = getattr(st, "_grad_sync", None)
+        done = sync.take_done() if sync is not None else []
+        for o, n in _merge(ranges):
+            for (a, b) in _subtract((o, o + n), done):
+                v = st.grad[a:b]
+                views.append(v)
+                if W > 1:
+                    works.append(dist.all_reduce(v, async_op=True))
+        if sync is not None:
+            works.extend(sync.take_works())
+            views.extend(sync.take_views())
+    buf = None
+    if loose:
+        sz = sum(t.numel() for t in loose)
+        buf = loose[0].new_zeros(sz)
+        off = 0
+        for t in loose:
+            buf[off:off + t.numel()].copy_(t.reshape(-1))
+            off += t.numel()
+        if W > 1:
+            works.append(dist.all_reduce(buf, async_op=True))
+    for w in works:
+        w.wait()
+    for v in views:
+        _scale_(v, scale)
+    if buf is not None:
+        _scale_(buf, scale)
+        off = 0
+        for t in loose:
+            t.reshape(-1).copy_(buf[off:off + t.numel()])
+            off += t.numel()
+
+
+def _subtract(span, done):
+    """parts of [a,b) not covered by the (sorted, disjoint) intervals in `done`"""
+    a, b = span
+    out = []
+    for (x, y) in sorted(done):
+        if y <= a or x >= b:
+            continue
+        if x > a:
+            out.append((a, x))
+        a = max(a, y)
+    if a < b:
+        out.append((a, b))
+    return out
+
+
+class GradSync:
+    """Overlap the gradient all-reduce with backward.  Usage (mirrors pretrain.py:557-566):
+
+        sync = GradSync(model)                     # once
+        ...
+        sync.arm()                                 # before the LAST micro-step's backward of a window
+        loss.backward()                            # each BertLayer's all-reduce starts as it finishes
+        all_reduce_and_rescale_tensors(grads, 1)   # reduces the rest, waits, averages
+
+    Not arming it simply gives the non-overlapped behaviour."""
+
+    def __init__(self, model):
+        from ..model.layer import BertLayer
+        from ..store import store_of
+        self.st = store_of(model)
+        self.st._grad_sync = self
+        self.layers = [m for m in model.modules() if isinstance(m, BertLayer)]
+        self.armed = False
+        self._works, self._views, self._done = [], [], []
+        for l in self.layers:
+            l.grad_ready_hook = self._on_layer_done
+
+    def arm(self):
+        self.armed = True
+        self._works, self._views, self._done = [], [], []
+
+    def _on_layer_done(self, layer):
+        if not self.armed or _world() == 1:
+            return
+        st = self.st
+        ps = list(layer.parameters())
+        lo = min(st.offsets[id(p)] for p in ps)
+        hi = max(st.offsets[id(p)] + p.numel() for p in ps)
+        v = st.grad[lo:hi]
+        self._works.append(dist.all_reduce(v, async_op=True))
+        self._views.append(v)
+        self._done.append((lo, hi))
+
+    def take_done(self):
+        d, self._done = self._done, []
+        return d
+
+    def take_works(self):
+        w, self._works = self._works, []
+        self.armed = False
+        return w
+
+    def take_views(self):
+        v, self._views = self._views, []
+        return v
+
+
+def broadcast_tensors(tensors, root_rank, buffer_size=10485760):
+    """rank `root_rank`'s values everywhere (utils/distributed.py:99-147).  Arena-backed tensors are
+    broadcast in place in buffer_size-byte chunks of the arena; others one by one."""
+    from ..store import mark_all_dirty
+    tensors = list(tensors)
+    if _world() > 1:
+        for t in tensors:
+            if t.is_contiguous():
+                flat = t.reshape(-1)
+                step = max(1, buffer_size // t.element_size())
+                for o in range(0, flat.numel(), step):
+                    dist.broadcast(flat[o:o + step], root_rank)
+            else:
+                c = t.contiguous()
+                dist.broadcast(c, root_rank)
+                t.copy_(c)
+    mark_all_dirty()
+
+
+def all_gather_list(data):
+    """gather arbitrary picklable data from every rank into a list (utils/distributed.py:175-204)"""
+    if _world() == 1:
+        return [data]
+    out = [None] * _world()
+    dist.all_gather_object(out, data)
+    return out
+
+
+def any_broadcast(data, root_rank):
+    """broadcast arbitrary picklable data from root_rank (utils/distributed.py:207-230)"""
+    if _world() == 1:
+        return data
+    obj = [data]
+    dist.broadcast_object_list(obj, src=root_rank)
+    return obj[0]
