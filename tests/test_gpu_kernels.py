@@ -278,3 +278,21 @@ def test_cast_roundtrip():
     b = ops.cast(x, torch.bfloat16)
     assert torch.equal(b, x.to(torch.bfloat16))
     assert torch.equal(ops.cast(b, torch.float32), b.float())
+
+
+@pytest.mark.parametrize("B,L,nh,D", [(2, 96, 12, 64), (3, 68, 4, 32), (1, 160, 2, 64)])
+def test_attention_mfma_equals_simple_under_dropout(B, L, nh, D):
+    """both implementations draw the same counter-based mask, so they must agree with dropout on"""
+    H = nh * D
+    qkv = rnd((B * L, 3 * H), 1, 0.7, dtype=torch.bfloat16)
+    mask = torch.zeros(B, L, device=DEV)
+    mask[0, L - 9:] = -10000.0
+    dctx = rnd((B * L, H), 2, dtype=torch.bfloat16)
+    seed = torch.tensor([4242], dtype=torch.int64, device=DEV)
+    c1, l1 = ops.attn_fwd(qkv, mask, B, L, nh, D, 0.1, seed, 5, impl=1)
+    c2, l2 = ops.attn_fwd(qkv, mask, B, L, nh, D, 0.1, seed, 5, impl=2)
+    assert rel_err(c2.float(), c1.float()) < 1e-2
+    assert rel_err(l2, l1) < 1e-3
+    g1 = ops.attn_bwd(qkv, mask, c1, dctx, l1, B, L, nh, D, 0.1, seed, 5, impl=1)
+    g2 = ops.attn_bwd(qkv, mask, c1, dctx, l1, B, L, nh, D, 0.1, seed, 5, impl=2)
+    assert rel_err(g2.float(), g1.float()) < 2e-2

@@ -1,14 +1,407 @@
-// MFMA attention kernels (bf16).  Placeholder until the MFMA kernels land: reports "unsupported"
-// so the auto dispatch in attention.hip uses the fp32-math kernels.
+// MFMA attention for bf16 (gfx950): one workgroup per (batch, head), one 64-lane wave per 32 rows of
+// the (padded) sequence, v_mfma_f32_32x32x16_bf16 everywhere, fp32 softmax statistics.
+//
+// Layout trick (CDNA4): every product is arranged so that the softmax axis never has to cross lanes
+// through LDS and no operand needs a transposed copy:
+//   * scores are computed "swapped", S^T[key][query] = K Q^T, so a lane owns one query column and the
+//     key axis runs over its 16 accumulator registers (+ the partner lane 32 away): max/sum are
+//     register reductions plus ONE __shfl_xor(…, 32);
+//   * a 32x32 fp32 accumulator tile, converted to bf16 in place, IS the B operand of the next MFMA that
+//     contracts over its row index (O^T = V^T P^T, dQ^T = K^T dS^T, dV^T = dO^T P, dK^T = Q^T dS);
+//     the k order inside such a step is permuted (element j of lane half h = row 16s + 8(j>>2) + 4h +
+//     (j&3)), and the matching A operand (V^T, K^T, dO^T, Q^T) is read with that same permutation
+//     straight out of the row-major LDS tile by ds_read_b64_tr_b16 (hardware transpose);
+//   * the backward computes S and dP in both orientations (7 small MFMA products instead of 5) so that
+//     dQ, dK and dV are all "contract over the accumulator's row index" products: no LDS round trip of
+//     P or dS, no atomics, each wave owns its 32 query rows (dQ) and its 32 key rows (dK, dV).
+// K, V (and Q, dO in the backward) are staged once per workgroup into LDS as row-major tiles with
+// 16 bytes of padding per row (conflict-free ds_read_b128 fragments).  Attention is ~2 % of the
+// layer's flops at L = 96, so the goal here is to be near the HBM time of reading QKV once.
+//
+// Checked on the device against the fp32-math kernels of attention.hip (tests/test_gpu_kernels.py).
 #include "common.h"
-extern "C" int uc2_attn_mfma_supported(int L, int D) { (void)L; (void)D; return 0; }
-extern "C" int uc2_attn_fwd_mfma(int, int, int, int, const void*, const float*, float, float, const uint64_t*, uint64_t,
-                                 void*, float*, void*) {
-  uc2_set_error(__FILE__, __LINE__, "MFMA attention not built");
-  return -1;
+
+#define AM_MAXW 5       // up to 160 positions
+
+__device__ __forceinline__ bf16x8 zero8() { return bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+
+// 8 consecutive bf16 of one row (row-major tile, RS bytes per row): fragment of a k-contiguous operand
+__device__ __forceinline__ bf16x8 ld_row(const char* tile, int RS, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(tile + row * RS + chunk * 16);
 }
-extern "C" int uc2_attn_bwd_mfma(int, int, int, int, const void*, const float*, float, float, const uint64_t*, uint64_t,
-                                 const void*, const void*, const float*, void*, void*) {
-  uc2_set_error(__FILE__, __LINE__, "MFMA attention not built");
-  return -1;
+// transposed fragment: element j of lane half h = tile[kbase + 8*(j>>2) + 4*h + (j&3)][cbase + (lane&31)]
+__device__ __forceinline__ bf16x8 ld_tr(const char* tile, int RS, int kbase, int cbase, int lane) {
+  const int G = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, h = G >> 1;
+  const int off = (kbase + 4 * h + q) * RS + (cbase + 16 * (G & 1) + 4 * pp) * 2;
+  typedef __attribute__((address_space(3))) short4v* lds_p;
+  short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tile + off));
+  short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tile + off + 8 * RS));
+  bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+  return bf16x8{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {   // registers 8s..8s+7 -> bf16x8 (s compile-time)
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (bf16)a[8 * s + j];
+  return r;
+}
+// row of accumulator register i for lane half h
+__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+template <int D>
+__device__ __forceinline__ void stage_tile(char* dst, const bf16* __restrict__ src, int ld, int L, int Lp, int tid,
+                                           int nthr) {
+  constexpr int RS = D * 2 + 16, CPR = D / 8;
+  for (int c = tid; c < Lp * CPR; c += nthr) {
+    const int row = c / CPR, c8 = c - row * CPR;
+    bf16x8 v = zero8();
+    if (row < L) v = *reinterpret_cast<const bf16x8*>(src + (size_t)row * ld + c8 * 8);
+    *reinterpret_cast<bf16x8*>(dst + row * RS + c8 * 16) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, const bf16* __restrict__ qkv,
+                                                                const float* __restrict__ mask, float scale,
+                                                                uint32_t thresh, float keep_scale,
+                                                                const uint64_t* __restrict__ seed_ptr,
+                                                                uint64_t seed_imm, bf16* __restrict__ ctx,
+                                                                float* __restrict__ lse) {
+  constexpr int KS = D / 16, DB = D / 32, RS = D * 2 + 16, Lp = NW * 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + Lp * RS;
+  float* Ms = reinterpret_cast<float*>(smem + 2 * Lp * RS);
+  const int bh = blockIdx.x, b = bh / nh, head = bh - b * nh;
+  const int H = nh * D, ld = 3 * H;
+  const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
+  const bf16* base = qkv + (size_t)b * L * ld + head * D;
+  const int tid = threadIdx.x;
+  stage_tile<D>(Ks, base + H, ld, L, Lp, tid, NW * 64);
+  stage_tile<D>(Vs, base + 2 * H, ld, L, Lp, tid, NW * 64);
+  for (int k = tid; k < Lp; k += NW * 64) Ms[k] = (k < L) ? (mask ? mask[(size_t)b * L + k] : 0.f) : -1e30f;
+  __syncthreads();
+
+  const int w = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+  const int q = 32 * w + c;
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+    qf[s] = (q < L) ? *reinterpret_cast<const bf16x8*>(base + (size_t)q * ld + 16 * s + 8 * h) : zero8();
+
+  f32x16 sc[NW];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kb = 0; kb < NW; ++kb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_row(Ks, RS, 32 * kb + c, 2 * s + h), qf[s], sc[kb], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 mv = *reinterpret_cast<const float4*>(Ms + 32 * kb + 8 * g + 4 * h);
+      const float m4[4] = {mv.x, mv.y, mv.z, mv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = sc[kb][4 * g + e] * scale + m4[e];
+        sc[kb][4 * g + e] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < NW; ++kb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float p = __expf(sc[kb][i] - mx);
+      sum += p;
+      float pd = p;
+      if (thresh) {
+        const int key = 32 * kb + acc_row(i, h);
+        pd = drop_keep(seed, ((uint64_t)bh * L + q) * L + key, thresh) ? p * keep_scale : 0.f;
+      }
+      sc[kb][i] = pd;
+    }
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.0f / sum;
+
+  bf16* out = ctx + ((size_t)b * L + q) * H + head * D;
+#pragma unroll
+  for (int db = 0; db < DB; ++db) {
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NW; ++kb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr(Vs, RS, 32 * kb + 16 * s, 32 * db, lane), pack8(sc[kb], s), o,
+                                                    0, 0, 0);
+    if (q < L) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v[4] = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
+        Vec4<bf16>::store(out + 32 * db + 8 * g + 4 * h, v);
+      }
+    }
+  }
+  if (lse && q < L && h == 0) lse[(size_t)bh * L + q] = mx + __logf(sum);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, const bf16* __restrict__ qkv,
+                                                                const float* __restrict__ mask, float scale,
+                                                                uint32_t thresh, float keep_scale,
+                                                                const uint64_t* __restrict__ seed_ptr,
+                                                                uint64_t seed_imm, const bf16* __restrict__ ctx,
+                                                                const bf16* __restrict__ dctx,
+                                                                const float* __restrict__ lse,
+                                                                bf16* __restrict__ dqkv) {
+  constexpr int KS = D / 16, DB = D / 32, RS = D * 2 + 16, Lp = NW * 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;
+  char* Ks = smem + Lp * RS;
+  char* Vs = smem + 2 * Lp * RS;
+  char* Gs = smem + 3 * Lp * RS;                       // dO
+  float* Ms = reinterpret_cast<float*>(smem + 4 * Lp * RS);
+  float* Ls = Ms + Lp;
+  float* Ds = Ls + Lp;
+  const int bh = blockIdx.x, b = bh / nh, head = bh - b * nh;
+  const int H = nh * D, ld = 3 * H;
+  const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
+  const bf16* base = qkv + (size_t)b * L * ld + head * D;
+  const bf16* dob = dctx + (size_t)b * L * H + head * D;
+  const bf16* ob = ctx + (size_t)b * L * H + head * D;
+  bf16* dbase = dqkv + (size_t)b * L * ld + head * D;
+  const int tid = threadIdx.x;
+  stage_tile<D>(Qs, base, ld, L, Lp, tid, NW * 64);
+  stage_tile<D>(Ks, base + H, ld, L, Lp, tid, NW * 64);
+  stage_tile<D>(Vs, base + 2 * H, ld, L, Lp, tid, NW * 64);
+  stage_tile<D>(Gs, dob, H, L, Lp, tid, NW * 64);
+  for (int k = tid; k < Lp; k += NW * 64) {
+    Ms[k] = (k < L) ? (mask ? mask[(size_t)b * L + k] : 0.f) : -1e30f;
+    Ls[k] = (k < L) ? lse[(size_t)bh * L + k] : 0.f;
+    float dl = 0.f;
+    if (k < L) {
+#pragma unroll
+      for (int d = 0; d < D; d += 8) {
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(dob + (size_t)k * H + d);
+        const bf16x8 o = *reinterpret_cast<const bf16x8*>(ob + (size_t)k * H + d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)g[e] * (float)o[e];
+      }
+    }
+    Ds[k] = dl;
+  }
+  __syncthreads();
+
+  const int w = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+  const int r0 = 32 * w + c;               // this lane's query (orientation 1) and key (orientation 2)
+
+  // ---------------- orientation 1: rows = key, cols = query (this wave's 32 queries) -> dQ ----------------
+  {
+    bf16x8 qf[KS], gf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) { qf[s] = ld_row(Qs, RS, r0, 2 * s + h); gf[s] = ld_row(Gs, RS, r0, 2 * s + h); }
+    const float lq = Ls[r0], dl = Ds[r0];
+    f32x16 dq[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NW; ++kb) {
+      f32x16 sa, pa;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sa[r] = 0.f; pa[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_row(Ks, RS, 32 * kb + c, 2 * s + h), qf[s], sa, 0, 0, 0);
+        pa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_row(Vs, RS, 32 * kb + c, 2 * s + h), gf[s], pa, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 mv = *reinterpret_cast<const float4*>(Ms + 32 * kb + 8 * g + 4 * h);
+        const float m4[4] = {mv.x, mv.y, mv.z, mv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * g + e;
+          const float p = __expf(sa[i] * scale + m4[e] - lq);
+          float dp = pa[i];
+          if (thresh) {
+            const int key = 32 * kb + acc_row(i, h);
+            dp = drop_keep(seed, ((uint64_t)bh * L + r0) * L + key, thresh) ? dp * keep_scale : 0.f;
+          }
+          sa[i] = p * (dp - dl) * scale;            // dS^T
+        }
+      }
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr(Ks, RS, 32 * kb + 16 * s, 32 * db, lane),
+                                                           pack8(sa, s), dq[db], 0, 0, 0);
+    }
+    if (r0 < L) {
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v[4] = {dq[db][4 * g], dq[db][4 * g + 1], dq[db][4 * g + 2], dq[db][4 * g + 3]};
+          Vec4<bf16>::store(dbase + (size_t)r0 * ld + 32 * db + 8 * g + 4 * h, v);
+        }
+    }
+  }
+
+  // ---------------- orientation 2: rows = query, cols = key (this wave's 32 keys) -> dK, dV ----------------
+  {
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) { kf[s] = ld_row(Ks, RS, r0, 2 * s + h); vf[s] = ld_row(Vs, RS, r0, 2 * s + h); }
+    const float mk = Ms[r0];
+    f32x16 dk[DB], dv[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+#pragma unroll
+    for (int qb = 0; qb < NW; ++qb) {
+      f32x16 sa, pa;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sa[r] = 0.f; pa[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_row(Qs, RS, 32 * qb + c, 2 * s + h), kf[s], sa, 0, 0, 0);
+        pa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_row(Gs, RS, 32 * qb + c, 2 * s + h), vf[s], pa, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 lv = *reinterpret_cast<const float4*>(Ls + 32 * qb + 8 * g + 4 * h);
+        const float4 dv4 = *reinterpret_cast<const float4*>(Ds + 32 * qb + 8 * g + 4 * h);
+        const float l4[4] = {lv.x, lv.y, lv.z, lv.w}, d4[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * g + e;
+          const float p = __expf(sa[i] * scale + mk - l4[e]);
+          float pd = p, dp = pa[i];
+          if (thresh) {
+            const int qq = 32 * qb + acc_row(i, h);
+            const bool keep = drop_keep(seed, ((uint64_t)bh * L + qq) * L + r0, thresh);
+            pd = keep ? p * keep_scale : 0.f;
+            dp = keep ? dp * keep_scale : 0.f;
+          }
+          pa[i] = pd;                                // dropped P
+          sa[i] = p * (dp - d4[e]) * scale;          // dS
+        }
+      }
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr(Gs, RS, 32 * qb + 16 * s, 32 * db, lane),
+                                                           pack8(pa, s), dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr(Qs, RS, 32 * qb + 16 * s, 32 * db, lane),
+                                                           pack8(sa, s), dk[db], 0, 0, 0);
+        }
+    }
+    if (r0 < L) {
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v[4] = {dk[db][4 * g], dk[db][4 * g + 1], dk[db][4 * g + 2], dk[db][4 * g + 3]};
+          Vec4<bf16>::store(dbase + (size_t)r0 * ld + H + 32 * db + 8 * g + 4 * h, v);
+          float u[4] = {dv[db][4 * g], dv[db][4 * g + 1], dv[db][4 * g + 2], dv[db][4 * g + 3]};
+          Vec4<bf16>::store(dbase + (size_t)r0 * ld + 2 * H + 32 * db + 8 * g + 4 * h, u);
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host dispatch
+// ------------------------------------------------------------------------------------------------
+extern "C" int uc2_attn_mfma_supported(int L, int D) { return (D == 32 || D == 64) && L >= 1 && L <= 32 * AM_MAXW; }
+
+template <int D, int NW>
+static int launch_fwd(int B, int L, int nh, const void* qkv, const float* mask, float scale, float drop_p,
+                      const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse, hipStream_t st) {
+  constexpr int RS = D * 2 + 16, Lp = NW * 32;
+  const size_t smem = 2 * Lp * RS + Lp * sizeof(float);
+  hipLaunchKernelGGL((attn_fwd_mfma_kernel<D, NW>), dim3(B * nh), dim3(NW * 64), smem, st, L, nh, (const bf16*)qkv, mask,
+                     scale, drop_thresh(drop_p), 1.0f / (1.0f - drop_p), seed_ptr, seed_imm, (bf16*)ctx, lse);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+template <int D, int NW>
+static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, float scale, float drop_p,
+                      const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx, const void* dctx,
+                      const float* lse, void* dqkv, hipStream_t st) {
+  constexpr int RS = D * 2 + 16, Lp = NW * 32;
+  const size_t smem = 4 * Lp * RS + 3 * Lp * sizeof(float);
+  auto kern = attn_bwd_mfma_kernel<D, NW>;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) { uc2_set_error(__FILE__, __LINE__, hipGetErrorString(e)); return (int)e; }
+  }
+  hipLaunchKernelGGL(kern, dim3(B * nh), dim3(NW * 64), smem, st, L, nh, (const bf16*)qkv, mask, scale,
+                     drop_thresh(drop_p), 1.0f / (1.0f - drop_p), seed_ptr, seed_imm, (const bf16*)ctx,
+                     (const bf16*)dctx, lse, (bf16*)dqkv);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+#define AM_DISPATCH(FN, ...)                                                   \
+  do {                                                                         \
+    const int nw = (L + 31) / 32;                                              \
+    if (D == 64) {                                                             \
+      switch (nw) {                                                            \
+        case 1: return FN<64, 1>(__VA_ARGS__);                                 \
+        case 2: return FN<64, 2>(__VA_ARGS__);                                 \
+        case 3: return FN<64, 3>(__VA_ARGS__);                                 \
+        case 4: return FN<64, 4>(__VA_ARGS__);                                 \
+        default: return FN<64, 5>(__VA_ARGS__);                                \
+      }                                                                        \
+    } else {                                                                   \
+      switch (nw) {                                                            \
+        case 1: return FN<32, 1>(__VA_ARGS__);                                 \
+        case 2: return FN<32, 2>(__VA_ARGS__);                                 \
+        case 3: return FN<32, 3>(__VA_ARGS__);                                 \
+        case 4: return FN<32, 4>(__VA_ARGS__);                                 \
+        default: return FN<32, 5>(__VA_ARGS__);                                \
+      }                                                                        \
+    }                                                                          \
+  } while (0)
+
+extern "C" int uc2_attn_fwd_mfma(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
+                                 float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse,
+                                 void* stream) {
+  UC2_CHECK_ARG(uc2_attn_mfma_supported(L, D));
+  UC2_CHECK_ARG(B >= 0 && nh >= 1 && drop_p >= 0.f && drop_p < 1.f);
+  UC2_CHECK_ARG(((nh * D) % 8) == 0);
+  if (B == 0) return 0;
+  UC2_CHECK_ARG(qkv && ctx);
+  hipStream_t st = (hipStream_t)stream;
+  AM_DISPATCH(launch_fwd, B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, lse, st);
+}
+
+extern "C" int uc2_attn_bwd_mfma(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
+                                 float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx,
+                                 const void* dctx, const float* lse, void* dqkv, void* stream) {
+  UC2_CHECK_ARG(uc2_attn_mfma_supported(L, D));
+  UC2_CHECK_ARG(B >= 0 && nh >= 1 && drop_p >= 0.f && drop_p < 1.f);
+  UC2_CHECK_ARG(((nh * D) % 8) == 0);
+  if (B == 0) return 0;
+  UC2_CHECK_ARG(qkv && ctx && dctx && lse && dqkv);
+  hipStream_t st = (hipStream_t)stream;
+  AM_DISPATCH(launch_bwd, B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv, st);
 }

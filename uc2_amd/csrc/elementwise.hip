@@ -210,26 +210,44 @@ extern "C" int uc2_select_rows(int dtype, int n, int H, const void* src, int ld_
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const T* __restrict__ X, int ldx,
                                                      const uint8_t* __restrict__ rowmask, float* __restrict__ out,
-                                                     int rows_per_blk) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
+                                                     int rows_per_blk, int vec) {
+  const int n = (blockIdx.x * 256 + threadIdx.x) * 4;       // 4 consecutive columns per thread
   if (n >= N) return;
   const int m0 = blockIdx.y * rows_per_blk, m1 = min(M, m0 + rows_per_blk);
-  float s = 0.f;
-  for (int m = m0; m < m1; ++m)
-    if (!rowmask || rowmask[m]) s += to_f<T>(X[(size_t)m * ldx + n]);
-  atomicAdd(out + n, s);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (vec && n + 3 < N) {
+    for (int m = m0; m < m1; ++m) {
+      if (rowmask && !rowmask[m]) continue;
+      float v[4];
+      Vec4<T>::load(X + (size_t)m * ldx + n, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += v[e];
+    }
+  } else {
+    for (int m = m0; m < m1; ++m) {
+      if (rowmask && !rowmask[m]) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < N) s[e] += to_f<T>(X[(size_t)m * ldx + n + e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (n + e < N) atomicAdd(out + n + e, s[e]);
 }
 extern "C" int uc2_colsum_accum(int dtype, int M, int N, const void* X, int ldx, const uint8_t* rowmask, float* out,
                                 void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
   if (M <= 0 || N <= 0) return 0;
   UC2_CHECK_ARG(X && out);
-  int splits = (M + 63) / 64;
-  if (splits > 256) splits = 256;
+  int splits = (M + 31) / 32;
+  if (splits > 512) splits = 512;
   const int rpb = (M + splits - 1) / splits;
-  dim3 grid((N + 255) / 256, (M + rpb - 1) / rpb);
-  if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, M, N, (const float*)X, ldx, rowmask, out, rpb);
-  else hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, M, N, (const bf16*)X, ldx, rowmask, out, rpb);
+  dim3 grid((N + 1023) / 1024, (M + rpb - 1) / rpb);
+  const int esz = dtype == 0 ? 4 : 2;
+  const int vec = ((ldx & 3) == 0) && ((((uintptr_t)X) & (4 * esz - 1)) == 0);
+  if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, M, N, (const float*)X, ldx, rowmask, out, rpb, vec);
+  else hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, M, N, (const bf16*)X, ldx, rowmask, out, rpb, vec);
   UC2_LAUNCH_CHECK();
   return 0;
 }

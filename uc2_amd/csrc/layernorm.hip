@@ -168,14 +168,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
   }
 }
 
+// second stage: 64 columns per workgroup, the 4 waves split the partial rows, LDS combine
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(int nblk, int H, const float* __restrict__ ws,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= 2 * H) return;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += ws[(size_t)b * 2 * H + idx];
-  if (idx < H) { if (dgamma) dgamma[idx] += s; }
-  else { if (dbeta) dbeta[idx - H] += s; }
+  if (idx < 2 * H)
+    for (int b = wv; b < nblk; b += 4) s += ws[(size_t)b * 2 * H + idx];
+  red[wv][lane] = s;
+  __syncthreads();
+  if (wv == 0 && idx < 2 * H) {
+    s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (idx < H) { if (dgamma) dgamma[idx] += s; }
+    else { if (dbeta) dbeta[idx - H] += s; }
+  }
 }
 
 static int ln_bwd_blocks(int M) {
@@ -227,7 +235,7 @@ extern "C" int uc2_ln_bwd(int dtype, int M, int H, const void* dy, const void* x
                        (const bf16*)residual, gamma, mean, rstd, th, ks, seed_ptr, seed_imm, (bf16*)dx, (bf16*)dres, (float*)ws);
   UC2_LAUNCH_CHECK();
   if (dgamma || dbeta) {
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * H + 255) / 256), dim3(256), 0, st, nb, H, (const float*)ws,
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * H + 63) / 64), dim3(256), 0, st, nb, H, (const float*)ws,
                        dgamma, dbeta);
     UC2_LAUNCH_CHECK();
   }

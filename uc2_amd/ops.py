@@ -13,6 +13,29 @@ from .store import store_of
 
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_ADD, EPI_TANH = 0, 1, 2, 3, 4
 ATTN_IMPL = 0          # 0 auto, 1 fp32-math kernels, 2 MFMA kernels (tests flip this)
+GEMM_TIMER = None      # bench.py installs a GemmTimer to time one GEMM kernel variant with HIP events
+
+
+class GemmTimer:
+    """HIP-event timing of every launch of one GEMM kernel instantiation (dtype, trans_a, trans_b)"""
+
+    def __init__(self, dtype, ta, tb):
+        self.key = (dtype, bool(ta), bool(tb))
+        self.pairs = []
+
+    def wants(self, dtype, ta, tb):
+        return (dtype, bool(ta), bool(tb)) == self.key
+
+    def add(self, flops, e0, e1):
+        self.pairs.append((flops, e0, e1))
+
+    def summary(self):
+        """(launches, total flops, total seconds) -- call after a device synchronize"""
+        tot_f, tot_t = 0.0, 0.0
+        for f, e0, e1 in self.pairs:
+            tot_f += f
+            tot_t += e0.elapsed_time(e1) * 1e-3
+        return len(self.pairs), tot_f, tot_t
 
 
 def _require_cuda(t):
@@ -68,8 +91,17 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
     for x in (aux_in, aux_out):
         if x is not None:
             ldaux = x.stride(0)
+    timer = GEMM_TIMER
+    if timer is not None and timer.wants(dtype, ta, tb):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()                # on torch's current stream == the stream the kernel is launched on
+    else:
+        e0 = None
     call("uc2_gemm", dt(dtype), int(ta), int(tb), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc, int(c_f32),
          ptr(bias), epi, ptr(aux_in), ptr(aux_out), ldaux, int(accumulate), split_k, stream())
+    if e0 is not None:
+        e1.record()
+        timer.add(2.0 * M * N * K, e0, e1)
     return out
 
 
