@@ -296,3 +296,28 @@ def test_attention_mfma_equals_simple_under_dropout(B, L, nh, D):
     g1 = ops.attn_bwd(qkv, mask, c1, dctx, l1, B, L, nh, D, 0.1, seed, 5, impl=1)
     g2 = ops.attn_bwd(qkv, mask, c1, dctx, l1, B, L, nh, D, 0.1, seed, 5, impl=2)
     assert rel_err(g2.float(), g1.float()) < 2e-2
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 768, 768), (776, 2304, 832), (128, 136, 64)])
+def test_gemm_pipelined_equals_generic(ta, tb, M, N, K):
+    """the LDS-DMA pipelined kernel and the generic register-staged kernel compute the same bf16 result"""
+    lib = ops._lib.load()
+    a = rnd((K, M) if ta else (M, K), 1, dtype=torch.bfloat16)
+    b = rnd((K, N) if tb else (N, K), 2, dtype=torch.bfloat16)
+    bias = rnd((N,), 3)
+    try:
+        lib.uc2_gemm_force_generic(1)
+        ref = ops.gemm(a, b, M, N, K, ta=ta, tb=tb, bias=bias)
+        lib.uc2_gemm_force_generic(0)
+        out = ops.gemm(a, b, M, N, K, ta=ta, tb=tb, bias=bias)
+    finally:
+        lib.uc2_gemm_force_generic(0)
+    assert torch.equal(out, ref)
+    acc_ref = rnd((M, N), 4)
+    acc = acc_ref.clone()
+    lib.uc2_gemm_force_generic(1)
+    ops.gemm(a, b, M, N, K, ta=ta, tb=tb, out=acc_ref, accumulate=True, split_k=2 if K >= 128 else 1)
+    lib.uc2_gemm_force_generic(0)
+    ops.gemm(a, b, M, N, K, ta=ta, tb=tb, out=acc, accumulate=True, split_k=2 if K >= 128 else 1)
+    assert rel_err(acc, acc_ref) < 1e-5
