@@ -95,8 +95,10 @@ def test_layernorm_fwd_bwd(dtype, M, H, with_res):
     y, mean, rstd = ops.ln_fwd(x, r, g, b, 1e-12)
     assert max_rel(y.float(), ref) < tol(dtype, 2e-5, 2e-2)
     dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
-    dx, dres = ops.ln_bwd(dy, x, r, g, mean, rstd, dg, db)
+    dbias = torch.zeros(H, device=DEV)
+    dx, dres = ops.ln_bwd(dy, x, r, g, mean, rstd, dg, db, dbias=dbias)
     assert dres is dx
+    assert rel_err(dbias, dx.float().sum(0)) < tol(dtype, 1e-4, 1e-2)     # fp32 sum of the unrounded dx
     assert rel_err(dx.float(), xs.grad) < tol(dtype, 2e-5, 1e-2)
     assert rel_err(dg, gs.grad) < tol(dtype, 2e-5, 1e-2)
     assert rel_err(db, bs.grad) < tol(dtype, 2e-5, 1e-2)

@@ -207,43 +207,63 @@ extern "C" int uc2_select_rows(int dtype, int n, int H, const void* src, int ld_
 // ---------------------------------------------------------------------------------------
 // column sum (bias gradients): out[n] += sum_{m : rowmask[m]} X[m, n]   (rowmask optional)
 // ---------------------------------------------------------------------------------------
+// One wave reads 256 contiguous columns of a row (4 per lane, 8-byte loads for bf16); the 4 waves of a
+// workgroup take 4 different rows per step; partials are combined through LDS, one atomic per column
+// per workgroup.  HBM-bound: algorithmic bytes = M * N * sizeof(T).
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const T* __restrict__ X, int ldx,
                                                      const uint8_t* __restrict__ rowmask, float* __restrict__ out,
                                                      int rows_per_blk, int vec) {
-  const int n = (blockIdx.x * 256 + threadIdx.x) * 4;       // 4 consecutive columns per thread
-  if (n >= N) return;
+  __shared__ float red[4][256];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n = blockIdx.x * 256 + lane * 4;
   const int m0 = blockIdx.y * rows_per_blk, m1 = min(M, m0 + rows_per_blk);
   float s[4] = {0.f, 0.f, 0.f, 0.f};
-  if (vec && n + 3 < N) {
-    for (int m = m0; m < m1; ++m) {
-      if (rowmask && !rowmask[m]) continue;
-      float v[4];
-      Vec4<T>::load(X + (size_t)m * ldx + n, v);
+  if (n < N) {
+    if (vec && n + 3 < N) {
+      int m = m0 + wv;
+      for (; m + 4 < m1; m += 8) {                 // two rows in flight per wave
+        float v[4], u[4];
+        const bool k0 = !rowmask || rowmask[m], k1 = !rowmask || rowmask[m + 4];
+        Vec4<T>::load(X + (size_t)m * ldx + n, v);
+        Vec4<T>::load(X + (size_t)(m + 4) * ldx + n, u);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s[e] += v[e];
-    }
-  } else {
-    for (int m = m0; m < m1; ++m) {
-      if (rowmask && !rowmask[m]) continue;
+        for (int e = 0; e < 4; ++e) s[e] += (k0 ? v[e] : 0.f) + (k1 ? u[e] : 0.f);
+      }
+      for (; m < m1; m += 4) {
+        if (rowmask && !rowmask[m]) continue;
+        float v[4];
+        Vec4<T>::load(X + (size_t)m * ldx + n, v);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (n + e < N) s[e] += to_f<T>(X[(size_t)m * ldx + n + e]);
+        for (int e = 0; e < 4; ++e) s[e] += v[e];
+      }
+    } else {
+      for (int m = m0 + wv; m < m1; m += 4) {
+        if (rowmask && !rowmask[m]) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < N) s[e] += to_f<T>(X[(size_t)m * ldx + n + e]);
+      }
     }
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
-    if (n + e < N) atomicAdd(out + n + e, s[e]);
+  for (int e = 0; e < 4; ++e) red[wv][lane * 4 + e] = s[e];
+  __syncthreads();
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col < N) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 extern "C" int uc2_colsum_accum(int dtype, int M, int N, const void* X, int ldx, const uint8_t* rowmask, float* out,
                                 void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
   if (M <= 0 || N <= 0) return 0;
   UC2_CHECK_ARG(X && out);
-  int splits = (M + 31) / 32;
-  if (splits > 512) splits = 512;
-  const int rpb = (M + splits - 1) / splits;
-  dim3 grid((N + 1023) / 1024, (M + rpb - 1) / rpb);
+  const int colblk = (N + 255) / 256;
+  int splits = (M + 63) / 64;
+  const int want = (2048 + colblk - 1) / colblk;         // ~8 workgroups per CU in total
+  if (splits > want) splits = want;
+  if (splits < 1) splits = 1;
+  const int rpb = ((M + splits - 1) / splits + 3) / 4 * 4;
+  dim3 grid(colblk, (M + rpb - 1) / rpb);
   const int esz = dtype == 0 ? 4 : 2;
   const int vec = ((ldx & 3) == 0) && ((((uintptr_t)X) & (4 * esz - 1)) == 0);
   if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, M, N, (const float*)X, ldx, rowmask, out, rpb, vec);

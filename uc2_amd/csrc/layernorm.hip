@@ -76,29 +76,29 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int H, const T* __re
 // backward.  dz = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 //   dres = dz ;  dx = dz * keep / (1-p)
 //   dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy   (per-workgroup partials -> ws, then reduced)
-template <typename T>
+template <typename T, int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __restrict__ dy, const T* __restrict__ x,
                                                      const T* __restrict__ res, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      uint32_t thresh, float keep_scale, const uint64_t* __restrict__ seed_ptr,
-                                                     uint64_t seed_imm, T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ ws) {
-  __shared__ float red[4][2][LN_MAXC * 4 * 64];
+                                                     uint64_t seed_imm, T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ ws, int want_dbias) {
+  __shared__ float red[4][3][NC * 4 * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nch = H >> 2;
   const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
-  float dg[LN_MAXC][4], db[LN_MAXC][4];
+  float dg[NC][4], db[NC][4], dbx[NC][4];
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i)
+  for (int i = 0; i < NC; ++i)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
+    for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; dbx[i][e] = 0.f; }
 
   for (int row = blockIdx.x * 4 + wv; row < M; row += gridDim.x * 4) {
     const float mean = mean_i[row], rstd = rstd_i[row];
-    float xh[LN_MAXC][4], g[LN_MAXC][4];
-    bool kp[LN_MAXC][4];
+    float xh[NC][4], g[NC][4];
+    bool kp[NC][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < NC; ++i) {
       const int c = lane + 64 * i;
       if (c < nch) {
         const size_t off = (size_t)row * H + c * 4;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
     s1 = wave_sum(s1) / (float)H;
     s2 = wave_sum(s2) / (float)H;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < NC; ++i) {
       const int c = lane + 64 * i;
       if (c < nch) {
         const size_t off = (size_t)row * H + c * 4;
@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
         for (int e = 0; e < 4; ++e) {
           dz[e] = rstd * (g[i][e] - s1 - xh[i][e] * s2);
           dxv[e] = thresh ? (kp[i][e] ? dz[e] * keep_scale : 0.f) : dz[e];
+          dbx[i][e] += dxv[e];
         }
         if (dx) Vec4<T>::store(dx + off, dxv);
         if (dres) Vec4<T>::store(dres + off, dz);
@@ -152,43 +153,45 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
   }
   // reduce the 4 waves of this workgroup, write one partial row per workgroup
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i)
+  for (int i = 0; i < NC; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       red[wv][0][(i * 64 + lane) * 4 + e] = dg[i][e];
       red[wv][1][(i * 64 + lane) * 4 + e] = db[i][e];
+      red[wv][2][(i * 64 + lane) * 4 + e] = dbx[i][e];
     }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 2 * H; idx += 256) {
-    const int which = idx / H, col = idx - which * H;      // col = c*4 + e with c = lane + 64*i
-    const int c = col >> 2, e = col & 3, i = c >> 6, ln = c & 63;
-    const int a = (i * 64 + ln) * 4 + e;
-    const float sum = red[0][which][a] + red[1][which][a] + red[2][which][a] + red[3][which][a];
-    ws[(size_t)blockIdx.x * 2 * H + idx] = sum;
+  const int nout = want_dbias ? 3 : 2;
+  for (int idx = threadIdx.x; idx < nout * H; idx += 256) {
+    const int which = idx / H, col = idx - which * H;      // red index == column (c*4 + e, c = lane + 64*i)
+    const float sum = red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
+    ws[(size_t)blockIdx.x * 3 * H + idx] = sum;
   }
 }
 
 // second stage: 64 columns per workgroup, the 4 waves split the partial rows, LDS combine
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(int nblk, int H, const float* __restrict__ ws,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(int nblk, int H, int nout, const float* __restrict__ ws,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            float* __restrict__ dbias) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + lane;
   float s = 0.f;
-  if (idx < 2 * H)
-    for (int b = wv; b < nblk; b += 4) s += ws[(size_t)b * 2 * H + idx];
+  if (idx < nout * H)
+    for (int b = wv; b < nblk; b += 4) s += ws[(size_t)b * 3 * H + idx];
   red[wv][lane] = s;
   __syncthreads();
-  if (wv == 0 && idx < 2 * H) {
+  if (wv == 0 && idx < nout * H) {
     s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
     if (idx < H) { if (dgamma) dgamma[idx] += s; }
-    else { if (dbeta) dbeta[idx - H] += s; }
+    else if (idx < 2 * H) { if (dbeta) dbeta[idx - H] += s; }
+    else { if (dbias) dbias[idx - 2 * H] += s; }
   }
 }
 
 static int ln_bwd_blocks(int M) {
   int nb = (M + 3) / 4;
-  return nb < 1 ? 1 : (nb > 512 ? 512 : nb);
+  return nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
 }
 
 extern "C" int uc2_ln_fwd(int dtype, int M, int H, const void* x, const void* residual, const float* gamma,
@@ -213,11 +216,12 @@ extern "C" int uc2_ln_fwd(int dtype, int M, int H, const void* x, const void* re
   return 0;
 }
 
-extern "C" size_t uc2_ln_bwd_workspace(int M, int H) { return (size_t)ln_bwd_blocks(M) * 2 * H * sizeof(float); }
+extern "C" size_t uc2_ln_bwd_workspace(int M, int H) { return (size_t)ln_bwd_blocks(M) * 3 * H * sizeof(float); }
 
 extern "C" int uc2_ln_bwd(int dtype, int M, int H, const void* dy, const void* x, const void* residual,
                           const float* gamma, const float* mean, const float* rstd, float drop_p, const uint64_t* seed_ptr,
-                          uint64_t seed_imm, void* dx, void* dres, float* dgamma, float* dbeta, void* ws, void* stream) {
+                          uint64_t seed_imm, void* dx, void* dres, float* dgamma, float* dbeta, float* dbias, void* ws,
+                          void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
   UC2_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= LN_MAXC * 256);
   UC2_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
@@ -227,16 +231,24 @@ extern "C" int uc2_ln_bwd(int dtype, int M, int H, const void* dy, const void* x
   const float ks = 1.0f / (1.0f - drop_p);
   const int nb = ln_bwd_blocks(M);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == 0)
-    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, M, H, (const float*)dy, (const float*)x,
-                       (const float*)residual, gamma, mean, rstd, th, ks, seed_ptr, seed_imm, (float*)dx, (float*)dres, (float*)ws);
-  else
-    hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, M, H, (const bf16*)dy, (const bf16*)x,
-                       (const bf16*)residual, gamma, mean, rstd, th, ks, seed_ptr, seed_imm, (bf16*)dx, (bf16*)dres, (float*)ws);
+  const int nc = (H + 255) / 256;
+#define LN_BWD_LAUNCH(TT, NCC)                                                                                      \
+  hipLaunchKernelGGL((ln_bwd_kernel<TT, NCC>), dim3(nb), dim3(256), 0, st, M, H, (const TT*)dy, (const TT*)x,        \
+                     (const TT*)residual, gamma, mean, rstd, th, ks, seed_ptr, seed_imm, (TT*)dx, (TT*)dres,         \
+                     (float*)ws, dbias ? 1 : 0)
+  if (dtype == 0) {
+    if (nc == 1) LN_BWD_LAUNCH(float, 1); else if (nc == 2) LN_BWD_LAUNCH(float, 2);
+    else if (nc == 3) LN_BWD_LAUNCH(float, 3); else LN_BWD_LAUNCH(float, 4);
+  } else {
+    if (nc == 1) LN_BWD_LAUNCH(bf16, 1); else if (nc == 2) LN_BWD_LAUNCH(bf16, 2);
+    else if (nc == 3) LN_BWD_LAUNCH(bf16, 3); else LN_BWD_LAUNCH(bf16, 4);
+  }
+#undef LN_BWD_LAUNCH
   UC2_LAUNCH_CHECK();
-  if (dgamma || dbeta) {
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * H + 63) / 64), dim3(256), 0, st, nb, H, (const float*)ws,
-                       dgamma, dbeta);
+  if (dgamma || dbeta || dbias) {
+    const int nout = dbias ? 3 : 2;
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((nout * H + 63) / 64), dim3(256), 0, st, nb, H, nout,
+                       (const float*)ws, dgamma, dbeta, dbias);
     UC2_LAUNCH_CHECK();
   }
   return 0;

@@ -151,15 +151,17 @@ def ln_fwd(x2, res2, gamma, beta, eps, drop_p=0.0, seed=None, seed_imm=0, want_s
     return y, mean, rstd
 
 
-def ln_bwd(dy2, x2, res2, gamma, mean, rstd, dgamma, dbeta, drop_p=0.0, seed=None, seed_imm=0, need_dres=True):
-    """returns (dx, dres); with drop_p == 0 they are the same tensor"""
+def ln_bwd(dy2, x2, res2, gamma, mean, rstd, dgamma, dbeta, drop_p=0.0, seed=None, seed_imm=0, need_dres=True,
+           dbias=None):
+    """returns (dx, dres); with drop_p == 0 they are the same tensor.  dbias (optional, fp32 [H]) accumulates
+    the column sum of dx: the bias gradient of the dense layer that produced x, for free in the same pass."""
     M, H = x2.shape
     lib = _lib.load()
     ws = torch.empty(lib.uc2_ln_bwd_workspace(M, H) // 4, dtype=torch.float32, device=x2.device)
     dx = torch.empty_like(x2)
     dres = torch.empty_like(x2) if (drop_p > 0.0 and need_dres) else None
     call("uc2_ln_bwd", dt(x2.dtype), M, H, ptr(dy2), ptr(x2), ptr(res2), ptr(gamma), ptr(mean), ptr(rstd), drop_p,
-         ptr(seed), seed_imm, ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), ptr(ws), stream())
+         ptr(seed), seed_imm, ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(ws), stream())
     return dx, (dres if dres is not None else dx)
 
 
@@ -272,14 +274,16 @@ class BertLayerFn(torch.autograd.Function):
         G = st.grad_buf
 
         # LN2 and FFN
-        d_o2, dz2 = ln_bwd(dy2, o2, a, P["g2"].data, mean2, rstd2, G(P["g2"]), G(P["b2"]), p_h, seed, sid + 3)
-        linear_wgrad(d_o2, u, G(P["fw"]), G(P["fb"]))
+        d_o2, dz2 = ln_bwd(dy2, o2, a, P["g2"].data, mean2, rstd2, G(P["g2"]), G(P["b2"]), p_h, seed, sid + 3,
+                           dbias=G(P["fb"]))
+        linear_wgrad(d_o2, u, G(P["fw"]), None)
         d_pre = linear_dgrad(d_o2, st.compute(P["fw"], dtype), EPI_DGELU, pre)
         linear_wgrad(d_pre, a, G(P["iw"]), G(P["ib"]))
         da = linear_dgrad(d_pre, st.compute(P["iw"], dtype), EPI_ADD, dz2)
         # LN1, output projection, attention, fused QKV
-        d_o1, dz1 = ln_bwd(da, o1, x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, sid + 2)
-        linear_wgrad(d_o1, ctxv, G(P["ow"]), G(P["ob"]))
+        d_o1, dz1 = ln_bwd(da, o1, x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, sid + 2,
+                           dbias=G(P["ob"]))
+        linear_wgrad(d_o1, ctxv, G(P["ow"]), None)
         dctx = linear_dgrad(d_o1, st.compute(P["ow"], dtype))
         dqkv = attn_bwd(qkv, mask2d, ctxv, dctx, lse, B, L, nh, D, p_a, seed, sid + 1)
         dwqkv = st.grad_span(P["qw"], P["vw"], (3 * H, H))
