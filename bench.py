@@ -210,7 +210,7 @@ def main():
                        "pairs_per_gpu_per_step": a.batch, "global_batch": a.batch * world,
                        "seq_len": T_TXT + N_REG, "parallelism": "dp%d" % world, "final_loss": round(lossv, 4)},
             "mfma_frac_encoder": round(value * ENC_GFLOP_PER_PAIR * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<false,false,true> (forward X*W^T GEMMs)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_fast_kernel<false,false,true,256,32,3> (forward X*W^T GEMMs)",
                          "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "launches": n_l, "avg_us": round(sec / max(n_l, 1) * 1e6, 2)},

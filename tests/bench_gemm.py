@@ -14,11 +14,15 @@ def timeit(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e-3
 
+VARIANTS = [0, 1, 2, 3, 4, 5]   # see gf_launch2 in uc2_amd/csrc/gemm_fast.hip
+
+
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     M = B * 96
     lib = _lib.load()
     dev = "cuda"
+    only = sys.argv[2] if len(sys.argv) > 2 else None
     shapes = [("fwd qkv   ", False, False, M, 2304, 768), ("fwd out   ", False, False, M, 768, 768),
               ("fwd ffn1  ", False, False, M, 3072, 768), ("fwd ffn2  ", False, False, M, 768, 3072),
               ("dgrad qkv ", False, True, M, 768, 2304), ("dgrad ffn1", False, True, M, 768, 3072),
@@ -26,19 +30,36 @@ def main():
               ("wgrad qkv ", True, True, 2304, 768, M), ("wgrad ffn1", True, True, 3072, 768, M),
               ("wgrad ffn2", True, True, 768, 3072, M), ("wgrad out ", True, True, 768, 768, M)]
     for name, ta, tb, m, n, k in shapes:
+        if only and only not in name:
+            continue
         a = torch.randn((k, m) if ta else (m, k), device=dev).to(torch.bfloat16)
         b = torch.randn((k, n) if tb else (n, k), device=dev).to(torch.bfloat16)
         wg = ta and tb
         out = torch.zeros((m, n), dtype=torch.float32 if wg else torch.bfloat16, device=dev)
         split = ops._wgrad_split(torch.bfloat16, m, n, k) if wg else 1
         res = []
-        for generic in (0, 1):
-            lib.uc2_gemm_force_generic(generic)
-            fn = lambda: ops.gemm(a, b, m, n, k, ta=ta, tb=tb, out=out, accumulate=wg, split_k=split)
-            t = timeit(fn)
-            res.append(2.0 * m * n * k / t / 1e12)
+        fn = lambda: ops.gemm(a, b, m, n, k, ta=ta, tb=tb, out=out, accumulate=wg, split_k=split)
+        for rep in range(2):
+            for v in VARIANTS:
+                lib.uc2_gemm_set_variant(v)
+                t = timeit(fn)
+                if rep == 1:
+                    res.append(2.0 * m * n * k / t / 1e12)
+        diag = {}
+        for mode, label in ((1, "fetch only"), (2, "fetch+lds-read"), (4, "fetch+mfma"), (8, "full, no epilogue"), (17, "fetch + epilogue")):
+            lib.uc2_gemm_set_fetch_only(mode)
+            diag[label] = []
+            for v in VARIANTS:
+                lib.uc2_gemm_set_variant(v)
+                diag[label].append(2.0 * m * n * k / timeit(fn) / 1e12)
+        lib.uc2_gemm_set_fetch_only(0)
+        lib.uc2_gemm_force_generic(1)
+        tg = 2.0 * m * n * k / timeit(fn) / 1e12
         lib.uc2_gemm_force_generic(0)
-        print("%s M=%6d N=%5d K=%6d split=%2d  pipelined %7.1f TF/s   generic %7.1f TF/s" % (name, m, n, k, split, res[0], res[1]))
+        lib.uc2_gemm_set_variant(-2)
+        print("%s M=%6d N=%5d K=%6d split=%2d  " % (name, m, n, k, split) + " ".join("v%d %6.1f" % (v, r) for v, r in zip(VARIANTS, res)) + "  generic %6.1f" % tg)
+        for label, fo in diag.items():
+            print("      %-16s (equivalent TF/s):           " % label + " ".join("v%d %6.1f" % (v, r) for v, r in zip(VARIANTS, fo)))
 
 if __name__ == "__main__":
     main()

@@ -300,11 +300,14 @@ def test_attention_mfma_equals_simple_under_dropout(B, L, nh, D):
     assert rel_err(g2.float(), g1.float()) < 2e-2
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 768, 768), (776, 2304, 832), (128, 136, 64)])
-def test_gemm_pipelined_equals_generic(ta, tb, M, N, K):
-    """the LDS-DMA pipelined kernel and the generic register-staged kernel compute the same bf16 result"""
+def test_gemm_pipelined_equals_generic(ta, tb, M, N, K, variant):
+    """the LDS-DMA pipelined kernels (every tile/stage variant) and the generic register-staged kernel
+    compute the same bf16 result, bit for bit"""
     lib = ops._lib.load()
+    lib.uc2_gemm_set_variant(variant)
     a = rnd((K, M) if ta else (M, K), 1, dtype=torch.bfloat16)
     b = rnd((K, N) if tb else (N, K), 2, dtype=torch.bfloat16)
     bias = rnd((N,), 3)
@@ -322,4 +325,5 @@ def test_gemm_pipelined_equals_generic(ta, tb, M, N, K):
     ops.gemm(a, b, M, N, K, ta=ta, tb=tb, out=acc_ref, accumulate=True, split_k=2 if K >= 128 else 1)
     lib.uc2_gemm_force_generic(0)
     ops.gemm(a, b, M, N, K, ta=ta, tb=tb, out=acc, accumulate=True, split_k=2 if K >= 128 else 1)
+    lib.uc2_gemm_set_variant(-2)
     assert rel_err(acc, acc_ref) < 1e-5

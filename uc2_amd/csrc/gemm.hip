@@ -241,7 +241,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     __syncthreads();
   }
 
-  bf16_tile_epilogue<TACC>(p, acc, m0, n0, wm, wn, lane);
+  // (the K loop ends with a barrier: every wave is done reading the staging tiles)
+  bf16_tile_epilogue<TACC>(p, acc, m0, n0, wm, wn, lane, smem + w * EPI_LDS_PER_WAVE);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -34,7 +34,7 @@ __device__ __forceinline__ void epi_store(const GemmArgs& p, int m, int n, float
   const size_t ic = (size_t)m * p.ldc + n;
   if (p.c_f32) {
     float* c = reinterpret_cast<float*>(p.C);
-    if (p.atomic) atomicAdd(c + ic, v);
+    if (p.atomic & 1) atomicAdd(c + ic, v);
     else if (p.accumulate) c[ic] += v;
     else c[ic] = v;
   } else {
@@ -45,58 +45,99 @@ __device__ __forceinline__ void epi_store(const GemmArgs& p, int m, int n, float
 }
 
 
-// write one workgroup tile (4 waves as 2x2, each 64x64 = 2x2 MFMA 32x32 tiles) through the epilogue.
-// TACC = true : acc holds D^T (lane owns 4 consecutive n of one m -> 8-byte bf16 stores)
-// TACC = false: acc holds D   (one register = two 128-B row segments -> full-rate f32 atomics)
+// Write one wave's 64x64 block of the workgroup tile through the epilogue.
+// TACC = true : acc holds D^T (lane = one output row m, 4 consecutive n per register group).  The block is
+//               staged through a wave-private LDS area (EPI_LDS_PER_WAVE bytes, fp32, 32 rows at a time) and
+//               leaves as whole 128-byte row segments, 16 bytes per lane: bias, aux reads/writes and the C
+//               stores are all full-line accesses.  (Per-lane 8-byte stores straight from the accumulator
+//               layout touch 32 different lines per instruction and cost more than the whole K loop at K=768.)
+// TACC = false: acc holds D (one register = two 128-B row segments): f32 atomics / accumulation, direct.
+// The caller must have passed a workgroup barrier after its last LDS read before calling this.
+#define EPI_ROW_F32 68                       /* 64 + 4 floats of padding: conflict-free b128 rows */
+#define EPI_LDS_PER_WAVE (32 * EPI_ROW_F32 * 4)
+
 template <bool TACC>
 __device__ __forceinline__ void bf16_tile_epilogue(const GemmArgs& p, const f32x16 (&acc)[2][2], int m0, int n0,
-                                                   int wm, int wn, int lane) {
+                                                   int wm, int wn, int lane, char* lds_wave) {
   // 32x32 C/D map: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const int h = lane >> 5, c31 = lane & 31;
+  if (TACC) {
+    float* st = reinterpret_cast<float*>(lds_wave);
+    const int nb = n0 + wn * 64;
+    const int cg = lane & 7, rr = lane >> 3;            // store phase: lane -> (row rr + 8*it, 8 columns at 8*cg)
+    const int n = nb + 8 * cg;
+    const bool vec_ok = !p.c_f32 && !p.accumulate && ((p.ldc & 7) == 0) && ((p.ldaux & 7) == 0) && (n + 7 < p.N) &&
+                        ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(p.aux_in) & 15) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(p.aux_out) & 15) == 0);
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+      for (int e = 0; e < 8; ++e) bv[e] = (n + e < p.N) ? p.bias[n + e] : 0.f;
+    }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int mb = m0 + wm * 64 + i * 32, nb = n0 + wn * 64 + j * 32;
-      if (TACC) {
-        const int m = mb + c31;
+    for (int i = 0; i < 2; ++i) {
+      // ---- accumulator layout -> LDS (fp32): row = c31, columns 32*j + 8*c + 4*h .. +3
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int n = nb + 8 * c + 4 * h;
-          float v[4] = {acc[i][j][4 * c], acc[i][j][4 * c + 1], acc[i][j][4 * c + 2], acc[i][j][4 * c + 3]};
-          const bool fast = (m < p.M) && (n + 3 < p.N) && !p.c_f32 && !p.accumulate && ((p.ldc & 3) == 0) &&
-                            ((p.ldaux & 3) == 0);
-          if (fast) {
-            if (p.bias) {
-              const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-              v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          *reinterpret_cast<float4*>(st + c31 * EPI_ROW_F32 + 32 * j + 8 * c + 4 * h) =
+              make_float4(acc[i][j][4 * c], acc[i][j][4 * c + 1], acc[i][j][4 * c + 2], acc[i][j][4 * c + 3]);
+      __builtin_amdgcn_wave_barrier();
+      // ---- LDS -> global: 8 rows x 128 B per wave-instruction
+      const int mb = m0 + wm * 64 + i * 32;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = rr + 8 * it, m = mb + r;
+        const float4 lo = *reinterpret_cast<const float4*>(st + r * EPI_ROW_F32 + 8 * cg);
+        const float4 hi = *reinterpret_cast<const float4*>(st + r * EPI_ROW_F32 + 8 * cg + 4);
+        const float raw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (m >= p.M) continue;
+        if (vec_ok) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = raw[e] + bv[e];
+          const size_t ia = (size_t)m * p.ldaux + n;
+          if (p.epi == EPI_GELU) {
+            if (p.aux_out) {
+              bf16x8 o;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+              *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.aux_out) + ia) = o;
             }
-            const size_t ia = (size_t)m * p.ldaux + n;
-            if (p.epi == EPI_GELU) {
-              if (p.aux_out) Vec4<bf16>::store(reinterpret_cast<bf16*>(p.aux_out) + ia, v);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
-            } else if (p.epi == EPI_DGELU) {
-              float x[4];
-              Vec4<bf16>::load(reinterpret_cast<const bf16*>(p.aux_in) + ia, x);
+            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+          } else if (p.epi == EPI_DGELU) {
+            const bf16x8 x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.aux_in) + ia);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(x[e]);
-            } else if (p.epi == EPI_ADD) {
-              float x[4];
-              Vec4<bf16>::load(reinterpret_cast<const bf16*>(p.aux_in) + ia, x);
+            for (int e = 0; e < 8; ++e) v[e] *= dgelu_f((float)x[e]);
+          } else if (p.epi == EPI_ADD) {
+            const bf16x8 x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.aux_in) + ia);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += x[e];
-            } else if (p.epi == EPI_TANH) {
+            for (int e = 0; e < 8; ++e) v[e] += (float)x[e];
+          } else if (p.epi == EPI_TANH) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
-            }
-            Vec4<bf16>::store(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n, v);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) epi_store<bf16>(p, m, n + e, v[e]);
+            for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
           }
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = o;
+        } else {
+          // ragged / unaligned / fp32-output tiles: element-wise path (bias is applied inside epi_store)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) epi_store<bf16>(p, m, n + e, raw[e]);
         }
-      } else {
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int mb = m0 + wm * 64 + i * 32, nb = n0 + wn * 64 + j * 32;
         const int n = nb + c31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -104,5 +145,5 @@ __device__ __forceinline__ void bf16_tile_epilogue(const GemmArgs& p, const f32x
           epi_store<bf16>(p, m, n, acc[i][j][r]);
         }
       }
-    }
+  }
 }
