@@ -1,0 +1,131 @@
+/* uc2_hip.h -- C ABI of libuc2_hip.so: the MI355X (gfx950) kernels of the UC2 encoder hot path.
+ *
+ * The reference (zmykevin/UC2) is pure Python on PyTorch; it has no FFI layer of its own.  Its hot path
+ * reaches the device through torch ops, apex.FusedLayerNorm and Horovod.  This library is what a binding
+ * for that path binds instead: every entry point below names the reference code it replaces
+ * (paths relative to the reference repository).  uc2_amd/_lib.py is the ctypes binding used by the
+ * reference-shaped Python modules in uc2_amd/; INTEGRATION.md shows the stub a maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only: raw DEVICE pointers, explicit sizes / leading dimensions, no torch types;
+ *   - dtype: UC2_F32 (0) = fp32 parity mode, UC2_BF16 (1) = bf16 throughput mode (fp32 accumulate / statistics);
+ *     parameters that are always fp32 (biases, LayerNorm gains, embedding tables, gradients of weights,
+ *     optimizer state) are typed `float*`;
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t) and returns; no call synchronises, allocates or
+ *     frees; workspaces are caller-owned (sizes from the *_workspace functions);
+ *   - return value: 0 = ok, < 0 = argument error, > 0 = hipError_t; uc2_last_error() describes the last failure
+ *     of the calling thread; nothing throws across the boundary;
+ *   - dropout masks are a pure function of (seed, element index): seed = *seed_ptr (device, may be NULL) + seed_imm,
+ *     so the backward regenerates the forward's mask and a captured hipGraph draws fresh masks per replay;
+ *   - not re-entrant per stream ordering only: one host thread per process drives the step (one process per GPU).
+ */
+#ifndef UC2_HIP_H
+#define UC2_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { UC2_F32 = 0, UC2_BF16 = 1 };
+enum { UC2_EPI_NONE = 0, UC2_EPI_GELU = 1, UC2_EPI_DGELU = 2, UC2_EPI_ADD = 3, UC2_EPI_TANH = 4 };
+
+/* ---- library ---------------------------------------------------------------------------------------- */
+int uc2_abi_version(void);
+const char* uc2_last_error(void);
+int uc2_device_info(int* cu_count, int* clock_khz, char* arch, int arch_len);
+
+/* ---- dense contractions: nn.Linear forward / backward (model/layer.py:76-78,111,139,152; model/model.py:355,357;
+ *      layer.py:257-265 tied decoder; model/model.py:1155 transposed regression weight) ------------------------
+ *   C[M,N] (=|+=) epi( sum_k A(m,k) * B(n,k) + bias[n] )
+ *   A(m,k) = A[m*lda+k] (trans_a=0) or A[k*lda+m] (trans_a=1);  B(n,k) = B[n*ldb+k] (trans_b=0) or B[k*ldb+n]
+ *   forward Y = X W^T: (0,0); input gradient dX = dY W: (0,1); weight gradient dW += dY^T X: (1,1), accumulate,
+ *   split_k > 1 reduces with fp32 atomics.  epilogue: GELU (erf form, optional pre-activation to aux_out),
+ *   DGELU (multiply by gelu'(aux_in)), ADD (+ aux_in), TANH.  c_is_f32: fp32 output for bf16 inputs. */
+int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+             void* C, int ldc, int c_is_f32, const float* bias, int epilogue, const void* aux_in, void* aux_out,
+             int ldaux, int accumulate, int split_k, void* stream);
+/* kernel selection knobs for A/B tests (tests/bench_gemm.py): not needed in production */
+int uc2_gemm_force_generic(int on);
+int uc2_gemm_set_variant(int variant);
+int uc2_gemm_set_fetch_only(int diagnostic_mode);
+
+/* ---- LayerNorm fused with dropout + residual (apex FusedLayerNorm, model/layer.py:25; the dense->dropout->
+ *      LayerNorm(x + residual) tails at model/layer.py:111-115,152-156; embeddings model/model.py:331,358-362) -----
+ *   y = LN(dropout(x) + residual) * gamma + beta ; mean/rstd [M] saved for the backward.
+ *   backward: dx (grad of x), dres (grad of residual; may be NULL; equals dx when drop_p == 0), dgamma/dbeta
+ *   accumulated (+=), and optionally dbias += column-sum(dx) = bias gradient of the dense layer producing x. */
+int uc2_ln_fwd(int dtype, int M, int H, const void* x, const void* residual, const float* gamma, const float* beta,
+               float eps, float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, void* y, float* mean,
+               float* rstd, void* stream);
+size_t uc2_ln_bwd_workspace(int M, int H);
+int uc2_ln_bwd(int dtype, int M, int H, const void* dy, const void* x, const void* residual, const float* gamma,
+               const float* mean, const float* rstd, float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm,
+               void* dx, void* dres, float* dgamma, float* dbeta, float* dbias, void* ws, void* stream);
+
+/* ---- fused scaled-dot-product attention over the packed QKV projection (BertSelfAttention.forward,
+ *      model/layer.py:75-101; additive key mask model/model.py:433-436) --------------------------------------------
+ *   qkv [B*L, 3*nh*D] (q|k|v, head h at column h*D), mask [B, L] fp32 additive, ctx [B*L, nh*D], lse [B,nh,L].
+ *   impl: 0 auto, 1 fp32-math kernels (any dtype), 2 MFMA kernels (bf16, L <= 160, D in {32,64}). */
+int uc2_attn_fwd(int dtype, int impl, int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
+                 float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse, void* stream);
+int uc2_attn_bwd(int dtype, int impl, int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
+                 float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx, const void* dctx,
+                 const float* lse, void* dqkv, void* stream);
+int uc2_attn_mfma_supported(int L, int D);
+
+/* ---- embeddings and sequence assembly (model/model.py:280-335, 352-364, 412-425) ---------------------------- */
+int uc2_position_ids(int B, int T, const int64_t* ids, int64_t pad, int64_t* out, void* stream);
+int uc2_embed_fwd(int dtype, int rows, int H, const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
+                  int type_const, const float* word, const float* pos, const float* type, void* out, void* stream);
+int uc2_embed_bwd(int dtype, int rows, int H, const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
+                  const void* dpre, float* dword, float* dpos, float* dtype_tab, void* stream);
+int uc2_add_rowvec(int a_dtype, int dtype, int rows, int H, const void* a, const void* b, const float* vec,
+                   const uint8_t* rowmask, void* out, void* stream);
+int uc2_gather_rows_fwd(int dtype, int B, int S, int L, int H, const void* src, const int64_t* index, void* out,
+                        void* stream);
+int uc2_gather_rows_bwd(int dtype, int B, int S, int L, int H, const void* dout, const int64_t* index, void* dsrc,
+                        void* stream);
+
+/* ---- heads and losses (model/model.py:583-596, 653-657, 668-688, 697-732, 738-775; model/itm.py:45-53) ----- */
+int uc2_select_rows(int dtype, int n, int H, const void* src, int ld_src, const int64_t* rows, void* dst, int ld_dst,
+                    int scatter, void* stream);
+int uc2_colsum_accum(int dtype, int M, int N, const void* X, int ldx, const uint8_t* rowmask, float* out,
+                     void* stream);
+int uc2_ce_fwd(int dtype, int n, int V, const void* logits, int ld, const int64_t* labels, int64_t ignore_index,
+               float* loss, float* lse, int64_t* argmax, void* stream);
+int uc2_ce_bwd(int dtype, int n, int V, void* logits_inout, int ld, const int64_t* labels, int64_t ignore_index,
+               const float* lse, const float* gout, void* stream);
+int uc2_kl_fwd(int dtype, int n, int V, const void* pred, int ld, const float* target, const float* lse, float* loss,
+               void* stream);
+int uc2_kl_bwd(int dtype, int n, int V, const void* pred, int ld, const float* target, const float* lse,
+               const float* gout, void* dpred, void* stream);
+int uc2_mse(int dtype, size_t n, const void* pred, const float* target, const float* gout, float* loss, void* dpred,
+            void* stream);
+int uc2_triplet(int dtype, int n, int sample_size, float margin, const void* score, const float* gout, float* loss,
+                void* dscore, void* stream);
+int uc2_dtanh(int dtype, size_t n, const void* y, const void* dy, void* dx, void* stream);
+int uc2_dgelu(int dtype, size_t n, const void* pre, const void* dy, void* dx, void* stream);
+int uc2_cast(int from_dtype, int to_dtype, size_t n, const void* in, void* out, void* stream);
+
+/* ---- optimizer step and gradient clipping (optim/adamw.py:40-103; clip_grad_norm_ at pretrain.py:610) ------
+ *   chunks: DEVICE array of uc2_adam_chunk records built once by the host; active / steps: DEVICE int32 per
+ *   parameter (active == 0 means p.grad is None: skipped; steps = updates applied so far, bumped by the call).
+ *   Per-group scalars are passed by value every step (the loop rewrites lr each step, pretrain.py:574-576). */
+typedef struct uc2_adam_chunk {
+  float* p; float* g; float* m; float* v; void* p_bf16;   /* p_bf16 may be NULL */
+  uint32_t n; uint16_t group; uint16_t param;
+} uc2_adam_chunk;
+size_t uc2_adamw_chunk_bytes(void);
+int uc2_adamw_step(const void* chunks, int n_chunks, int n_params, int n_groups, const float* lr, const float* beta1,
+                   const float* beta2, const float* eps, const float* weight_decay, const int* correct_bias,
+                   const int* active_dev, int* steps_dev, const float* grad_scale_dev, int zero_grad, void* stream);
+int uc2_sumsq_accum(size_t n, const float* x, float* out, void* stream);
+int uc2_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream);
+int uc2_scale(size_t n, float* x, const float* scale_dev, float scale_imm, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UC2_HIP_H */

@@ -1,0 +1,246 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports everything include/uc2_hip.h declares,
+the reference-shaped modules expose the reference's parameter names / state_dict keys / grouping, the
+flat arenas behave, the product path refuses to run without a GPU (no CPU fallback), and the
+data-parallel helpers are correct under a 2-process gloo group."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import specs
+from oracle import uc2_oracle as O
+from uc2_amd import _lib
+from uc2_amd.model.itm import VLXLMRForImageTextRetrieval
+from uc2_amd.model.layer import BertLayer
+from uc2_amd.model.model import VLXLMRConfig, VLXLMRForPretraining
+from uc2_amd.optim import sched
+from uc2_amd.optim.misc import param_groups
+from uc2_amd.store import ParamStore, store_of
+from util import golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def tiny_cfg():
+    d = dict(hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+             max_position_embeddings=514, type_vocab_size=2, initializer_range=0.02, layer_norm_eps=1e-5,
+             pad_token_id=1)
+    d.update(O.TINY)
+    return VLXLMRConfig.from_dict(d)
+
+
+# ------------------------------------------------------------------------------------------ C ABI
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "uc2_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(uc2_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_is_valid_c():
+    subprocess.check_call(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "uc2_hip.h")])
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()                                   # raises if the .so or any bound symbol is missing
+    syms = header_symbols()
+    assert len(syms) >= 35
+    for s in syms:
+        assert hasattr(lib, s), "libuc2_hip.so does not export %s" % s
+        assert s in _lib.SIGNATURES, "uc2_amd/_lib.py does not bind %s" % s
+    for s in _lib.SIGNATURES:
+        assert s in syms, "%s is bound by uc2_amd/_lib.py but not declared in include/uc2_hip.h" % s
+    assert lib.uc2_abi_version() == 1
+    assert lib.uc2_adamw_chunk_bytes() == 48            # sizeof(uc2_adam_chunk)
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    lib = _lib.load()
+    # bad dtype -> negative return code and a message, no kernel launch
+    rc = lib.uc2_gemm(7, 0, 0, 1, 1, 1, None, 1, None, 1, None, 1, 0, None, 0, None, None, 0, 0, 1, None)
+    assert rc < 0
+    assert b"dtype" in lib.uc2_last_error()
+    with pytest.raises(_lib.Uc2Error):
+        _lib.check(rc)
+
+
+# ------------------------------------------------------------------------------------------ module surface
+def test_parameter_names_match_reference():
+    cfg = tiny_cfg()
+    m = VLXLMRForPretraining(cfg, img_dim=2048, img_label_dim=1601)
+    ocfg = O.Config.make(**O.TINY)
+    ref = specs.pretrain_shapes(ocfg)
+    got = [(n, tuple(p.shape)) for n, p in m.named_parameters()]
+    assert got == list(ref.items())
+    sd = set(m.state_dict().keys())
+    for tied in ("cls.decoder.weight", "cls.decoder.bias", "feat_regress.weight"):
+        assert tied in sd                                # tied tensors keep their reference state_dict keys
+    assert m.cls.decoder.weight is m.roberta.embeddings.word_embeddings.weight
+    assert m.feat_regress.weight is m.roberta.img_embeddings.img_linear.weight
+    r = VLXLMRForImageTextRetrieval(cfg, img_dim=2048)
+    assert [(n, tuple(p.shape)) for n, p in r.named_parameters()] == list(specs.itm_rank_shapes(ocfg).items())
+    total = sum(p.numel() for p in m.parameters())
+    assert total == sum(int(np.prod(s)) for s in ref.values())
+
+
+def test_state_dict_roundtrip_and_from_pretrained(tmp_path):
+    cfg = tiny_cfg()
+    a = VLXLMRForPretraining(cfg, 2048, 1601)
+    sd = {k: v.clone() for k, v in a.state_dict().items()}
+    # checkpoints in the wild use gamma/beta for LayerNorm (model/model.py:205-216)
+    sd_old = {}
+    for k, v in sd.items():
+        k2 = k.replace("LayerNorm.weight", "LayerNorm.gamma").replace("LayerNorm.bias", "LayerNorm.beta")
+        sd_old[k2] = v
+    cfg_file = tmp_path / "cfg.json"
+    cfg_file.write_text(cfg.to_json_string())
+    b = VLXLMRForPretraining.from_pretrained(str(cfg_file), sd_old, img_dim=2048, img_label_dim=1601)
+    for (n1, p1), (n2, p2) in zip(a.named_parameters(), b.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
+
+
+def test_param_groups_and_schedule_against_golden():
+    g = golden("adamw")
+    m = VLXLMRForPretraining(tiny_cfg(), 2048, 1601)
+    names = {id(p): n for n, p in m.named_parameters()}
+    groups = param_groups(m, 0.01)
+    assert [names[id(p)] for p in groups[1]["params"]] == list(g["adamw/no_decay_names"])
+    assert [names[id(p)] for p in groups[0]["params"]] == list(g["adamw/decay_names"])
+    assert groups[0]["weight_decay"] == 0.01 and groups[1]["weight_decay"] == 0.0
+
+    class Opts:
+        learning_rate, warmup_steps, num_train_steps = 4e-5, 10000, 200000
+    for decay in ("linear", "invsqrt", "constant"):
+        Opts.decay = decay
+        mine = [sched.get_lr_sched(int(s), Opts) for s in g["sched/steps"]]
+        assert np.allclose(mine, g["sched/%s" % decay], rtol=1e-12, atol=0)
+
+
+# ------------------------------------------------------------------------------------------ arenas
+def test_param_store_layout_and_gradients():
+    layer = BertLayer(tiny_cfg())
+    before = {n: p.detach().clone() for n, p in layer.named_parameters()}
+    st = store_of(layer)
+    assert isinstance(st, ParamStore) and store_of(layer) is st
+    for n, p in layer.named_parameters():
+        assert torch.equal(p, before[n]) and st.owns(p)          # re-homed, values unchanged
+    s = layer.attention.self
+    H = s.query.weight.shape[0]
+    w = st.span(st.data, s.query.weight, s.value.weight, (3 * H, H))    # q|k|v adjacent: zero-copy fused view
+    assert torch.equal(w[:H], s.query.weight) and torch.equal(w[2 * H:], s.value.weight)
+    b = st.span(st.data, s.query.bias, s.value.bias, (3 * H,))
+    assert torch.equal(b[H:2 * H], s.key.bias)
+    w[0, 0] = 123.0
+    assert s.query.weight[0, 0].item() == 123.0                          # views alias the parameters
+    # gradient arena: installed lazily as .grad, accumulates, zero_grad resets and drops .grad
+    p = layer.output.dense.weight
+    assert p.grad is None
+    gb = st.grad_buf(p)
+    assert p.grad is not None and p.grad.data_ptr() == gb.data_ptr()
+    gb.add_(1.0)
+    st.grad_buf(p).add_(1.0)
+    assert float(p.grad.sum()) == 2.0 * p.numel()
+    gq = st.grad_span(s.query.weight, s.value.weight, (3 * H, H))
+    gq[H:2 * H].fill_(3.0)
+    assert float(s.key.weight.grad.mean()) == 3.0
+    st.zero_grad()
+    assert all(q.grad is None for q in layer.parameters()) and float(st.grad.abs().sum()) == 0.0
+    # a foreign .grad (e.g. assigned by user code) is folded into the arena
+    p.grad = torch.full_like(p, 5.0)
+    assert float(st.grad_buf(p).mean()) == 5.0 and p.grad.data_ptr() == st.view(st.grad, p).data_ptr()
+    # p.grad reset behind the store's back (plain nn.Module.zero_grad) must not leak stale values
+    p.grad = None
+    assert float(st.grad_buf(p).abs().sum()) == 0.0
+
+
+def test_parent_store_adopts_children():
+    m = VLXLMRForPretraining(tiny_cfg(), 2048, 1601)
+    st_layer = store_of(m.roberta.encoder.layer[0])
+    st = store_of(m)
+    assert st is not st_layer
+    assert store_of(m.roberta.encoder.layer[0]) is st and store_of(m.cls) is st
+    assert st.owns(m.roberta.embeddings.word_embeddings.weight)
+    off = st.offsets
+    l1 = m.roberta.encoder.layer[1]
+    ps = list(l1.parameters())
+    lo, hi = min(off[id(p)] for p in ps), max(off[id(p)] + p.numel() for p in ps)
+    assert hi - lo < sum(p.numel() for p in ps) + 64 * len(ps)           # one layer = one contiguous bucket
+
+
+def test_no_cpu_fallback():
+    """the product path must fail loudly without a GPU instead of computing on the CPU"""
+    m = VLXLMRForPretraining(tiny_cfg(), 2048, 1601)
+    from uc2_amd.utils import synth
+    b = {k: v for k, v in synth.make_batch(1000, 2, 8, 6, task="itm").items() if not k.startswith("_")}
+    with pytest.raises(Exception) as ei:
+        m(b, "itm")
+    assert isinstance(ei.value, (_lib.Uc2Error, RuntimeError))
+    src = open(os.path.join(ROOT, "uc2_amd", "ops.py")).read() + open(os.path.join(ROOT, "uc2_amd", "_lib.py")).read()
+    assert "import oracle" not in src and "from oracle" not in src
+
+
+# ------------------------------------------------------------------------------------------ data parallel (gloo)
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from uc2_amd.model.layer import BertLayer
+from uc2_amd.model.model import VLXLMRConfig, VLXLMREncoder
+from uc2_amd.store import store_of
+from uc2_amd.utils import distributed as D
+from oracle import uc2_oracle as O
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+d = dict(hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, max_position_embeddings=514,
+         type_vocab_size=2, initializer_range=0.02, layer_norm_eps=1e-5, pad_token_id=1); d.update(O.TINY)
+torch.manual_seed(100 + rank)
+enc = VLXLMREncoder(VLXLMRConfig.from_dict(d))
+st = store_of(enc)
+# 1. broadcast_tensors: rank 0's weights everywhere (pretrain.py:457)
+D.broadcast_tensors([p.data for p in enc.parameters()], 0)
+ref = [torch.zeros_like(p) for p in enc.parameters()]
+for r_, p in zip(ref, enc.parameters()): r_.copy_(p)
+for r_ in ref: dist.broadcast(r_, 0)
+assert all(torch.equal(a, b) for a, b in zip(ref, enc.parameters()))
+# 2. all_reduce_and_rescale_tensors on arena-backed gradients, with the overlapped per-layer path armed
+sync = D.GradSync(enc)
+for p in enc.parameters():
+    st.grad_buf(p).copy_(torch.full_like(p, float(rank + 1)) * (1 + torch.arange(p.numel()).view(p.shape) %% 7))
+expect = [sum((r + 1) for r in range(world)) / world / 2.0 * (1 + torch.arange(p.numel()).view(p.shape) %% 7) for p in enc.parameters()]
+sync.arm()
+for layer in reversed(list(enc.layer)):        # what BertLayerFn.backward does as each layer finishes
+    layer.grad_ready_hook(layer)
+grads = [p.grad.data for p in enc.parameters() if p.grad is not None]
+D.all_reduce_and_rescale_tensors(grads, 2.0)
+for p, e in zip(enc.parameters(), expect):
+    assert torch.allclose(p.grad, e.to(p.dtype), rtol=1e-6), "arena all-reduce mismatch"
+# unarmed path + loose (non-arena) tensors, like the reference's flatten/unflatten
+for p in enc.parameters():
+    st.grad_buf(p).fill_(float(rank))
+loose = [torch.full((5, 3), float(rank)), torch.full((7,), 2.0 * rank)]
+D.all_reduce_and_rescale_tensors([p.grad.data for p in enc.parameters()] + loose, 1.0)
+mean = sum(range(world)) / world
+assert all(torch.allclose(p.grad, torch.full_like(p, mean)) for p in enc.parameters())
+assert torch.allclose(loose[0], torch.full((5, 3), mean)) and torch.allclose(loose[1], torch.full((7,), 2 * mean))
+# 3. python-object helpers
+assert D.all_gather_list({"rank": rank}) == [{"rank": r} for r in range(world)]
+assert D.any_broadcast("task-%%d" %% rank, 0) == "task-0"
+dist.barrier(); dist.destroy_process_group()
+print("worker %%d ok" %% rank)
+'''
+
+
+def test_data_parallel_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", WORLD_SIZE="2", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
+        assert "worker %d ok" % r in o

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16_fast_kernel(GemmArgs p) {
 // ------------------------------------------------------------------------------------------------------
 static int g_fetch_only = 0;
 extern "C" int uc2_gemm_set_fetch_only(int v) { g_fetch_only = v; return 0; }
-static int g_variant = -1;          // -1 = read UC2_GEMM_VARIANT; -2 = per-shape heuristic (default); 0..5 = fixed
+static int g_variant = -1;          // -1 = read UC2_GEMM_VARIANT; -2 = per-shape heuristic (default); 0..5 = fixed; 99 = generic kernel
 extern "C" int uc2_gemm_set_variant(int v) { g_variant = v; return 0; }
 
 template <bool TA, bool TB, bool TACC, int BM, int BK, int NSTAGE>
@@ -264,6 +264,7 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
   if (trans_b ? ((p.N & 7) != 0 || p.N < 8) : (p.N < 1)) return 0;
   if (g_variant == -1) { const char* e = getenv("UC2_GEMM_VARIANT"); g_variant = e ? atoi(e) : -2; }
   int variant = g_variant;
+  if (variant == 99) return 0;                       // caller asked for the generic kernel
   if (variant == -2) {
     // measured on MI355X (tests/bench_gemm.py, profiles/): forward X*W^T -> 256x128x32 ring of 3, 2 WG/CU;
     // input-gradient dY*W with a narrow output -> the generic register-staged kernel (3 WG/CU) wins;

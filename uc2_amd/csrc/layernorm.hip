@@ -169,23 +169,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
   }
 }
 
-// second stage: 64 columns per workgroup, the 4 waves split the partial rows, LDS combine
+// second stage: 64 columns x (a slice of the partial rows) per workgroup; the 4 waves split the slice,
+// LDS combine, one atomic per column and slice (gridDim.y slices keep all CUs busy on the 1024 x 3H partials)
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(int nblk, int H, int nout, const float* __restrict__ ws,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             float* __restrict__ dbias) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + lane;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
   float s = 0.f;
   if (idx < nout * H)
-    for (int b = wv; b < nblk; b += 4) s += ws[(size_t)b * 3 * H + idx];
+    for (int b = b0 + wv; b < b1; b += 4) s += ws[(size_t)b * 3 * H + idx];
   red[wv][lane] = s;
   __syncthreads();
   if (wv == 0 && idx < nout * H) {
     s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-    if (idx < H) { if (dgamma) dgamma[idx] += s; }
-    else if (idx < 2 * H) { if (dbeta) dbeta[idx - H] += s; }
-    else { if (dbias) dbias[idx - 2 * H] += s; }
+    if (idx < H) { if (dgamma) atomicAdd(dgamma + idx, s); }
+    else if (idx < 2 * H) { if (dbeta) atomicAdd(dbeta + idx - H, s); }
+    else { if (dbias) atomicAdd(dbias + idx - 2 * H, s); }
   }
 }
 
@@ -247,7 +250,7 @@ extern "C" int uc2_ln_bwd(int dtype, int M, int H, const void* dy, const void* x
   UC2_LAUNCH_CHECK();
   if (dgamma || dbeta || dbias) {
     const int nout = dbias ? 3 : 2;
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((nout * H + 63) / 64), dim3(256), 0, st, nb, H, nout,
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((nout * H + 63) / 64, nb >= 256 ? 16 : 1), dim3(256), 0, st, nb, H, nout,
                        (const float*)ws, dgamma, dbeta, dbias);
     UC2_LAUNCH_CHECK();
   }

@@ -106,31 +106,93 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
 
 
 def _wgrad_split(dtype, n_out, n_in, rows):
-    """split-K factor for a weight-gradient GEMM (contraction over `rows` tokens): aim for >= 2 workgroups per CU"""
-    tile = 64 if dtype == torch.float32 else 128
-    tiles = ((n_out + tile - 1) // tile) * ((n_in + tile - 1) // tile)
-    s = max(1, min(512 // max(tiles, 1), (rows + 255) // 256))
-    return s
+    """split-K factor for a weight-gradient GEMM (contraction over `rows` tokens): the output is small
+    (n_out x n_in), so the token axis is split until there are ~2 workgroups per CU (256 CUs); each slice keeps
+    >= 1024 rows so the fp32 atomic reduction stays a small fraction of the traffic"""
+    tm, tn = (64, 64) if dtype == torch.float32 else (256, 128)
+    tiles = ((n_out + tm - 1) // tm) * ((n_in + tn - 1) // tn)
+    s = (512 + tiles - 1) // max(tiles, 1)
+    return max(1, min(s, (rows + 1023) // 1024))
+
+
+# ---- per-shape kernel selection: measured once per (layout, shape) on the device, then cached ----------
+AUTOTUNE = True
+_TUNE = {}
+_FWD_CANDIDATES = ((99, 1), (0, 1), (1, 1), (2, 1))             # (kernel variant, split_k); 99 = generic kernel
+_WGRAD_SPLITS = (2, 3, 4, 6, 8, 12, 16)
+
+
+def _time_gemm(fn, reps=3):
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def gemm_plan(dtype, ta, tb, M, N, K, wgrad=False):
+    """(variant, split_k) for one bf16 GEMM shape.  The first call for a shape times the candidate kernels
+    (gemm.hip generic, gemm_fast.hip ring variants, split-K factors for weight gradients) on scratch buffers
+    and caches the winner; later calls are a dict lookup.  fp32 (parity mode) and small shapes use defaults."""
+    if dtype != torch.bfloat16:
+        return -2, (_wgrad_split(dtype, M, N, K) if wgrad else 1)
+    key = (bool(ta), bool(tb), M, N, K, wgrad)
+    hit = _TUNE.get(key)
+    if hit is not None:
+        return hit
+    default = (-2, _wgrad_split(dtype, M, N, K) if wgrad else 1)
+    if (not AUTOTUNE) or float(M) * N * K < 2.0 ** 31 or torch.cuda.is_current_stream_capturing():
+        return default
+    dev = torch.device("cuda", torch.cuda.current_device())
+    a = torch.randn((K, M) if ta else (M, K), device=dev).to(torch.bfloat16)
+    b = torch.randn((K, N) if tb else (N, K), device=dev).to(torch.bfloat16)
+    out = torch.zeros((M, N), dtype=torch.float32 if wgrad else torch.bfloat16, device=dev)
+    lib = _lib.load()
+    cands = [(v, s) for v in (99, 1, 0) for s in _WGRAD_SPLITS if s * 1024 <= K] if wgrad else list(_FWD_CANDIDATES)
+    best, best_t = default, None
+    for v, sp in cands:
+        lib.uc2_gemm_set_variant(v)
+        t = _time_gemm(lambda: gemm(a, b, M, N, K, ta=ta, tb=tb, out=out, accumulate=wgrad, split_k=sp))
+        if best_t is None or t < best_t:
+            best, best_t = (v, sp), t
+    lib.uc2_gemm_set_variant(-2)
+    _TUNE[key] = best
+    return best
+
+
+def _gemm_planned(a, b, M, N, K, ta, tb, wgrad=False, **kw):
+    v, sp = gemm_plan(a.dtype, ta, tb, M, N, K, wgrad)
+    lib = _lib.load()
+    if v != -2:
+        lib.uc2_gemm_set_variant(v)
+    try:
+        return gemm(a, b, M, N, K, ta=ta, tb=tb, split_k=sp, **kw)
+    finally:
+        if v != -2:
+            lib.uc2_gemm_set_variant(-2)
 
 
 def linear_fwd(x2, w, bias, epi=EPI_NONE, aux_out=None):
     M, K = x2.shape
     N = w.shape[0]
-    return gemm(x2, w, M, N, K, bias=bias, epi=epi, aux_out=aux_out)
+    return _gemm_planned(x2, w, M, N, K, False, False, bias=bias, epi=epi, aux_out=aux_out)
 
 
 def linear_dgrad(dy2, w, epi=EPI_NONE, aux_in=None):
     """dX[M,K] = dY[M,N] @ W[N,K]  (W in nn.Linear layout)"""
     M, N = dy2.shape
     K = w.shape[1]
-    return gemm(dy2, w, M, K, N, tb=True, epi=epi, aux_in=aux_in)
+    return _gemm_planned(dy2, w, M, K, N, False, True, epi=epi, aux_in=aux_in)
 
 
 def linear_wgrad(dy2, x2, dw, db):
     """dW[N,K] += dY^T X ; db[N] += colsum(dY)  (fp32 accumulation buffers)"""
     M, N = dy2.shape
     K = x2.shape[1]
-    gemm(dy2, x2, N, K, M, ta=True, tb=True, out=dw, accumulate=True, split_k=_wgrad_split(dy2.dtype, N, K, M))
+    _gemm_planned(dy2, x2, N, K, M, True, True, wgrad=True, out=dw, accumulate=True)
     if db is not None:
         colsum_accum(dy2, db)
 
