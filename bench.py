@@ -149,13 +149,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    # UC2_DIST_BACKEND=gloo lets several ranks share one GPU (functional check of the N>1 path on a 1-GPU box)
+    backend = os.environ.get("UC2_DIST_BACKEND", "nccl")
+    dev = torch.device("cuda", local % max(ndev, 1))
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == a.gpus, "--gpus %d but WORLD_SIZE %d" % (a.gpus, world)
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
 
     torch.manual_seed(0)                                   # weights seed 0 (random init, N(0, 0.02))
     model = VLXLMRForPretraining(make_cfg(a.layers), img_dim=IMG_DIM, img_label_dim=1601)
@@ -205,6 +210,14 @@ def main():
         dt = t.item()
     lossv = float(loss.mean().item())
     assert lossv == lossv, "loss is NaN"
+    in_sync = True
+    if world > 1:          # data-parallel invariant: every replica holds bit-identical weights after the steps
+        cs = st.data.double().sum().reshape(1)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool((lo == hi).item())
+        assert in_sync, "replicas diverged: parameter checksums differ across ranks"
 
     if rank == 0:
         pairs = a.batch * world * a.steps
@@ -220,7 +233,10 @@ def main():
                                    "L=96), %s training step: fwd + bwd + grad all-reduce + clip + AdamW, dropout 0.1"
                                    % (a.layers, a.task.upper()),
                        "pairs_per_gpu_per_step": a.batch, "global_batch": a.batch * world,
-                       "seq_len": T_TXT + N_REG, "parallelism": "dp%d" % world, "final_loss": round(lossv, 4)},
+                       "seq_len": T_TXT + N_REG, "parallelism": "dp%d" % world, "final_loss": round(lossv, 4), "replicas_in_sync": in_sync,
+                       "gemm_plans": {"%s%s %dx%dx%d" % ("T" if k[0] else "N", "T" if k[1] else "N", k[2], k[3], k[4]):
+                                      "%s split %d" % ("generic" if v[0] == 99 else "ring v%d" % v[0], v[1])
+                                      for k, v in sorted(ops._TUNE.items())}},
             "mfma_frac_encoder": round(value * ENC_GFLOP_PER_PAIR * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_fast_kernel<false,false,true,256,32,3> (forward X*W^T GEMMs)",
                          "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -121,8 +121,11 @@ size_t uc2_adamw_chunk_bytes(void);
 int uc2_adamw_step(const void* chunks, int n_chunks, int n_params, int n_groups, const float* lr, const float* beta1,
                    const float* beta2, const float* eps, const float* weight_decay, const int* correct_bias,
                    const int* active_dev, int* steps_dev, const float* grad_scale_dev, int zero_grad, void* stream);
-int uc2_sumsq_accum(size_t n, const float* x, float* out, void* stream);
-int uc2_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream);
+/* deterministic (atomic-free) global norm: one slot of uc2_sumsq_blocks() partials per gradient span, then a
+ * fixed-order final sum -- data-parallel replicas must compute bit-identical clip coefficients */
+int uc2_sumsq_blocks(void);
+int uc2_sumsq_partials(size_t n, const float* x, float* partials, void* stream);
+int uc2_clip_coef(const float* partials, int count, float max_norm, float* coef, float* norm_out, void* stream);
 int uc2_scale(size_t n, float* x, const float* scale_dev, float scale_imm, void* stream);
 
 #ifdef __cplusplus

@@ -50,8 +50,9 @@ SIGNATURES = {
     "uc2_cast": (I, [I, I, SZ, P, P, P]),
     "uc2_adamw_chunk_bytes": (SZ, []),
     "uc2_adamw_step": (I, [P, I, I, I, P, P, P, P, P, P, P, P, P, I, P]),
-    "uc2_sumsq_accum": (I, [SZ, P, P, P]),
-    "uc2_clip_coef": (I, [P, F, P, P, P]),
+    "uc2_sumsq_partials": (I, [SZ, P, P, P]),
+    "uc2_sumsq_blocks": (I, []),
+    "uc2_clip_coef": (I, [P, I, F, P, P, P]),
     "uc2_scale": (I, [SZ, P, P, F, P]),
 }
 

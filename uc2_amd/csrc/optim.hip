@@ -101,8 +101,11 @@ extern "C" int uc2_adamw_step(const void* chunks, int n_chunks, int n_params, in
   return 0;
 }
 
-// ---- sum of squares (global grad norm), accumulates into *out (caller zeroes it) ----
-__global__ __launch_bounds__(256) void sumsq_kernel(size_t n, const float* __restrict__ x, float* __restrict__ out) {
+// ---- sum of squares (global grad norm), deterministic: every workgroup writes ONE partial (fixed order inside
+// the workgroup), the clip kernel adds the partials in a fixed tree.  No atomics: data-parallel replicas that
+// hold identical gradients must compute bit-identical norms or they drift apart through the clip coefficient.
+#define UC2_SUMSQ_BLOCKS 1024
+__global__ __launch_bounds__(256) void sumsq_kernel(size_t n, const float* __restrict__ x, float* __restrict__ partials) {
   __shared__ float red[4];
   float s = 0.f;
   const size_t n4 = n >> 2;
@@ -114,29 +117,42 @@ __global__ __launch_bounds__(256) void sumsq_kernel(size_t n, const float* __res
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-extern "C" int uc2_sumsq_accum(size_t n, const float* x, float* out, void* stream) {
-  if (n == 0) return 0;
-  UC2_CHECK_ARG(x && out && (((uintptr_t)x & 15) == 0));
-  size_t g = (n / 4 + 255) / 256;
-  if (g < 1) g = 1;
-  if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(sumsq_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, n, x, out);
+// partials: UC2_SUMSQ_BLOCKS floats per call (the caller provides one such slot per gradient span)
+extern "C" int uc2_sumsq_partials(size_t n, const float* x, float* partials, void* stream) {
+  UC2_CHECK_ARG(partials);
+  UC2_CHECK_ARG(n == 0 || (x && (((uintptr_t)x & 15) == 0)));
+  hipLaunchKernelGGL(sumsq_kernel, dim3(UC2_SUMSQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, n, x, partials);
   UC2_LAUNCH_CHECK();
   return 0;
 }
+extern "C" int uc2_sumsq_blocks(void) { return UC2_SUMSQ_BLOCKS; }
 
-// coef = min(1, max_norm / (sqrt(sumsq) + 1e-6)); norm_out = sqrt(sumsq)
-__global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* coef, float* norm_out) {
-  const float nrm = sqrtf(*sumsq);
-  if (norm_out) *norm_out = nrm;
-  const float c = max_norm / (nrm + 1e-6f);
-  *coef = c < 1.f ? c : 1.f;
+// coef = min(1, max_norm / (sqrt(sum) + 1e-6)); norm_out = sqrt(sum); sum over `count` partials, fixed order
+__global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict__ partials, int count, float max_norm,
+                                                        float* coef, float* norm_out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < count; i += 256) s += (double)partials[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float nrm = sqrtf((float)red[0]);
+    if (norm_out) *norm_out = nrm;
+    const float c = max_norm / (nrm + 1e-6f);
+    *coef = c < 1.f ? c : 1.f;
+  }
 }
-extern "C" int uc2_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream) {
-  UC2_CHECK_ARG(sumsq && coef);
-  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, coef, norm_out);
+extern "C" int uc2_clip_coef(const float* partials, int count, float max_norm, float* coef, float* norm_out,
+                             void* stream) {
+  UC2_CHECK_ARG(partials && coef && count > 0);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, count, max_norm, coef,
+                     norm_out);
   UC2_LAUNCH_CHECK();
   return 0;
 }

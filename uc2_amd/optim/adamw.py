@@ -199,12 +199,13 @@ def clip_grad_norm_(parameters, max_norm, fused=False):
             spans[-1][1] = max(spans[-1][1], e)
         else:
             spans.append([b, e])
-    sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+    nb = _lib.load().uc2_sumsq_blocks()
+    partials = torch.empty(len(spans) * nb, dtype=torch.float32, device=dev)
     coef = torch.empty(1, dtype=torch.float32, device=dev)
     norm = torch.empty(1, dtype=torch.float32, device=dev)
-    for b, e in spans:
-        call("uc2_sumsq_accum", (e - b) // 4, b, ptr(sumsq), stream())
-    call("uc2_clip_coef", ptr(sumsq), float(max_norm), ptr(coef), ptr(norm), stream())
+    for i, (b, e) in enumerate(spans):
+        call("uc2_sumsq_partials", (e - b) // 4, b, partials[i * nb:].data_ptr(), stream())
+    call("uc2_clip_coef", ptr(partials), len(spans) * nb, float(max_norm), ptr(coef), ptr(norm), stream())
     if fused:
         return norm[0], coef
     for b, e in spans:
