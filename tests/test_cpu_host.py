@@ -48,7 +48,7 @@ def test_header_is_valid_c():
 def test_library_exports_every_declared_symbol():
     lib = _lib.load()                                   # raises if the .so or any bound symbol is missing
     syms = header_symbols()
-    assert len(syms) >= 40
+    assert len(syms) >= 36
     for s in syms:
         assert hasattr(lib, s), "libuc2_hip.so does not export %s" % s
         assert s in _lib.SIGNATURES, "uc2_amd/_lib.py does not bind %s" % s
