@@ -126,103 +126,103 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16_fast_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-#define GF_ISSUE(STAGE_IDX)                                                                                   \
+  // Issue wave-instruction q (1 KiB) of a tile into ring stage DST: q < A_PW -> A, else B.  ADV: advance the
+  // source to the next k-tile afterwards; when the ring is only being kept full (no tile left) the last valid
+  // tile is re-fetched instead (BACK = one k-tile), so every iteration issues the same number of loads.
+#define GF_ISSUE1(DST, Q, ADVA, ADVB, BACKA, BACKB)                                                            \
   do {                                                                                                        \
-    char* sa_ = smem + (STAGE_IDX) * STAGE + w * 1024;                                                        \
-    _Pragma("unroll") for (int i = 0; i < A_PW; ++i) {                                                        \
-      __builtin_amdgcn_global_load_lds((glb_void_p)pa[i], (lds_void_p)(sa_ + i * NW * 1024), 16, 0, 0);       \
-      pa[i] += stepa;                                                                                         \
-    }                                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < B_PW; ++i) {                                                        \
-      __builtin_amdgcn_global_load_lds((glb_void_p)pb[i], (lds_void_p)(sa_ + A_BYTES + i * NW * 1024), 16, 0, 0); \
-      pb[i] += stepb;                                                                                         \
+    if ((Q) < A_PW) {                                                                                         \
+      __builtin_amdgcn_global_load_lds((glb_void_p)(pa[(Q)] - (BACKA)), (lds_void_p)((DST) + (Q) * NW * 1024), \
+                                       16, 0, 0);                                                             \
+      pa[(Q)] += (ADVA);                                                                                      \
+    } else {                                                                                                  \
+      __builtin_amdgcn_global_load_lds((glb_void_p)(pb[(Q) - A_PW] - (BACKB)),                                \
+                                       (lds_void_p)((DST) + A_BYTES + ((Q) - A_PW) * NW * 1024), 16, 0, 0);   \
+      pb[(Q) - A_PW] += (ADVB);                                                                               \
     }                                                                                                         \
   } while (0)
 
 #pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s)
-    if (s < nt) GF_ISSUE(s);
+  for (int s = 0; s < NSTAGE - 1; ++s) {               // prologue: the ring always holds NSTAGE-1 tiles
+    const bool real = s < nt;
+    char* dst = smem + s * STAGE + w * 1024;
+#pragma unroll
+    for (int q = 0; q < LPT; ++q)
+      GF_ISSUE1(dst, q, real ? stepa : 0, real ? stepb : 0, real ? 0 : stepa, real ? 0 : stepb);
+  }
 
+  constexpr int KS = BK / 16;
   int cur = 0, nxt = NSTAGE - 1;                       // stage holding tile kt / stage to refill
   for (int kt = 0; kt < nt; ++kt) {
-    // wait for tile kt only: the tiles issued after it (up to NSTAGE-2) stay in flight across the barrier
-    const int ahead = min(NSTAGE - 2, nt - 1 - kt);
-    if (NSTAGE >= 4 && ahead == 2) wait_vmcnt<2 * LPT>();
-    else if (NSTAGE >= 3 && ahead >= 1) wait_vmcnt<LPT>();
-    else wait_vmcnt<0>();
+    // Wait for tile kt only: the NSTAGE-2 tiles issued after it stay in flight across the barrier (the count is
+    // a compile-time constant because the ring is kept full to the end; the loop body has no branches).
+    wait_vmcnt<(NSTAGE - 2) * LPT>();
     __builtin_amdgcn_s_barrier();                      // every wave's part of tile kt landed; stage nxt is free
-    if (kt + NSTAGE - 1 < nt) GF_ISSUE(nxt);
+    const bool refill = (kt + NSTAGE - 1 < nt);
+    const size_t adva = refill ? stepa : 0, advb = refill ? stepb : 0;
+    const size_t backa = refill ? 0 : stepa, backb = refill ? 0 : stepb;
     const char* As = smem + cur * STAGE;
     const char* Bs = As + A_BYTES;
-    if (p.atomic & 0x100) {          // diagnostic: fetch-only (no fragment reads, no MFMAs): the staging rate alone
-      cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-      nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
-      continue;
-    }
-    // all fragment reads of the k-tile are issued up front; the MFMAs then wait with counted lgkmcnt, so
-    // the LDS latency of step s+1.. hides under the MFMAs of step s even at 1-2 waves per SIMD
-    bf16x8 a[BK / 16][2], b[BK / 16][2];
-    if (p.atomic & 0x400) {          // diagnostic: no LDS reads (constant fragments), MFMAs only
-#pragma unroll
-      for (int s = 0; s < BK / 16; ++s)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { a[s][i] = bf16x8{1, 1, 1, 1, 1, 1, 1, 1}; b[s][i] = bf16x8{1, 1, 1, 1, 1, 1, 1, 1}; }
-    } else {
-#pragma unroll
-      for (int s = 0; s < BK / 16; ++s) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a[s][i] = gf_frag<TA, BM, BK>(As, wm * 64 + i * 32, s, lane);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) b[s][j] = gf_frag<TB, GF_BN, BK>(Bs, wn * 64 + j * 32, s, lane);
-      }
-    }
-    if (p.atomic & 0x200) {          // diagnostic: LDS reads but no MFMAs (fragments folded by cheap VALU)
-#pragma unroll
-      for (int s = 0; s < BK / 16; ++s)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i][0][s] += (float)a[s][i][0] + (float)b[s][i][7];
-      cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-      nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
-      continue;
-    }
-#pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (TACC) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[s][j], a[s][i], acc[i][j], 0, 0, 0);
-          else      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
-        }
-    }
-    // pin the interleave (LLVM sched_group_barrier masks: MFMA 0x8, DS_READ 0x100): the first two k16-steps'
-    // fragments, then one ds_read behind every MFMA while fragments remain, then the rest of the MFMAs
-    {
-      constexpr int NF = (BK / 16) * 4, NM = (BK / 16) * 4;
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-      for (int q = 0; q < NF - 8; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x8, NM - (NF - 8), 0);
-    }
+    char* dst = smem + nxt * STAGE + w * 1024;
     cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
     nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
+    if (p.atomic & 0x100) {          // diagnostic: fetch-only (no fragment reads, no MFMAs): the staging rate alone
+#pragma unroll
+      for (int q = 0; q < LPT; ++q) GF_ISSUE1(dst, q, adva, advb, backa, backb);
+      continue;
+    }
+    // Software pipeline inside the k-tile: behind each MFMA of k16-step s the wave issues a fragment read of step
+    // s+1, and its share of the next tile's LDS-DMA is spread over the steps.  Spreading the DMA issue matters: the
+    // CU's address unit accepts one 1-KiB wave-instruction per ~30 cycles, and a wave that issues all its DMA up
+    // front sits in the issue queue instead of feeding the MFMA pipe (measured: fetch alone 50 us + MFMA alone
+    // 35 us ran as 97 us when issued back to back).
+    bf16x8 a[2][2], b[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      a[0][i] = gf_frag<TA, BM, BK>(As, wm * 64 + i * 32, 0, lane);
+      b[0][i] = gf_frag<TB, GF_BN, BK>(Bs, wn * 64 + i * 32, 0, lane);
+    }
+    // one k16-step with literal index S (the sched_group_barrier arguments must be integer constants)
+    constexpr int RD = (TA ? 4 : 2) + (TB ? 4 : 2);            // ds_read instructions per step (tr fragment = 2 reads)
+    constexpr int R0 = RD / 4 + (RD % 4 > 0), R1 = RD / 4 + (RD % 4 > 1), R2 = RD / 4 + (RD % 4 > 2), R3 = RD / 4;
+#define GF_STEP(S)                                                                                             \
+    if constexpr ((S) < KS) {                                                                                  \
+      constexpr int c = (S) & 1, n = c ^ 1;                                                                    \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                        \
+          if (TACC) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[c][j], a[c][i], acc[i][j], 0, 0, 0); \
+          else      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c][i], b[c][j], acc[i][j], 0, 0, 0); \
+        }                                                                                                      \
+      if constexpr ((S) + 1 < KS) {                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
+          a[n][i] = gf_frag<TA, BM, BK>(As, wm * 64 + i * 32, (S) + 1, lane);                                  \
+          b[n][i] = gf_frag<TB, GF_BN, BK>(Bs, wn * 64 + i * 32, (S) + 1, lane);                               \
+        }                                                                                                      \
+      }                                                                                                        \
+      _Pragma("unroll") for (int q = 0; q < LPT; ++q)                                                          \
+        if (q % KS == (S)) GF_ISSUE1(dst, q, adva, advb, backa, backb);                                        \
+      /* pin: (MFMA, reads) x 4, then this step's DMA issues; LLVM masks: MFMA 0x8, DS_READ 0x100, VMEM 0x10 */ \
+      if constexpr ((S) + 1 < KS) {                                                                            \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, R0, 0);   \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, R1, 0);   \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, R2, 0);   \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                       \
+        if constexpr (R3 > 0) __builtin_amdgcn_sched_group_barrier(0x100, R3, 0);                              \
+      } else {                                                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);                                                       \
+      }                                                                                                        \
+      if constexpr ((LPT + KS - 1 - (S)) / KS > 0)                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x10, (LPT + KS - 1 - (S)) / KS, 0);                              \
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);        // step-0 fragments first
+    GF_STEP(0)
+    GF_STEP(1)
+    GF_STEP(2)
+    GF_STEP(3)
+#undef GF_STEP
   }
-#undef GF_ISSUE
-  if ((p.atomic & 0x100) && !(p.atomic & 0x1000)) return;
-  if (p.atomic & 0x800) {            // diagnostic: full main loop, no epilogue (one dummy store keeps acc alive)
-    float z = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z += acc[i][j][r];
-    if (z == 123.456f) reinterpret_cast<bf16*>(p.C)[0] = (bf16)z;
-    return;
-  }
+#undef GF_ISSUE1
+  if ((p.atomic & 0x100) && !(p.atomic & 0x1000)) return;      // diagnostic: staging only
   __syncthreads();                     // all waves are done reading the last stage: LDS is reused below
   bf16_tile_epilogue<TACC>(p, acc, m0, n0, wm, wn, lane, smem + w * EPI_LDS_PER_WAVE);
 }
