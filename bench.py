@@ -189,7 +189,7 @@ def main():
 
     for i in range(a.warmup):
         step(i)
-    timer = ops.GemmTimer(torch.bfloat16, False, False)
+    timer = ops.GemmTimer()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -222,8 +222,18 @@ def main():
     if rank == 0:
         pairs = a.batch * world * a.steps
         value = pairs / dt
-        n_l, fl, sec = timer.summary()
+        groups = timer.summary()
+        kname, n_l, fl, sec = groups[0] if groups else ("none", 0, 0.0, 0.0)
         ach = fl / sec / 1e12 if sec > 0 else 0.0
+        all_f = sum(g[2] for g in groups)
+        all_t = sum(g[3] for g in groups)
+        traffic = None
+        try:        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+            if pm.get("kernel", "").replace(" ", "") == kname.replace(" ", ""):
+                traffic = pm.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
         out = {
             "metric": "image-text pairs/sec fwd+bwd, 12L/768H seq_len=96",
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -238,10 +248,16 @@ def main():
                                       "%s split %d" % ("generic" if v[0] == 99 else "ring v%d" % v[0], v[1])
                                       for k, v in sorted(ops._TUNE.items())}},
             "mfma_frac_encoder": round(value * ENC_GFLOP_PER_PAIR * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_fast_kernel<false,false,true,256,32,3> (forward X*W^T GEMMs)",
+            "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                         "launches": n_l, "avg_us": round(sec / max(n_l, 1) * 1e6, 2)},
+                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "launches": n_l, "avg_us": round(sec / max(n_l, 1) * 1e6, 2),
+                         "all_gemm_kernels": {"achieved": round(all_f / all_t / 1e12, 1) if all_t > 0 else 0.0,
+                                              "share_of_step_time": round(all_t / dt, 3),
+                                              "by_kernel": [{"kernel": g[0], "launches": g[1],
+                                                             "tflops": round(g[2] / g[3] / 1e12, 1),
+                                                             "ms_per_step": round(g[3] / a.steps * 1e3, 2)}
+                                                            for g in groups[:6]]}},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.task, a.cpu_batch, a.layers)

@@ -228,6 +228,147 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16_fast_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Wave-specialised variant: 8 MFMA waves (4x2, 64x64 each, tile 256x128) + 4 loader waves per workgroup.
+// The loader waves own ALL the LDS-DMA of the workgroup (one per SIMD, 12 (BK=64) wave-instructions per k-tile
+// each), so the MFMA waves never queue behind the CU's address unit: their instruction stream is only
+// ds_read + MFMA.  Same ring, same single barrier per k-tile (all 12 waves take it): a loader waits for its
+// share of tile kt (counted vmcnt), takes the barrier, then refills the stage the MFMA waves have just left.
+// ------------------------------------------------------------------------------------------------------
+template <bool TA, bool TB, bool TACC, int BK, int NSTAGE, int NWL>
+__global__ __launch_bounds__(512 + NWL * 64) void gemm_bf16_ws_kernel(GemmArgs p) {
+  constexpr int BM = 256, NWC = 8;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = GF_BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_PL = A_BYTES / 1024 / NWL, B_PL = B_BYTES / 1024 / NWL, LPT = A_PL + B_PL;   // per loader wave
+  constexpr int KS = BK / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const bf16* __restrict__ A = reinterpret_cast<const bf16*>(p.A);
+  const bf16* __restrict__ B = reinterpret_cast<const bf16*>(p.B);
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+
+  const int nbx = (p.N + GF_BN - 1) / GF_BN, nby = (p.M + BM - 1) / BM;
+  const int nwg = nbx * nby;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int m0 = (bid / nbx) * BM, n0 = (bid % nbx) * GF_BN;
+  const int ktiles = p.K / BK;
+  const int per = (ktiles + p.split_k - 1) / p.split_k;
+  const int tbeg = blockIdx.z * per, tend = min(ktiles, tbeg + per);
+  if (tbeg >= tend) return;
+  const int nt = tend - tbeg, kbeg = tbeg * BK;
+
+  if (w >= NWC) {
+    // ------------------------------- loader wave -------------------------------
+    const int lw = w - NWC;
+    const bf16* pa[A_PL];
+    const bf16* pb[B_PL];
+#pragma unroll
+    for (int i = 0; i < A_PL; ++i) pa[i] = gf_src<TA, BM, BK>(A, p.lda, p.M, m0, kbeg, i * NWL + lw, lane);
+#pragma unroll
+    for (int i = 0; i < B_PL; ++i) pb[i] = gf_src<TB, GF_BN, BK>(B, p.ldb, p.N, n0, kbeg, i * NWL + lw, lane);
+    const size_t stepa = TA ? (size_t)BK * p.lda : (size_t)BK;
+    const size_t stepb = TB ? (size_t)BK * p.ldb : (size_t)BK;
+#define WS_ISSUE(DST, ADVA, ADVB, BACKA, BACKB)                                                                 \
+    do {                                                                                                       \
+      _Pragma("unroll") for (int q = 0; q < A_PL; ++q) {                                                       \
+        __builtin_amdgcn_global_load_lds((glb_void_p)(pa[q] - (BACKA)), (lds_void_p)((DST) + q * NWL * 1024), 16, 0, 0); \
+        pa[q] += (ADVA);                                                                                       \
+      }                                                                                                        \
+      _Pragma("unroll") for (int q = 0; q < B_PL; ++q) {                                                       \
+        __builtin_amdgcn_global_load_lds((glb_void_p)(pb[q] - (BACKB)), (lds_void_p)((DST) + A_BYTES + q * NWL * 1024), 16, 0, 0); \
+        pb[q] += (ADVB);                                                                                       \
+      }                                                                                                        \
+    } while (0)
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s) {
+      const bool real = s < nt;
+      char* dst = smem + s * STAGE + lw * 1024;
+      WS_ISSUE(dst, real ? stepa : 0, real ? stepb : 0, real ? 0 : stepa, real ? 0 : stepb);
+    }
+    int nxt = NSTAGE - 1;
+    for (int kt = 0; kt < nt; ++kt) {
+      wait_vmcnt<(NSTAGE - 2) * LPT>();                // this wave's share of tile kt has landed
+      __builtin_amdgcn_s_barrier();                    // ... publish it; the MFMA waves have left stage nxt
+      const bool refill = (kt + NSTAGE - 1 < nt);
+      char* dst = smem + nxt * STAGE + lw * 1024;
+      WS_ISSUE(dst, refill ? stepa : 0, refill ? stepb : 0, refill ? 0 : stepa, refill ? 0 : stepb);
+      nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
+    }
+#undef WS_ISSUE
+    __syncthreads();                                   // (drains the ring) matches the MFMA waves' pre-epilogue barrier
+    return;
+  }
+
+  // --------------------------------- MFMA wave ---------------------------------
+  const int wm = w >> 1, wn = w & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int cur = 0;
+  for (int kt = 0; kt < nt; ++kt) {
+    __builtin_amdgcn_s_barrier();                      // tile kt is in LDS (every loader waited for its share first)
+    const char* As = smem + cur * STAGE;
+    const char* Bs = As + A_BYTES;
+    cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+    bf16x8 a[2][2], b[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      a[0][i] = gf_frag<TA, BM, BK>(As, wm * 64 + i * 32, 0, lane);
+      b[0][i] = gf_frag<TB, GF_BN, BK>(Bs, wn * 64 + i * 32, 0, lane);
+    }
+    constexpr int RD = (TA ? 4 : 2) + (TB ? 4 : 2);
+    constexpr int R0 = RD / 4 + (RD % 4 > 0), R1 = RD / 4 + (RD % 4 > 1), R2 = RD / 4 + (RD % 4 > 2), R3 = RD / 4;
+#define WS_STEP(S)                                                                                             \
+    if constexpr ((S) < KS) {                                                                                  \
+      constexpr int c = (S) & 1, n = c ^ 1;                                                                    \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                        \
+          if (TACC) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[c][j], a[c][i], acc[i][j], 0, 0, 0); \
+          else      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[c][i], b[c][j], acc[i][j], 0, 0, 0); \
+        }                                                                                                      \
+      if constexpr ((S) + 1 < KS) {                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
+          a[n][i] = gf_frag<TA, BM, BK>(As, wm * 64 + i * 32, (S) + 1, lane);                                  \
+          b[n][i] = gf_frag<TB, GF_BN, BK>(Bs, wn * 64 + i * 32, (S) + 1, lane);                               \
+        }                                                                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, R0, 0);   \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, R1, 0);   \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, R2, 0);   \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                       \
+        if constexpr (R3 > 0) __builtin_amdgcn_sched_group_barrier(0x100, R3, 0);                              \
+      } else {                                                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);                                                       \
+      }                                                                                                        \
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+    WS_STEP(0)
+    WS_STEP(1)
+    WS_STEP(2)
+    WS_STEP(3)
+#undef WS_STEP
+  }
+  if ((p.atomic & 0x100) && !(p.atomic & 0x1000)) { __syncthreads(); return; }
+  __syncthreads();
+  bf16_tile_epilogue<TACC>(p, acc, m0, n0, wm, wn, lane, smem + w * EPI_LDS_PER_WAVE);
+}
+
+template <bool TA, bool TB, bool TACC, int BK, int NSTAGE, int NWL>
+static void ws_launch1(const GemmArgs& p, hipStream_t st) {
+  constexpr int smem = NSTAGE * (256 * BK * 2 + GF_BN * BK * 2);
+  auto kern = gemm_bf16_ws_kernel<TA, TB, TACC, BK, NSTAGE, NWL>;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+  const int nwg = ((p.N + GF_BN - 1) / GF_BN) * ((p.M + 255) / 256);
+  hipLaunchKernelGGL(kern, dim3(nwg, 1, p.split_k), dim3(512 + NWL * 64), smem, st, p);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // host side: variant selection
 // ------------------------------------------------------------------------------------------------------
 static int g_fetch_only = 0;
@@ -249,9 +390,8 @@ static void gf_launch2(const GemmArgs& p, int variant, hipStream_t st) {
   switch (variant) {
     case 0: gf_launch1<TA, TB, TACC, 128, 64, 2>(p, st); break;     // 64 KiB LDS, 2 workgroups / CU
     case 2: gf_launch1<TA, TB, TACC, 256, 32, 3>(p, st); break;     // 72 KiB LDS, 2 workgroups / CU
-    case 3: gf_launch1<TA, TB, TACC, 256, 32, 4>(p, st); break;     // 96 KiB LDS, 1 workgroup / CU
-    case 4: gf_launch1<TA, TB, TACC, 128, 64, 3>(p, st); break;     // 96 KiB LDS, 1 workgroup / CU
-    case 5: gf_launch1<TA, TB, TACC, 128, 32, 4>(p, st); break;     // 64 KiB LDS, 2 workgroups / CU
+    case 6: ws_launch1<TA, TB, TACC, 64, 3, 4>(p, st); break;        // wave-specialised: 8 MFMA + 4 loader waves
+    case 7: ws_launch1<TA, TB, TACC, 64, 3, 8>(p, st); break;        // wave-specialised: 8 MFMA + 8 loader waves
     default: gf_launch1<TA, TB, TACC, 256, 64, 3>(p, st); break;    // 144 KiB LDS, 1 workgroup / CU
   }
 }

@@ -17,25 +17,40 @@ GEMM_TIMER = None      # bench.py installs a GemmTimer to time one GEMM kernel v
 
 
 class GemmTimer:
-    """HIP-event timing of every launch of one GEMM kernel instantiation (dtype, trans_a, trans_b)"""
+    """HIP-event timing of every bf16 GEMM launch, grouped by kernel instantiation
+    (trans_a, trans_b, kernel variant, accumulate-into-fp32); bench.py reports the group with the largest
+    total time as the dominant kernel of the step"""
+    VARIANT_TEMPLATE = {0: "128,64,2", 1: "256,64,3", 2: "256,32,3"}
 
-    def __init__(self, dtype, ta, tb):
-        self.key = (dtype, bool(ta), bool(tb))
-        self.pairs = []
+    def __init__(self):
+        self.groups = {}
 
-    def wants(self, dtype, ta, tb):
-        return (dtype, bool(ta), bool(tb)) == self.key
+    def add(self, key, flops, e0, e1):
+        self.groups.setdefault(key, []).append((flops, e0, e1))
 
-    def add(self, flops, e0, e1):
-        self.pairs.append((flops, e0, e1))
+    @staticmethod
+    def kernel_name(key):
+        ta, tb, variant, atomic = key
+        b = lambda x: "true" if x else "false"
+        tacc = b(not atomic)
+        if variant == 99:
+            return "gemm_bf16_kernel<%s, %s, %s>" % (b(ta), b(tb), tacc)
+        if variant in (6, 7):
+            return "gemm_bf16_ws_kernel<%s, %s, %s, 64, 3, %d>" % (b(ta), b(tb), tacc, 4 if variant == 6 else 8)
+        return "gemm_bf16_fast_kernel<%s, %s, %s, %s>" % (b(ta), b(tb), tacc, GemmTimer.VARIANT_TEMPLATE.get(variant, "?"))
 
     def summary(self):
-        """(launches, total flops, total seconds) -- call after a device synchronize"""
-        tot_f, tot_t = 0.0, 0.0
-        for f, e0, e1 in self.pairs:
-            tot_f += f
-            tot_t += e0.elapsed_time(e1) * 1e-3
-        return len(self.pairs), tot_f, tot_t
+        """[(kernel name, launches, total flops, total seconds)] sorted by total time, descending;
+        call after a device synchronize"""
+        out = []
+        for key, pairs in self.groups.items():
+            tot_f = sum(f for f, _, _ in pairs)
+            tot_t = sum(e0.elapsed_time(e1) for _, e0, e1 in pairs) * 1e-3
+            out.append((self.kernel_name(key), len(pairs), tot_f, tot_t))
+        return sorted(out, key=lambda r: -r[3])
+
+
+_CUR_VARIANT = -2
 
 
 def _require_cuda(t):
@@ -92,7 +107,7 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
         if x is not None:
             ldaux = x.stride(0)
     timer = GEMM_TIMER
-    if timer is not None and timer.wants(dtype, ta, tb):
+    if timer is not None and dtype == torch.bfloat16 and _CUR_VARIANT != -2:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()                # on torch's current stream == the stream the kernel is launched on
     else:
@@ -101,7 +116,7 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
          ptr(bias), epi, ptr(aux_in), ptr(aux_out), ldaux, int(accumulate), split_k, stream())
     if e0 is not None:
         e1.record()
-        timer.add(2.0 * M * N * K, e0, e1)
+        timer.add((bool(ta), bool(tb), _CUR_VARIANT, bool(c_f32 and split_k > 1)), 2.0 * M * N * K, e0, e1)
     return out
 
 
@@ -118,11 +133,12 @@ def _wgrad_split(dtype, n_out, n_in, rows):
 # ---- per-shape kernel selection: measured once per (layout, shape) on the device, then cached ----------
 AUTOTUNE = True
 _TUNE = {}
-_FWD_CANDIDATES = ((99, 1), (0, 1), (1, 1), (2, 1))             # (kernel variant, split_k); 99 = generic kernel
+_FWD_CANDIDATES = ((99, 1), (0, 1), (1, 1), (2, 1), (6, 1), (7, 1))             # (kernel variant, split_k); 99 = generic kernel
 _WGRAD_SPLITS = (2, 3, 4, 6, 8, 12, 16)
 
 
-def _time_gemm(fn, reps=3):
+def _time_gemm(fn, reps=5):
+    fn()
     fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -151,7 +167,7 @@ def gemm_plan(dtype, ta, tb, M, N, K, wgrad=False):
     b = torch.randn((K, N) if tb else (N, K), device=dev).to(torch.bfloat16)
     out = torch.zeros((M, N), dtype=torch.float32 if wgrad else torch.bfloat16, device=dev)
     lib = _lib.load()
-    cands = [(v, s) for v in (99, 1, 0) for s in _WGRAD_SPLITS if s * 1024 <= K] if wgrad else list(_FWD_CANDIDATES)
+    cands = [(v, s) for v in (99, 1, 0, 6) for s in _WGRAD_SPLITS if s * 1024 <= K] if wgrad else list(_FWD_CANDIDATES)
     best, best_t = default, None
     for v, sp in cands:
         lib.uc2_gemm_set_variant(v)
@@ -164,15 +180,18 @@ def gemm_plan(dtype, ta, tb, M, N, K, wgrad=False):
 
 
 def _gemm_planned(a, b, M, N, K, ta, tb, wgrad=False, **kw):
+    global _CUR_VARIANT
     v, sp = gemm_plan(a.dtype, ta, tb, M, N, K, wgrad)
     lib = _lib.load()
     if v != -2:
         lib.uc2_gemm_set_variant(v)
+        _CUR_VARIANT = v
     try:
         return gemm(a, b, M, N, K, ta=ta, tb=tb, split_k=sp, **kw)
     finally:
         if v != -2:
             lib.uc2_gemm_set_variant(-2)
+            _CUR_VARIANT = -2
 
 
 def linear_fwd(x2, w, bias, epi=EPI_NONE, aux_out=None):
