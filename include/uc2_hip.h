@@ -74,6 +74,9 @@ int uc2_attn_bwd(int dtype, int impl, int B, int L, int nh, int D, const void* q
                  float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx, const void* dctx,
                  const float* lse, void* dqkv, void* stream);
 int uc2_attn_mfma_supported(int L, int D);
+/* head-averaged attention probabilities out[B, L, L] (MultiheadAttention need_weights, model/attention.py:255-260) */
+int uc2_attn_probs_mean(int dtype, int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
+                        float* out, void* stream);
 
 /* ---- embeddings and sequence assembly (model/model.py:280-335, 352-364, 412-425) ---------------------------- */
 int uc2_position_ids(int B, int T, const int64_t* ids, int64_t pad, int64_t* out, void* stream);

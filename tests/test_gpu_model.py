@@ -289,3 +289,23 @@ def test_base_geometry_bf16_properties():
         assert torch.equal(h1[:, :-6], h2[:, :-6])
     del model
     torch.cuda.empty_cache()
+
+
+def test_multihead_attention_vs_golden():
+    """reference model/attention.py MultiheadAttention (NLVR2 API surface): output and averaged weights"""
+    from uc2_amd.model.attention import MultiheadAttention
+    g = golden("mha")
+    E, nh, L, N = 128, 4, 10, 3
+    m = MultiheadAttention(E, nh, dropout=0.0)
+    synth.det_init_(m)
+    m.to(DEV).train()
+    q = synth.det_normal((L, N, E), 77).to(DEV)
+    kpm = torch.zeros(N, L, dtype=torch.bool, device=DEV)
+    kpm[1, 7:] = True
+    kpm[2, 4:] = True
+    qg = q.clone().requires_grad_(True)
+    o, w = m(qg, qg, qg, key_padding_mask=kpm)
+    check_against_golden(g, "mha/out", o, TOL32)
+    check_against_golden(g, "mha/weights", w, TOL32)
+    o.sum().backward()
+    assert qg.grad is not None and torch.isfinite(qg.grad).all() and m.in_proj_weight.grad is not None

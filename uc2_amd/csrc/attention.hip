@@ -341,3 +341,69 @@ extern "C" int uc2_attn_bwd(int dtype, int impl, int B, int L, int nh, int D, co
   return uc2_attn_bwd_simple(dtype, B, L, nh, D, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv,
                              stream);
 }
+
+// ---- head-averaged attention probabilities (MultiheadAttention need_weights=True, reference
+//      model/attention.py:255-260): out[b, q, k] = mean_h softmax_k(scale * Q_h K_h^T + mask)[q, k].
+//      fp32 math, forward only (the reference's callers discard the gradient of the weights). -------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_probs_mean_kernel(int L, int nh, int D, const T* __restrict__ qkv,
+                                                              const float* __restrict__ mask, float scale,
+                                                              float* __restrict__ out) {
+  __shared__ float red[4];
+  __shared__ float qs[256];
+  const int bq = blockIdx.x, b = bq / L, q = bq - b * L;
+  const int H = nh * D, ld = 3 * H, t = threadIdx.x;
+  const T* base = qkv + (size_t)b * L * ld;
+  for (int k0 = 0; k0 < L; k0 += 256) {
+    const int k = k0 + t;
+    if (k < L) out[(size_t)bq * L + k] = 0.f;
+  }
+  for (int h = 0; h < nh; ++h) {
+    __syncthreads();
+    if (t < D) qs[t] = to_f<T>(base[(size_t)q * ld + h * D + t]);
+    __syncthreads();
+    // pass 1: max, pass 2: sum, pass 3: write (L <= 512 -> at most 2 keys per thread, recomputed)
+    float sc[2], m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int k = t + 256 * r;
+      sc[r] = -INFINITY;
+      if (k < L) {
+        float s = 0.f;
+        const T* kr = base + (size_t)k * ld + H + h * D;
+        for (int d = 0; d < D; ++d) s += qs[d] * to_f<T>(kr[d]);
+        sc[r] = s * scale + (mask ? mask[(size_t)b * L + k] : 0.f);
+        m = fmaxf(m, sc[r]);
+      }
+    }
+    m = wave_max(m);
+    if ((t & 63) == 0) red[t >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float e[2], sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { e[r] = (t + 256 * r < L) ? __expf(sc[r] - m) : 0.f; sum += e[r]; }
+    sum = wave_sum(sum);
+    if ((t & 63) == 0) red[t >> 6] = sum;
+    __syncthreads();
+    sum = red[0] + red[1] + red[2] + red[3];
+    const float inv = 1.f / (sum * (float)nh);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int k = t + 256 * r;
+      if (k < L) out[(size_t)bq * L + k] += e[r] * inv;
+    }
+  }
+}
+extern "C" int uc2_attn_probs_mean(int dtype, int B, int L, int nh, int D, const void* qkv, const float* mask,
+                                   float scale, float* out, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  UC2_CHECK_ARG(L >= 1 && L <= 512 && D >= 1 && D <= 256 && nh >= 1);
+  if (B <= 0) return 0;
+  UC2_CHECK_ARG(qkv && out);
+  if (dtype == 0) hipLaunchKernelGGL(attn_probs_mean_kernel<float>, dim3(B * L), dim3(256), 0, (hipStream_t)stream, L, nh, D, (const float*)qkv, mask, scale, out);
+  else hipLaunchKernelGGL(attn_probs_mean_kernel<bf16>, dim3(B * L), dim3(256), 0, (hipStream_t)stream, L, nh, D, (const bf16*)qkv, mask, scale, out);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}

@@ -795,3 +795,29 @@ class DecoderCEFn(torch.autograd.Function):
         call("uc2_colsum_accum", dt(dtype), n, V, ptr(dlog), Vp, None, ptr(st.grad_buf(bias)), stream())
         dz = gemm(dlog, st.compute(weight, dtype), n, H, V, tb=True, lda=Vp)
         return dz, None, None, None, None, None
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(QK^T/sqrt(d) + mask) V over a packed [B*L, 3H] projection (one node; used by MultiheadAttention)"""
+
+    @staticmethod
+    def forward(ctx, qkv2, mask2d, B, L, nh, D, drop_p, seed_imm):
+        seed = rng.snapshot(qkv2.device) if drop_p > 0 else None
+        ctxv, lse = attn_fwd(qkv2, mask2d, B, L, nh, D, drop_p, seed, seed_imm)
+        ctx.save_for_backward(qkv2, mask2d, ctxv, lse, seed)
+        ctx.cfg = (B, L, nh, D, drop_p, seed_imm)
+        return ctxv
+
+    @staticmethod
+    def backward(ctx, dctx):
+        qkv2, mask2d, ctxv, lse, seed = ctx.saved_tensors
+        B, L, nh, D, drop_p, seed_imm = ctx.cfg
+        dqkv = attn_bwd(qkv2, mask2d, ctxv, dctx.contiguous(), lse, B, L, nh, D, drop_p, seed, seed_imm)
+        return dqkv, None, None, None, None, None, None, None
+
+
+def attn_probs_mean(qkv2, mask2d, B, L, nh, D):
+    out = torch.empty((B, L, L), dtype=torch.float32, device=qkv2.device)
+    call("uc2_attn_probs_mean", dt(qkv2.dtype), B, L, nh, D, ptr(qkv2), ptr(mask2d), 1.0 / math.sqrt(D), ptr(out),
+         stream())
+    return out
