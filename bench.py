@@ -219,6 +219,8 @@ def main():
         in_sync = bool((lo == hi).item())
         assert in_sync, "replicas diverged: parameter checksums differ across ranks"
 
+    if rank == 0 and os.environ.get("UC2_SAVE_PLANS"):
+        ops.save_plans(os.environ["UC2_SAVE_PLANS"])
     if rank == 0:
         pairs = a.batch * world * a.steps
         value = pairs / dt

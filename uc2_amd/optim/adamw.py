@@ -122,6 +122,8 @@ class AdamW(Optimizer):
         plan = self._plan or self._build_plan()
         if plan is None:
             return loss
+        from .. import ops
+        ops.join_side_streams()
         ah = plan["active_host"]
         any_active = False
         for (p, gi, pi, m, v, st) in plan["recs"]:
@@ -183,6 +185,8 @@ def clip_grad_norm_(parameters, max_norm, fused=False):
     params = [p for p in parameters if p.grad is not None]
     if not params:
         return torch.tensor(0.0)
+    from .. import ops
+    ops.join_side_streams()
     dev = params[0].grad.device
     arenas = []
     for p in params:

@@ -140,6 +140,9 @@ class ParamStore:
 
     def zero_grad(self):
         if self.grad is not None:
+            if self.grad.is_cuda:
+                from . import ops
+                ops.join_side_streams()
             self.grad.zero_()
         self.grad_epoch += 1
         for p in self.params:

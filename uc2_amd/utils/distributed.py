@@ -80,6 +80,9 @@ def all_reduce_and_rescale_tensors(tensors, rescale_denom):
     tensors = list(tensors)
     if not tensors:
         return
+    if tensors[0].is_cuda:
+        from .. import ops
+        ops.join_side_streams()
     W = _world()
     scale = 1.0 / (W * rescale_denom)
     # find arena-backed spans by address
