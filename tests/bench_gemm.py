@@ -46,7 +46,7 @@ def main():
                 if rep == 1:
                     res.append(2.0 * m * n * k / t / 1e12)
         diag = {}
-        for mode, label in ((1, "fetch only"), (17, "fetch + epilogue")):
+        for mode, label in ((1, "fetch only"), (17, "fetch + epilogue"), (32, "compute only (ws)")):
             lib.uc2_gemm_set_fetch_only(mode)
             diag[label] = []
             for v in VARIANTS:

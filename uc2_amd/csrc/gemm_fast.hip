@@ -81,8 +81,10 @@ template <> __device__ __forceinline__ void wait_vmcnt<16>() { asm volatile("s_w
 template <> __device__ __forceinline__ void wait_vmcnt<18>() { asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vmcnt<24>() { asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); }
 
+// (second launch-bound argument = waves per SIMD: rings of <= 80 KiB are meant to run two workgroups per CU)
 template <bool TA, bool TB, bool TACC, int BM, int BK, int NSTAGE>
-__global__ __launch_bounds__(BM * 2) void gemm_bf16_fast_kernel(GemmArgs p) {
+__global__ __launch_bounds__(BM * 2, (NSTAGE * (BM + GF_BN) * BK * 2 <= 80 * 1024) ? (2 * BM * 2 / 256) : (BM * 2 / 256))
+void gemm_bf16_fast_kernel(GemmArgs p) {
   constexpr int NW = BM / 32;                         // waves: 8 (BM 256) or 4 (BM 128); wave grid (BM/64) x 2
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = GF_BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int A_PW = A_BYTES / 1024 / NW;           // wave-instructions per wave per k-tile
@@ -288,9 +290,11 @@ __global__ __launch_bounds__(512 + NWL * 64) void gemm_bf16_ws_kernel(GemmArgs p
       WS_ISSUE(dst, real ? stepa : 0, real ? stepb : 0, real ? 0 : stepa, real ? 0 : stepb);
     }
     int nxt = NSTAGE - 1;
+    const bool no_fetch = (p.atomic & 0x2000) != 0;    // diagnostic: compute side only (stale LDS contents)
     for (int kt = 0; kt < nt; ++kt) {
       wait_vmcnt<(NSTAGE - 2) * LPT>();                // this wave's share of tile kt has landed
       __builtin_amdgcn_s_barrier();                    // ... publish it; the MFMA waves have left stage nxt
+      if (no_fetch) continue;
       const bool refill = (kt + NSTAGE - 1 < nt);
       char* dst = smem + nxt * STAGE + lw * 1024;
       WS_ISSUE(dst, refill ? stepa : 0, refill ? stepb : 0, refill ? 0 : stepa, refill ? 0 : stepb);

@@ -10,9 +10,6 @@ What changes relative to the reference (utils/distributed.py:15-42):
     exposed; RCCL picks the multi-link algorithm (7 xGMI links per GPU), nothing forces a ring;
   * the mean over ranks (Horovod's default) and `/ rescale_denom` are one scaling pass.
 """
-import math
-import pickle
-
 import torch
 import torch.distributed as dist
 
@@ -35,29 +32,6 @@ def _scale_(t, s):
         _lib.call("uc2_scale", t.numel(), _lib.ptr(t), None, float(s), _lib.stream())
     else:
         t.mul_(s)
-
-
-def _flat_spans(tensors):
-    """group tensors into maximal spans that are contiguous in memory inside one gradient arena;
-    returns (list of flat views, list of leftover tensors that are not arena-backed)"""
-    by_store, loose = {}, []
-    for t in tensors:
-        st = getattr(t, "_uc2_arena", None)
-        if st is None:
-            loose.append(t)
-        else:
-            by_store.setdefault(id(st), (st, []))[1].append(t)
-    return by_store, loose
-
-
-def arena_of(params):
-    """{store: [(elem_offset, numel)]} for parameters whose gradients live in a store arena"""
-    out = {}
-    for p in params:
-        st = getattr(p, "_uc2_store", None)
-        if st is not None and st.owns(p) and st.grad is not None:
-            out.setdefault(id(st), (st, []))[1].append((st.offsets[id(p)], p.numel()))
-    return out
 
 
 def _merge(ranges, gap=64):
