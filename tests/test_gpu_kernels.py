@@ -300,9 +300,9 @@ def test_attention_mfma_equals_simple_under_dropout(B, L, nh, D):
     assert rel_err(g2.float(), g1.float()) < 2e-2
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 6, 7, 8])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 768, 768), (776, 2304, 832), (128, 136, 64)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 512, 1024), (1000, 768, 768), (776, 2304, 832), (128, 136, 64)])
 def test_gemm_pipelined_equals_generic(ta, tb, M, N, K, variant):
     """the LDS-DMA pipelined kernels (every tile/stage variant) and the generic register-staged kernel
     compute the same bf16 result, bit for bit"""

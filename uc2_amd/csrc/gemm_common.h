@@ -147,3 +147,68 @@ __device__ __forceinline__ void bf16_tile_epilogue(const GemmArgs& p, const f32x
       }
   }
 }
+
+// Direct (no LDS) epilogue for one wave's 64x64 block held transposed (TACC layout: lane = output row m,
+// register 4c+e = column 8c + 4*(lane>>5) + e of a 32-wide block).  v_permlane32_swap exchanges the 4-column
+// groups between the two lane halves so that every lane ends up with 8 consecutive columns
+// (lane half h: columns 8h..8h+7 and 16+8h..16+8h+7 of each 32-wide block), i.e. one 16-byte bf16 store per
+// lane with 32 contiguous bytes per output row and instruction.  Requirements (checked by the caller):
+// bf16 output, no accumulate, N % 16 == 0, ldc/ldaux % 8 == 0, 16-byte aligned C / aux pointers.
+__device__ __forceinline__ void bf16_tile_epilogue_direct(const GemmArgs& p, const f32x16 (&acc)[2][2], int mb0,
+                                                          int nb, int lane) {
+  const int h = lane >> 5, c31 = lane & 31;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int n = nb + 32 * j + 16 * g + 8 * h;
+      float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (p.bias && n < p.N) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // X = group c = 2g, Y = group c = 2g+1: afterwards the low half holds (own X, partner's X), the high half (partner's Y... see above)
+          // (copy the vector elements to scalars first: __builtin_bit_cast on an ext-vector element reads element 0)
+          const float fx = acc[i][j][8 * g + e], fy = acc[i][j][8 * g + 4 + e];
+          const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(fx), __float_as_uint(fy), false, false);
+          v[e] = __uint_as_float(r[0]);
+          v[4 + e] = __uint_as_float(r[1]);
+        }
+        const int m = mb0 + i * 32 + c31;
+        if (m >= p.M || n >= p.N) continue;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bv[e];
+        const size_t ia = (size_t)m * p.ldaux + n;
+        if (p.epi == EPI_GELU) {
+          if (p.aux_out) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.aux_out) + ia) = o;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        } else if (p.epi == EPI_DGELU) {
+          const bf16x8 x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.aux_in) + ia);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= dgelu_f((float)x[e]);
+        } else if (p.epi == EPI_ADD) {
+          const bf16x8 x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.aux_in) + ia);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)x[e];
+        } else if (p.epi == EPI_TANH) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = o;
+      }
+    }
+}

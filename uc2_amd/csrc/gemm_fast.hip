@@ -18,72 +18,11 @@
 // 16-byte aligned operands with leading dimensions % 8 == 0, and extents % 8 == 0 for k-strided operands.
 // Row/column edges are handled by clamping the source row (the clamped lanes only feed outputs that the
 // epilogue guards away).
-#include "gemm_common.h"
-#include <stdlib.h>
-
-#define GF_BN 128
-
-typedef __attribute__((address_space(3))) void* lds_void_p;
-typedef const __attribute__((address_space(1))) void* glb_void_p;
-
-// per-lane source pointer for wave-instruction `wi` (1 KiB of the operand tile) at the first k-tile.
-//   !TR: tile [W rows][BK] , row = BK*2 bytes ;  TR: tile [BK k-rows][W], k-row = W*2 bytes
-template <bool TR, int W, int BK>
-__device__ __forceinline__ const bf16* gf_src(const bf16* __restrict__ X, int ld, int rows, int r0, int kbeg, int wi,
-                                              int l) {
-  if (!TR) {
-    constexpr int CPR = BK / 8;                 // 16-B chunks per row (8 or 4)
-    constexpr int RPI = 64 / CPR;               // rows per wave-instruction
-    const int row = wi * RPI + l / CPR, cp = l % CPR;
-    const int c = cp ^ ((row >> (CPR == 8 ? 1 : 2)) & (CPR - 1));
-    const int gr = min(r0 + row, rows - 1);
-    return X + (size_t)gr * ld + kbeg + c * 8;
-  } else {
-    constexpr int CPR = W / 8;                  // chunks per k-row (16 or 32)
-    constexpr int RPI = 64 / CPR;               // k-rows per wave-instruction (4 or 2)
-    const int krow = wi * RPI + l / CPR, cp = l % CPR;
-    const int c = cp ^ ((krow & 3) << 2);
-    const int col = min(r0 + c * 8, rows - 8);
-    return X + (size_t)(kbeg + krow) * ld + col;
-  }
-}
-
-// one MFMA operand fragment (32 rows x 16 k) for k16-step s of the tile; rbase = first row of the fragment
-template <bool TR, int W, int BK>
-__device__ __forceinline__ bf16x8 gf_frag(const char* lds, int rbase, int s, int lane) {
-  if (!TR) {
-    constexpr int CPR = BK / 8;
-    const int row = rbase + (lane & 31), h = lane >> 5;
-    return *reinterpret_cast<const bf16x8*>(lds + row * (BK * 2) +
-                                            ((((s << 1) + h) ^ ((row >> (CPR == 8 ? 1 : 2)) & (CPR - 1))) << 4));
-  } else {
-    const int G = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, h = G >> 1;
-    const int krow = 16 * s + 8 * h + q;                 // krow & 3 == q for both reads
-    const int col = rbase + 16 * (G & 1) + 4 * pp;
-    const int off = krow * (W * 2) + ((((col >> 3) ^ (q << 2))) << 4) + (col & 7) * 2;
-    typedef __attribute__((address_space(3))) short4v* lds_p;
-    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds + off));
-    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lds + off + 4 * (W * 2)));
-    bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
-    return bf16x8{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
-  }
-}
-
-template <int N> __device__ __forceinline__ void wait_vmcnt();
-template <> __device__ __forceinline__ void wait_vmcnt<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-template <> __device__ __forceinline__ void wait_vmcnt<3>() { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
-template <> __device__ __forceinline__ void wait_vmcnt<4>() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-template <> __device__ __forceinline__ void wait_vmcnt<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-template <> __device__ __forceinline__ void wait_vmcnt<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-template <> __device__ __forceinline__ void wait_vmcnt<9>() { asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }
-template <> __device__ __forceinline__ void wait_vmcnt<12>() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
-template <> __device__ __forceinline__ void wait_vmcnt<16>() { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
-template <> __device__ __forceinline__ void wait_vmcnt<18>() { asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); }
-template <> __device__ __forceinline__ void wait_vmcnt<24>() { asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); }
+#include "gemm_tile.h"
 
 // (second launch-bound argument = waves per SIMD: rings of <= 80 KiB are meant to run two workgroups per CU)
 template <bool TA, bool TB, bool TACC, int BM, int BK, int NSTAGE>
-__global__ __launch_bounds__(BM * 2, (NSTAGE * (BM + GF_BN) * BK * 2 <= 80 * 1024) ? (2 * BM * 2 / 256) : (BM * 2 / 256))
+__global__ __launch_bounds__(BM * 2)
 void gemm_bf16_fast_kernel(GemmArgs p) {
   constexpr int NW = BM / 32;                         // waves: 8 (BM 256) or 4 (BM 128); wave grid (BM/64) x 2
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = GF_BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -372,6 +311,8 @@ static void ws_launch1(const GemmArgs& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(nwg, 1, p.split_k), dim3(512 + NWL * 64), smem, st, p);
 }
 
+template <bool TA, bool TB, bool TACC> void pp_launch1(const GemmArgs& p, hipStream_t st);   // gemm_pp.hip
+
 // ------------------------------------------------------------------------------------------------------
 // host side: variant selection
 // ------------------------------------------------------------------------------------------------------
@@ -396,6 +337,7 @@ static void gf_launch2(const GemmArgs& p, int variant, hipStream_t st) {
     case 2: gf_launch1<TA, TB, TACC, 256, 32, 3>(p, st); break;     // 72 KiB LDS, 2 workgroups / CU
     case 6: ws_launch1<TA, TB, TACC, 64, 3, 4>(p, st); break;        // wave-specialised: 8 MFMA + 4 loader waves
     case 7: ws_launch1<TA, TB, TACC, 64, 3, 8>(p, st); break;        // wave-specialised: 8 MFMA + 8 loader waves
+    case 8: pp_launch1<TA, TB, TACC>(p, st); break;                  // 256x256x64 ping-pong
     default: gf_launch1<TA, TB, TACC, 256, 64, 3>(p, st); break;    // 144 KiB LDS, 1 workgroup / CU
   }
 }
@@ -409,6 +351,13 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
   if (g_variant == -1) { const char* e = getenv("UC2_GEMM_VARIANT"); g_variant = e ? atoi(e) : -2; }
   int variant = g_variant;
   if (variant == 99) return 0;                       // caller asked for the generic kernel
+  if (variant == 8) {                                // the ping-pong kernel needs >= 2 k-tiles per split and whole 16-B chunks
+    const int per = (p.K / 64 + p.split_k - 1) / p.split_k;
+    if (per < 2 || (p.K / 64) - (p.split_k - 1) * per < 2) return 0;
+    if (!p.c_f32 && (p.accumulate || (p.N & 15) || (p.ldc & 7) || (p.ldaux & 7) || ((uintptr_t)p.C & 15) ||
+                     ((uintptr_t)p.aux_in & 15) || ((uintptr_t)p.aux_out & 15) || ((uintptr_t)p.bias & 15)))
+      return 0;
+  }
   if (variant == -2) {
     // measured on MI355X (tests/bench_gemm.py, profiles/): forward X*W^T -> 256x128x32 ring of 3, 2 WG/CU;
     // input-gradient dY*W with a narrow output -> the generic register-staged kernel (3 WG/CU) wins;
@@ -417,7 +366,7 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
     else if (!trans_a && trans_b) { if (p.N >= 2048) variant = 2; else return 0; }
     else variant = 1;
   }
-  const bool tacc = !(p.c_f32 && p.atomic);
+  const bool tacc = (variant == 8) ? !p.c_f32 : !(p.c_f32 && p.atomic);
   GemmArgs pd = p;
   if (g_fetch_only) pd.atomic |= (g_fetch_only << 8);
 #define GF_GO(TA_, TB_) do { if (tacc) gf_launch2<TA_, TB_, true>(pd, variant, st); else gf_launch2<TA_, TB_, false>(pd, variant, st); } while (0)
