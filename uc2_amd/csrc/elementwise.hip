@@ -551,7 +551,7 @@ extern "C" int uc2_dtanh(int dtype, size_t n, const void* y, const void* dy, voi
 template <typename T>
 __global__ void dgelu_kernel(size_t n, const T* __restrict__ pre, const T* __restrict__ dy, T* __restrict__ dx) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    dx[i] = from_f<T>(to_f<T>(dy[i]) * dgelu_f(to_f<T>(pre[i])));
+    dx[i] = from_f<T>(to_f<T>(dy[i]) * dgelu_t<T>(to_f<T>(pre[i])));
 }
 extern "C" int uc2_dgelu(int dtype, size_t n, const void* pre, const void* dy, void* dx, void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);

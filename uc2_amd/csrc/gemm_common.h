@@ -23,13 +23,13 @@ __device__ __forceinline__ void epi_store(const GemmArgs& p, int m, int n, float
   const size_t ia = (size_t)m * p.ldaux + n;
   if (p.epi == EPI_GELU) {
     if (p.aux_out) reinterpret_cast<T*>(p.aux_out)[ia] = from_f<T>(v);
-    v = gelu_f(v);
+    v = gelu_t<T>(v);
   } else if (p.epi == EPI_DGELU) {
-    v *= dgelu_f(to_f<T>(reinterpret_cast<const T*>(p.aux_in)[ia]));
+    v *= dgelu_t<T>(to_f<T>(reinterpret_cast<const T*>(p.aux_in)[ia]));
   } else if (p.epi == EPI_ADD) {
     v += to_f<T>(reinterpret_cast<const T*>(p.aux_in)[ia]);
   } else if (p.epi == EPI_TANH) {
-    v = tanhf(v);
+    v = tanh_t<T>(v);
   }
   const size_t ic = (size_t)m * p.ldc + n;
   if (p.c_f32) {
@@ -107,18 +107,18 @@ __device__ __forceinline__ void bf16_tile_epilogue(const GemmArgs& p, const f32x
               *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.aux_out) + ia) = o;
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+            for (int e = 0; e < 8; ++e) v[e] = gelu_bf(v[e]);
           } else if (p.epi == EPI_DGELU) {
             const bf16x8 x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.aux_in) + ia);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= dgelu_f((float)x[e]);
+            for (int e = 0; e < 8; ++e) v[e] *= dgelu_bf((float)x[e]);
           } else if (p.epi == EPI_ADD) {
             const bf16x8 x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.aux_in) + ia);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += (float)x[e];
           } else if (p.epi == EPI_TANH) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+            for (int e = 0; e < 8; ++e) v[e] = tanh_bf(v[e]);
           }
           bf16x8 o;
 #pragma unroll
@@ -192,18 +192,18 @@ __device__ __forceinline__ void bf16_tile_epilogue_direct(const GemmArgs& p, con
             *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.aux_out) + ia) = o;
           }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+          for (int e = 0; e < 8; ++e) v[e] = gelu_bf(v[e]);
         } else if (p.epi == EPI_DGELU) {
           const bf16x8 x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.aux_in) + ia);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= dgelu_f((float)x[e]);
+          for (int e = 0; e < 8; ++e) v[e] *= dgelu_bf((float)x[e]);
         } else if (p.epi == EPI_ADD) {
           const bf16x8 x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.aux_in) + ia);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += (float)x[e];
         } else if (p.epi == EPI_TANH) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+          for (int e = 0; e < 8; ++e) v[e] = tanh_bf(v[e]);
         }
         bf16x8 o;
 #pragma unroll

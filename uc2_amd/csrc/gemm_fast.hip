@@ -311,7 +311,8 @@ static void ws_launch1(const GemmArgs& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(nwg, 1, p.split_k), dim3(512 + NWL * 64), smem, st, p);
 }
 
-template <bool TA, bool TB, bool TACC> void pp_launch1(const GemmArgs& p, hipStream_t st);   // gemm_pp.hip
+bool uc2_gemm_pp_supported(int trans_a, int trans_b, int c_f32, int epi);                       // gemm_pp.hip
+void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------------
 // host side: variant selection
@@ -337,7 +338,6 @@ static void gf_launch2(const GemmArgs& p, int variant, hipStream_t st) {
     case 2: gf_launch1<TA, TB, TACC, 256, 32, 3>(p, st); break;     // 72 KiB LDS, 2 workgroups / CU
     case 6: ws_launch1<TA, TB, TACC, 64, 3, 4>(p, st); break;        // wave-specialised: 8 MFMA + 4 loader waves
     case 7: ws_launch1<TA, TB, TACC, 64, 3, 8>(p, st); break;        // wave-specialised: 8 MFMA + 8 loader waves
-    case 8: pp_launch1<TA, TB, TACC>(p, st); break;                  // 256x256x64 ping-pong
     default: gf_launch1<TA, TB, TACC, 256, 64, 3>(p, st); break;    // 144 KiB LDS, 1 workgroup / CU
   }
 }
@@ -351,24 +351,21 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
   if (g_variant == -1) { const char* e = getenv("UC2_GEMM_VARIANT"); g_variant = e ? atoi(e) : -2; }
   int variant = g_variant;
   if (variant == 99) return 0;                       // caller asked for the generic kernel
-  if (variant == 8) {                                // the ping-pong kernel needs >= 2 k-tiles per split and whole 16-B chunks
+  if (variant == 8) {
+    // ping-pong kernel: whole 256x256 tiles, >= 2 k-tiles per split, and (bf16 output) an epilogue made of whole
+    // 16-byte accesses; anything else runs on the ring kernels above / the generic kernel
     const int per = (p.K / 64 + p.split_k - 1) / p.split_k;
     if (per < 2 || (p.K / 64) - (p.split_k - 1) * per < 2) return 0;
-    if (!p.c_f32 && (p.accumulate || (p.N & 15) || (p.ldc & 7) || (p.ldaux & 7) || ((uintptr_t)p.C & 15) ||
+    if ((p.M & 255) || (p.N & 255)) return 0;
+    if (!uc2_gemm_pp_supported(trans_a, trans_b, p.c_f32, p.epi)) return 0;
+    if (!p.c_f32 && (p.accumulate || (p.ldc & 7) || (p.ldaux & 7) || ((uintptr_t)p.C & 15) ||
                      ((uintptr_t)p.aux_in & 15) || ((uintptr_t)p.aux_out & 15) || ((uintptr_t)p.bias & 15)))
       return 0;
   }
-  if (variant == -2) {
-    // measured on MI355X (tests/bench_gemm.py, profiles/): forward X*W^T -> 256x128x32 ring of 3, 2 WG/CU;
-    // input-gradient dY*W with a narrow output -> the generic register-staged kernel (3 WG/CU) wins;
-    // weight-gradient (long contraction, split-K) -> 256x128x64 ring of 3.
-    if (!trans_a && !trans_b) variant = 2;
-    else if (!trans_a && trans_b) { if (p.N >= 2048) variant = 2; else return 0; }
-    else variant = 1;
-  }
-  const bool tacc = (variant == 8) ? !p.c_f32 : !(p.c_f32 && p.atomic);
+  const bool tacc = !(p.c_f32 && p.atomic);
   GemmArgs pd = p;
   if (g_fetch_only) pd.atomic |= (g_fetch_only << 8);
+  if (variant == 8) { uc2_gemm_pp_launch(pd, trans_a, trans_b, st); return 1; }
 #define GF_GO(TA_, TB_) do { if (tacc) gf_launch2<TA_, TB_, true>(pd, variant, st); else gf_launch2<TA_, TB_, false>(pd, variant, st); } while (0)
   if (!trans_a && !trans_b) GF_GO(false, false);
   else if (!trans_a && trans_b) GF_GO(false, true);

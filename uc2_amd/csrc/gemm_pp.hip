@@ -20,6 +20,12 @@
 // barrier intervals after the last read of the unit it overwrites; `s_waitcnt vmcnt(8)` at the end of every
 // L section retires exactly the units the next phase reads (all but the 4 youngest units), and the barrier
 // that follows publishes them to the other waves.
+//
+// The kernel is persistent: one workgroup per CU walks over (output tile, k-split) work items.  The epilogue
+// stores straight from the accumulator registers (gemm_common.h, bf16_tile_epilogue_direct), so the LDS ring is
+// free as soon as the main loop ends: the next item's first six units are issued BEFORE the epilogue's stores
+// and land while they drain (`vmcnt(8 + stores)` then retires only the two units the first phase reads).
+// At K = 768 the per-tile launch + first-fetch latency and the store tail were 40 % of a non-persistent tile.
 // ------------------------------------------------------------------------------------------------------
 #define PP_UNIT 16384
 
@@ -74,48 +80,160 @@ template <bool TR, int S> __device__ __forceinline__ void pp_read(bf16x8& dst, u
   }
 }
 
-template <bool TA, bool TB, bool TACC>
+// Direct epilogue in two parts, so that the next item's LDS-DMA can be issued in between:
+//   pp_epi_compute: aux_in loads (EPI_ADD / EPI_DGELU), lane-half exchange, bias, activation, conversion.  It leaves
+//                   the wave's 128x64 outputs as 16 packed bf16x8 registers per lane (+16 for the pre-activation
+//                   copy of EPI_GELU) -- every VMEM load of the epilogue is issued here, BEFORE the DMA, because
+//                   vmcnt retires in order: a load issued after the DMA would wait for the whole prologue.
+//                   (The bias is not added here: the accumulators START at the bias, see the kernel.)
+//   pp_epi_store  : the stores only; full tiles, so their number is a compile-time function of the epilogue kind.
+// Layout after the exchange (v_permlane32_swap, see gemm_common.h): lane (row m, half h) holds columns
+// 32j + 16g + 8h .. +7 of the wave's 64 for j, g in {0,1}.
+struct PpOut {
+  bf16x8 o[2][2][2][2];       // [A half][i][j][g]
+  bf16x8 pre[2][2][2][2];     // pre-activation values (EPI_GELU with aux_out)
+};
+
+template <int EPI>
+__device__ __forceinline__ void pp_epi_compute(const GemmArgs& p, const f32x16 (&acc)[2][2][2], PpOut& out, int mb0, int nb,
+                                               int lane) {
+  const int h = lane >> 5, c31 = lane & 31;
+  constexpr bool has_aux = (EPI == EPI_DGELU || EPI == EPI_ADD);
+  bf16x8 ax[2][2][2][2];
+  if (has_aux) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const int m = mb0 + hh * 64 + i * 32 + c31, n = nb + 32 * j + 16 * g + 8 * h;
+            ax[hh][i][j][g] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.aux_in) + (size_t)m * p.ldaux + n);
+          }
+  }
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float fx = acc[hh][i][j][8 * g + e], fy = acc[hh][i][j][8 * g + 4 + e];
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(fx), __float_as_uint(fy), false, false);
+            v[e] = __uint_as_float(sw[0]);
+            v[4 + e] = __uint_as_float(sw[1]);
+          }
+          if (EPI == EPI_GELU) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+            out.pre[hh][i][j][g] = o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_bf(v[e]);
+          } else if (EPI == EPI_DGELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= dgelu_bf((float)ax[hh][i][j][g][e]);
+          } else if (EPI == EPI_ADD) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)ax[hh][i][j][g][e];
+          } else if (EPI == EPI_TANH) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tanh_bf(v[e]);
+          }
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+          out.o[hh][i][j][g] = o;
+        }
+}
+
+template <int EPI>
+__device__ __forceinline__ void pp_epi_store(const GemmArgs& p, const PpOut& out, int mb0, int nb, int lane) {
+  const int h = lane >> 5, c31 = lane & 31;
+  const bool pre = (EPI == EPI_GELU) && p.aux_out;
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mb0 + hh * 64 + i * 32 + c31;
+      bf16* crow = reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + nb + 8 * h;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          *reinterpret_cast<bf16x8*>(crow + 32 * j + 16 * g) = out.o[hh][i][j][g];
+        }
+      if (pre) {
+        bf16* prow = reinterpret_cast<bf16*>(p.aux_out) + (size_t)m * p.ldaux + nb + 8 * h;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            *reinterpret_cast<bf16x8*>(prow + 32 * j + 16 * g) = out.pre[hh][i][j][g];
+          }
+      }
+    }
+}
+
+template <> __device__ __forceinline__ void wait_vmcnt<40>() { asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); }
+
+template <bool TA, bool TB, bool TACC, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const bf16* __restrict__ A = reinterpret_cast<const bf16*>(p.A);
   const bf16* __restrict__ B = reinterpret_cast<const bf16*>(p.B);
   const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wr = w >> 2, wc = w & 3;
 
-  const int nbx = (p.N + 255) / 256, nby = (p.M + 255) / 256;
-  const int nwg = nbx * nby;
-  int bid = blockIdx.x;
+  // ---- work items: (tile, k-split), tile-major inside a split.  Workgroups land on XCD blockIdx % 8; each XCD
+  //      owns a contiguous range of items (neighbouring tiles share an A row panel in that XCD's L2) and its
+  //      workgroups stride through it together.
+  const int nbx = p.N / 256, ntile = nbx * (p.M / 256);
+  const int nitems = ntile * p.split_k;
+  const int ktiles = p.K / 64, per = (ktiles + p.split_k - 1) / p.split_k;
+  int item, item_end, item_step;
   {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    const int G = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int nx = min(G, 8);                                    // XCDs in use
+    const int q = nitems / nx, r = nitems % nx;
+    const int beg = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    item_end = beg + q + (xcd < r ? 1 : 0);
+    item_step = (G - xcd + 7) >> 3;                              // workgroups on this XCD
+    item = beg + slot;
   }
-  const int m0 = (bid / nbx) * 256, n0 = (bid % nbx) * 256;
-  const int ktiles = p.K / 64;
-  const int per = (ktiles + p.split_k - 1) / p.split_k;
-  const int tbeg = blockIdx.z * per, tend = min(ktiles, tbeg + per);
-  if (tbeg >= tend) return;
-  const int nt = tend - tbeg, kbeg = tbeg * 64;
-  const int nunits = 4 * nt;
-  // diagnostic time stamps (p.atomic & 0x10000, p.aux_out = uint32 [8 waves][32]): workgroup 0, k-tile 3.
-  // s_memtime returns through lgkmcnt; the values are only read after the kernel's own lgkmcnt(0) waits.
-  const bool dbg = (p.atomic & 0x10000) && blockIdx.x == 0 && blockIdx.z == 0;
-  unsigned ts[32];
-#pragma unroll
-  for (int i = 0; i < 32; ++i) ts[i] = 0;
-#define PP_STAMP(I) do { if (dbg_t) { unsigned long long t64_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t64_) :: "memory"); ts[I] = (unsigned)t64_; } } while (0)
-  { const bool dbg_t = dbg; PP_STAMP(19); }
+  if (item >= item_end) return;
 
-  // staging sources: unit type J (0 A0, 1 B0, 2 B1, 3 A1), wave-instructions w and w + 8 of each
-  const bf16* src[4][2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    src[0][q] = pp_src<TA, 0>(A, p.lda, p.M, m0, kbeg, w + 8 * q, lane);
-    src[1][q] = pp_src<TB, 1>(B, p.ldb, p.N, n0, kbeg, w + 8 * q, lane);
-    src[2][q] = pp_src<TB, 2>(B, p.ldb, p.N, n0, kbeg, w + 8 * q, lane);
-    src[3][q] = pp_src<TA, 3>(A, p.lda, p.M, m0, kbeg, w + 8 * q, lane);
-  }
   const size_t stepa = TA ? (size_t)64 * p.lda : (size_t)64;
   const size_t stepb = TB ? (size_t)64 * p.ldb : (size_t)64;
   const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((lds_void_p)smem);
+  unsigned fa[2], fb;                                            // fragment addresses (buffer 0; the other is + 65536)
+  fa[0] = lds0 + pp_frag_off<TA>(wr * 64, lane);
+  fa[1] = lds0 + pp_frag_off<TA>(wr * 64 + 32, lane);
+  fb = lds0 + pp_frag_off<TB>(wc * 32, lane);
+
+  int m0, n0, nt;
+  const bf16* src[4][2];        // staging sources: unit type J (0 A0, 1 B0, 2 B1, 3 A1), wave-instructions w and w + 8
+  auto setup = [&](int it) __attribute__((always_inline)) {
+    const int z = it / ntile, tile = it - z * ntile;
+    m0 = (tile / nbx) * 256; n0 = (tile % nbx) * 256;
+    const int tbeg = z * per;
+    nt = min(ktiles, tbeg + per) - tbeg;
+    const int kbeg = tbeg * 64;
+    int ln = lane;                                     // opaque copy: keeps the per-lane address arithmetic from being
+    asm volatile("" : "+v"(ln));                       // hoisted out of the item loop (it would live, and spill, across the main loop)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      src[0][q] = pp_src<TA, 0>(A, p.lda, p.M, m0, kbeg, w + 8 * q, ln);
+      src[1][q] = pp_src<TB, 1>(B, p.ldb, p.N, n0, kbeg, w + 8 * q, ln);
+      src[2][q] = pp_src<TB, 2>(B, p.ldb, p.N, n0, kbeg, w + 8 * q, ln);
+      src[3][q] = pp_src<TA, 3>(A, p.lda, p.M, m0, kbeg, w + 8 * q, ln);
+    }
+  };
 
   // issue unit type J of the next k-tile that type has not fetched yet into buffer BUF (0/1)
 #define PP_ISSUE(J, BUF)                                                                                        \
@@ -126,32 +244,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
       src[J][q] += ((J) == 0 || (J) == 3) ? stepa : stepb;                                                     \
     }                                                                                                          \
   } while (0)
+  // first six units of an item (k-tile 0 whole, A0 and B0 of k-tile 1); the host guarantees nt >= 2
+#define PP_PROLOGUE() do { PP_ISSUE(0, 0); PP_ISSUE(1, 0); PP_ISSUE(2, 0); PP_ISSUE(3, 0); PP_ISSUE(0, 1); PP_ISSUE(1, 1); } while (0)
 
   f32x16 acc[2][2][2];                                 // [A half][i][j]
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
-
-  // fragment addresses (buffer 0); the other buffer is + 65536
-  unsigned fa[2], fb;
-  fa[0] = lds0 + pp_frag_off<TA>(wr * 64, lane);
-  fa[1] = lds0 + pp_frag_off<TA>(wr * 64 + 32, lane);
-  fb = lds0 + pp_frag_off<TB>(wc * 32, lane);
-
-  // prologue: units 0..5 (k-tile 0 whole, A0 and B0 of k-tile 1); the host guarantees nt >= 2
-  PP_ISSUE(0, 0); PP_ISSUE(1, 0); PP_ISSUE(2, 0); PP_ISSUE(3, 0); PP_ISSUE(0, 1); PP_ISSUE(1, 1);
-  wait_vmcnt<8>();                                     // units 0 and 1
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();           // wave row 1 runs one barrier interval behind
-  __builtin_amdgcn_sched_barrier(0);
-
   bf16x8 a[2][4], b0[4], b1[4];
-  { const bool dbg_t = dbg; PP_STAMP(20); }
 
 #define PP_MFMA(H, JB, BREG)                                                                                   \
   do {                                                                                                         \
@@ -174,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     pp_read<TB, 2>(BREG[2], fb + (BASEOFF)); pp_read<TB, 3>(BREG[3], fb + (BASEOFF));                          \
   } while (0)
   // end of an L section: retire the units the next phase reads, publish, then wait for this phase's own reads
-#define PP_SYNC_L(ALLOW, P)                                                                                    \
+#define PP_SYNC_L(ALLOW)                                                                                       \
   do {                                                                                                         \
     if ((ALLOW) >= 4) wait_vmcnt<8>(); else if ((ALLOW) == 3) wait_vmcnt<6>(); else if ((ALLOW) == 2) wait_vmcnt<4>(); \
     else if ((ALLOW) == 1) wait_vmcnt<2>(); else wait_vmcnt<0>();                                              \
@@ -184,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     __builtin_amdgcn_s_setprio(1);                                                                             \
   } while (0)
-#define PP_SYNC_C(P)                                                                                           \
+#define PP_SYNC_C()                                                                                            \
   do {                                                                                                         \
     __builtin_amdgcn_s_setprio(0);                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
@@ -192,33 +289,34 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   } while (0)
 
-  const bool no_dma = (p.atomic & 0x2000) != 0, no_rd = (p.atomic & 0x8000) != 0;   // diagnostics
   auto body = [&](auto tail_c, int kt) __attribute__((always_inline)) {
     constexpr bool TAIL = decltype(tail_c)::value;
+    const int nunits = 4 * nt;
     const unsigned cb = (kt & 1) * 65536u;             // this k-tile's buffer
     const int nb = (kt & 1) ^ 1;                       // buffer of k-tile kt+1 (kt+2 shares this tile's)
     const int f0 = 4 * kt;                             // first phase; phase f issues unit f+6, may leave min(4, nunits-3-f) units in flight
     // ---- phase 0
-    if (!no_rd) { PP_READ_A(cb + 0 * PP_UNIT); PP_READ_B(b0, cb + 1 * PP_UNIT); }
-    if ((!TAIL || f0 + 6 < nunits) && !no_dma) PP_ISSUE(2, nb);
-    PP_SYNC_L(TAIL ? nunits - 3 - f0 : 4, 0);
+    PP_READ_A(cb + 0 * PP_UNIT);
+    PP_READ_B(b0, cb + 1 * PP_UNIT);
+    if (!TAIL || f0 + 6 < nunits) PP_ISSUE(2, nb);
+    PP_SYNC_L(TAIL ? nunits - 3 - f0 : 4);
     PP_MFMA(0, 0, b0);
-    PP_SYNC_C(0);
+    PP_SYNC_C();
     // ---- phase 1
-    if (!no_rd) PP_READ_B(b1, cb + 2 * PP_UNIT);
-    if ((!TAIL || f0 + 7 < nunits) && !no_dma) PP_ISSUE(3, nb);
-    PP_SYNC_L(TAIL ? nunits - 4 - f0 : 4, 1);
+    PP_READ_B(b1, cb + 2 * PP_UNIT);
+    if (!TAIL || f0 + 7 < nunits) PP_ISSUE(3, nb);
+    PP_SYNC_L(TAIL ? nunits - 4 - f0 : 4);
     PP_MFMA(0, 1, b1);
-    PP_SYNC_C(1);
+    PP_SYNC_C();
     // ---- phase 2
-    if (!no_rd) PP_READ_A(cb + 3 * PP_UNIT);
-    if ((!TAIL || f0 + 8 < nunits) && !no_dma) PP_ISSUE(0, nb ^ 1);
-    PP_SYNC_L(TAIL ? nunits - 5 - f0 : 4, 2);
+    PP_READ_A(cb + 3 * PP_UNIT);
+    if (!TAIL || f0 + 8 < nunits) PP_ISSUE(0, nb ^ 1);
+    PP_SYNC_L(TAIL ? nunits - 5 - f0 : 4);
     PP_MFMA(1, 1, b1);
-    PP_SYNC_C(2);
+    PP_SYNC_C();
     // ---- phase 3
-    if ((!TAIL || f0 + 9 < nunits) && !no_dma) PP_ISSUE(1, nb ^ 1);
-    PP_SYNC_L(TAIL ? nunits - 6 - f0 : 4, 3);
+    if (!TAIL || f0 + 9 < nunits) PP_ISSUE(1, nb ^ 1);
+    PP_SYNC_L(TAIL ? nunits - 6 - f0 : 4);
     PP_MFMA(1, 0, b0);
     if (TAIL && kt == nt - 1) {                        // wave row 1 has no partner barrier left after its last C section
       __builtin_amdgcn_s_setprio(0);
@@ -226,62 +324,160 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
       if (wr == 0) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     } else {
-      PP_SYNC_C(3);
+      PP_SYNC_C();
     }
   };
-  if (p.atomic & 0x4000) {                             // diagnostic: epilogue only
-    wait_vmcnt<0>();
-    if (wr == 0) __builtin_amdgcn_s_barrier();
-    __syncthreads();
-  } else {
-    int kt = 0;
-    for (; kt + 2 < nt; ++kt) body(std::false_type{}, kt);
-    for (; kt < nt; ++kt) body(std::true_type{}, kt);
+
+  // diagnostic time stamps (p.atomic & 0x10000, p.aux_out = uint32 [8 waves][16]): workgroup 0, around its third item
+  const bool dbg = (p.atomic & 0x10000) && blockIdx.x == 0;
+  unsigned ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int nitem_done = 0;
+#define PP_STAMP(I) do { if (dbg && nitem_done == 2) { unsigned long long t64_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t64_) :: "memory"); ts[I] = (unsigned)t64_; } } while (0)
+  setup(item);
+  PP_PROLOGUE();
+  int younger = 8;                                     // VMEM operations issued after the first two units of the current item
+  for (;;) {
+    // units 0 and 1 of this item: this wave's part has landed, then publish
+    if (younger == 8) wait_vmcnt<8>(); else if (younger == 24) wait_vmcnt<24>(); else if (younger == 40) wait_vmcnt<40>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();         // wave row 1 runs one barrier interval behind
+    __builtin_amdgcn_sched_barrier(0);
+    // accumulators start at the bias (scalar loads: uniform address in constant space, lgkmcnt, no vector registers;
+    // this sits in the shadow of the staging wait above).  Register 8g+4cc+e of block j is column 32j+16g+8cc+4h+e.
+    if (TACC && p.bias) {
+      typedef __attribute__((ext_vector_type(16))) float f32x16c;
+      typedef const __attribute__((address_space(4))) f32x16c* cvec_p;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const f32x16c bvv = *(cvec_p)(uintptr_t)(p.bias + n0 + wc * 64 + 32 * j + 16 * g);
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float lo = bvv[8 * cc + e], hi = bvv[8 * cc + 4 + e];
+              const float b = (lane >> 5) ? hi : lo;
+#pragma unroll
+              for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[hh][i][j][8 * g + 4 * cc + e] = b;
+            }
+        }
+    } else {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[hh][i][j][r] = 0.f;
+    }
+    PP_STAMP(0);
+    if (dbg && nitem_done == 3) { unsigned long long t64_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t64_) :: "memory"); ts[6] = (unsigned)t64_; }
+    if (!(p.atomic & 0x4000)) {                        // (diagnostic 0x4000: epilogue only)
+      int kt = 0;
+      for (; kt + 2 < nt; ++kt) body(std::false_type{}, kt);
+      for (; kt < nt; ++kt) body(std::true_type{}, kt);
+    }
+    // The ring is free: no wave reads it after its last L section (wave row 1 is at most in its last C section),
+    // and every LDS-DMA of this item has been waited for.  Start the next item before storing this one.
+    PP_STAMP(1);
+    const int em0 = m0 + wr * 128, en0 = n0 + wc * 64;
+    item += item_step;
+    const bool more = item < item_end;
+    const bool store = !(p.atomic & 0x800);            // (diagnostic 0x800: main loop only)
+    if (!store) {
+      if (more) { setup(item); PP_PROLOGUE(); }
+      younger = 8;
+    } else if (TACC) {
+      PpOut out;
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      pp_epi_compute<EPI>(p, acc, out, em0, en0, ln);
+      PP_STAMP(2);
+      if (more) { setup(item); PP_PROLOGUE(); }
+      PP_STAMP(3);
+      asm volatile("" : "+v"(ln));
+      pp_epi_store<EPI>(p, out, em0, en0, ln);
+      PP_STAMP(4);
+      younger = (EPI == EPI_GELU && p.aux_out) ? 40 : 24;
+    } else {                                           // fp32 output (accumulate / split-K atomics): row segments per register
+      bf16_tile_epilogue<false>(p, acc[0], em0, en0, 0, 0, lane, smem);
+      bf16_tile_epilogue<false>(p, acc[1], em0 + 64, en0, 0, 0, lane, smem);
+      if (more) { setup(item); PP_PROLOGUE(); }
+      younger = 8;
+    }
+    ++nitem_done;
+    if (!more) break;
   }
+  if (dbg) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      unsigned* o = reinterpret_cast<unsigned*>(p.aux_out) + w * 16;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = ts[i];
+    }
+  }
+#undef PP_STAMP
 #undef PP_ISSUE
+#undef PP_PROLOGUE
 #undef PP_MFMA
 #undef PP_READ_A
 #undef PP_READ_B
 #undef PP_SYNC_L
 #undef PP_SYNC_C
-  // (the epilogue's LDS staging is wave-private and no wave reads the ring after its last L section, so wave
-  //  row 0 starts storing while wave row 1 is still in its last C section)
-  { const bool dbg_t = dbg; PP_STAMP(21); }
-  if (p.atomic & 0x800) return;                        // diagnostic: main loop only
-  if (TACC) {                                          // bf16 output, aligned (host-checked): straight from the registers
-    bf16_tile_epilogue_direct(p, acc[0], m0 + wr * 128, n0 + wc * 64, lane);
-    bf16_tile_epilogue_direct(p, acc[1], m0 + wr * 128 + 64, n0 + wc * 64, lane);
-  } else {                                             // fp32 output (accumulate / split-K atomics): row segments per register
-    bf16_tile_epilogue<false>(p, acc[0], m0 + wr * 128, n0 + wc * 64, 0, 0, lane, smem);
-    bf16_tile_epilogue<false>(p, acc[1], m0 + wr * 128 + 64, n0 + wc * 64, 0, 0, lane, smem);
-  }
-  if (dbg) {
-    { const bool dbg_t = true; PP_STAMP(22); }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) {
-      unsigned* o = reinterpret_cast<unsigned*>(p.aux_out) + w * 32;
-#pragma unroll
-      for (int i = 0; i < 32; ++i) o[i] = ts[i];
-    }
-  }
-#undef PP_STAMP
 }
 
-template <bool TA, bool TB, bool TACC>
-void pp_launch1(const GemmArgs& p, hipStream_t st) {
+static int pp_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <bool TA, bool TB, bool TACC, int EPI>
+static void pp_launch0(const GemmArgs& p, hipStream_t st) {
   constexpr int smem = 131072;
-  auto kern = gemm_bf16_pp_kernel<TA, TB, TACC>;
+  auto kern = gemm_bf16_pp_kernel<TA, TB, TACC, EPI>;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
-  const int nwg = ((p.N + 255) / 256) * ((p.M + 255) / 256);
-  hipLaunchKernelGGL(kern, dim3(nwg, 1, p.split_k), dim3(512), smem, st, p);
+  const int nitems = (p.N / 256) * (p.M / 256) * p.split_k;
+  const int grid = nitems < pp_num_cus() ? nitems : pp_num_cus();
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, p);
 }
 
-template void pp_launch1<false, false, false>(const GemmArgs&, hipStream_t);
-template void pp_launch1<false, false, true>(const GemmArgs&, hipStream_t);
-template void pp_launch1<false, true, false>(const GemmArgs&, hipStream_t);
-template void pp_launch1<false, true, true>(const GemmArgs&, hipStream_t);
-template void pp_launch1<true, false, false>(const GemmArgs&, hipStream_t);
-template void pp_launch1<true, false, true>(const GemmArgs&, hipStream_t);
-template void pp_launch1<true, true, false>(const GemmArgs&, hipStream_t);
-template void pp_launch1<true, true, true>(const GemmArgs&, hipStream_t);
+// The epilogue kind is a template parameter; only the combinations the encoder uses are instantiated:
+//   X*W^T (forward): none, GELU, +residual, tanh;  dY*W (input gradient): none, dGELU, +residual;  everything else: none.
+bool uc2_gemm_pp_supported(int trans_a, int trans_b, int c_f32, int epi) {
+  if (c_f32) return epi == EPI_NONE;
+  if (!trans_a && !trans_b) return epi == EPI_NONE || epi == EPI_GELU || epi == EPI_ADD || epi == EPI_TANH;
+  if (!trans_a && trans_b) return epi == EPI_NONE || epi == EPI_DGELU || epi == EPI_ADD;
+  return epi == EPI_NONE;
+}
+
+void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st) {
+  if (p.c_f32) {
+    if (!trans_a && !trans_b) pp_launch0<false, false, false, EPI_NONE>(p, st);
+    else if (!trans_a && trans_b) pp_launch0<false, true, false, EPI_NONE>(p, st);
+    else if (trans_a && !trans_b) pp_launch0<true, false, false, EPI_NONE>(p, st);
+    else pp_launch0<true, true, false, EPI_NONE>(p, st);
+  } else if (!trans_a && !trans_b) {
+    if (p.epi == EPI_GELU) pp_launch0<false, false, true, EPI_GELU>(p, st);
+    else if (p.epi == EPI_ADD) pp_launch0<false, false, true, EPI_ADD>(p, st);
+    else if (p.epi == EPI_TANH) pp_launch0<false, false, true, EPI_TANH>(p, st);
+    else pp_launch0<false, false, true, EPI_NONE>(p, st);
+  } else if (!trans_a && trans_b) {
+    if (p.epi == EPI_DGELU) pp_launch0<false, true, true, EPI_DGELU>(p, st);
+    else if (p.epi == EPI_ADD) pp_launch0<false, true, true, EPI_ADD>(p, st);
+    else pp_launch0<false, true, true, EPI_NONE>(p, st);
+  } else if (trans_a && !trans_b) {
+    pp_launch0<true, false, true, EPI_NONE>(p, st);
+  } else {
+    pp_launch0<true, true, true, EPI_NONE>(p, st);
+  }
+}

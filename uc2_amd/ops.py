@@ -30,9 +30,11 @@ class GemmTimer:
 
     @staticmethod
     def kernel_name(key):
-        ta, tb, variant, atomic = key
+        ta, tb, variant, atomic, epi = key
         b = lambda x: "true" if x else "false"
         tacc = b(not atomic)
+        if variant == 8:
+            return "gemm_bf16_pp_kernel<%s, %s, %s, %d>" % (b(ta), b(tb), b(not atomic), epi)
         if variant == 99:
             return "gemm_bf16_kernel<%s, %s, %s>" % (b(ta), b(tb), tacc)
         if variant in (6, 7):
@@ -116,7 +118,11 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
          ptr(bias), epi, ptr(aux_in), ptr(aux_out), ldaux, int(accumulate), split_k, stream())
     if e0 is not None:
         e1.record()
-        timer.add((bool(ta), bool(tb), _CUR_VARIANT, bool(c_f32 and split_k > 1)), 2.0 * M * N * K, e0, e1)
+        if _CUR_VARIANT == 8:       # ping-pong kernel: transposed accumulators iff bf16 output; the epilogue kind is a template argument
+            key = (bool(ta), bool(tb), 8, bool(c_f32), int(epi))
+        else:
+            key = (bool(ta), bool(tb), _CUR_VARIANT, bool(c_f32 and split_k > 1), 0)
+        timer.add(key, 2.0 * M * N * K, e0, e1)
     return out
 
 
@@ -133,7 +139,7 @@ def _wgrad_split(dtype, n_out, n_in, rows):
 # ---- per-shape kernel selection: measured once per (layout, shape) on the device, then cached ----------
 AUTOTUNE = True
 _TUNE = {}
-_FWD_CANDIDATES = ((99, 1), (0, 1), (1, 1), (2, 1), (6, 1), (7, 1))             # (kernel variant, split_k); 99 = generic kernel
+_FWD_CANDIDATES = ((99, 1), (0, 1), (1, 1), (2, 1), (6, 1), (7, 1), (8, 1))     # (kernel variant, split_k); 99 = generic kernel, 8 = ping-pong
 _WGRAD_SPLITS = (2, 3, 4, 6, 8, 12, 16)
 
 
@@ -198,6 +204,13 @@ def gemm_plan(dtype, ta, tb, M, N, K, wgrad=False):
     out = torch.zeros((M, N), dtype=torch.float32 if wgrad else torch.bfloat16, device=dev)
     lib = _lib.load()
     cands = [(v, s) for v in (99, 1, 0, 6) for s in _WGRAD_SPLITS if s * 1024 <= K] if wgrad else list(_FWD_CANDIDATES)
+    if wgrad and M % 256 == 0 and N % 256 == 0:
+        # persistent ping-pong kernel: one (tile, split) item per CU, or two
+        tiles = (M // 256) * (N // 256)
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        for s in sorted({max(1, cus // tiles), max(1, 2 * cus // tiles), max(1, (cus // tiles) // 2)}):
+            if s * 256 <= K:
+                cands.append((8, s))
     best, best_t = default, None
     for v, sp in cands:
         lib.uc2_gemm_set_variant(v)
