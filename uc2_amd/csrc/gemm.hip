@@ -267,6 +267,38 @@ static int g_force_generic = -1;
 // 1 = always use the generic register-staged kernel (A/B tests), 0 = prefer the pipelined one
 extern "C" int uc2_gemm_force_generic(int v) { g_force_generic = v ? 1 : 0; return 0; }
 
+// Split-K workspace (caller-owned device memory): with it, the ping-pong kernel's weight-gradient items store
+// their fp32 partial tiles with plain stores and uc2_splitk_reduce adds them into C -- no atomics, so the
+// result is bit-reproducible, and 64 MB of partials cost ~25 us instead of ~50 us of fp32 atomics.
+float* g_splitk_ws = nullptr;
+size_t g_splitk_ws_bytes = 0;
+extern "C" int uc2_gemm_set_workspace(void* ptr, size_t bytes) {
+  g_splitk_ws = reinterpret_cast<float*>(ptr); g_splitk_ws_bytes = ptr ? bytes : 0;
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int ldc, int split, const float* __restrict__ ws,
+                                                            float* __restrict__ C, int accumulate) {
+  const size_t mn4 = (size_t)M * N / 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < mn4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 a = reinterpret_cast<const float4*>(ws)[i];
+    for (int z = 1; z < split; ++z) {
+      const float4 b = reinterpret_cast<const float4*>(ws + (size_t)z * M * N)[i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const size_t e = i * 4, m = e / N, n = e - m * N;
+    float4* c = reinterpret_cast<float4*>(C + m * ldc + n);
+    if (accumulate) { const float4 o = *c; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+    *c = a;
+  }
+}
+void uc2_splitk_reduce(const GemmArgs& p, hipStream_t st) {        // called by gemm_fast.hip after the partial launch
+  const size_t mn4 = (size_t)p.M * p.N / 4;
+  const int blocks = (int)((mn4 + 255) / 256 < 2048 ? (mn4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.M, p.N, p.ldc, p.split_k, p.partial,
+                     reinterpret_cast<float*>(p.C), p.accumulate);
+}
+
 extern "C" int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K,
                         const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_is_f32,
                         const float* bias, int epilogue, const void* aux_in, void* aux_out, int ldaux,
@@ -284,7 +316,7 @@ extern "C" int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K
   p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux ? ldaux : ldc;
   p.epi = epilogue; p.c_f32 = (dtype == 0) ? 1 : c_is_f32; p.accumulate = accumulate;
-  p.split_k = split_k; p.atomic = (split_k > 1) ? 1 : 0;
+  p.split_k = split_k; p.atomic = (split_k > 1) ? 1 : 0; p.partial = nullptr;
   p.a_vec = (((uintptr_t)A & 15) == 0) && ((lda & 7) == 0);
   p.b_vec = (((uintptr_t)B & 15) == 0) && ((ldb & 7) == 0);
   hipStream_t st = (hipStream_t)stream;

@@ -11,6 +11,7 @@ struct GemmArgs {
   int lda, ldb, ldc, ldaux;
   int epi, c_f32, accumulate, split_k, atomic;
   int a_vec, b_vec;      // 16-byte vector loads allowed (alignment checked on the host)
+  float* partial;        // split-K partial tiles [split][M][N] fp32 (ping-pong kernel, two-stage reduction), or null
 };
 
 // ------------------------------------------------------------------------------------------

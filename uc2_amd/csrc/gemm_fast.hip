@@ -313,6 +313,9 @@ static void ws_launch1(const GemmArgs& p, hipStream_t st) {
 
 bool uc2_gemm_pp_supported(int trans_a, int trans_b, int c_f32, int epi);                       // gemm_pp.hip
 void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st);
+void uc2_splitk_reduce(const GemmArgs& p, hipStream_t st);                                        // gemm.hip
+extern float* g_splitk_ws;
+extern size_t g_splitk_ws_bytes;
 
 // ------------------------------------------------------------------------------------------------------
 // host side: variant selection
@@ -365,7 +368,18 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
   const bool tacc = !(p.c_f32 && p.atomic);
   GemmArgs pd = p;
   if (g_fetch_only) pd.atomic |= (g_fetch_only << 8);
-  if (variant == 8) { uc2_gemm_pp_launch(pd, trans_a, trans_b, st); return 1; }
+  if (variant == 8) {
+    const size_t need = (size_t)p.split_k * p.M * p.N * sizeof(float);
+    if (p.c_f32 && p.split_k > 1 && g_splitk_ws && need <= g_splitk_ws_bytes && (p.N & 3) == 0 && (p.ldc & 3) == 0 &&
+        ((uintptr_t)p.C & 15) == 0) {
+      pd.partial = g_splitk_ws;                      // two-stage: plain partial stores, then one reduction pass
+      uc2_gemm_pp_launch(pd, trans_a, trans_b, st);
+      uc2_splitk_reduce(pd, st);
+    } else {
+      uc2_gemm_pp_launch(pd, trans_a, trans_b, st);
+    }
+    return 1;
+  }
 #define GF_GO(TA_, TB_) do { if (tacc) gf_launch2<TA_, TB_, true>(pd, variant, st); else gf_launch2<TA_, TB_, false>(pd, variant, st); } while (0)
   if (!trans_a && !trans_b) GF_GO(false, false);
   else if (!trans_a && trans_b) GF_GO(false, true);

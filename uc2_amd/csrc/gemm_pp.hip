@@ -181,6 +181,25 @@ __device__ __forceinline__ void pp_epi_store(const GemmArgs& p, const PpOut& out
     }
 }
 
+// fp32 partial tile of one split-K item (two-stage reduction): transposed accumulators, lane = row m with 4
+// consecutive columns per register group -> 16-byte plain stores, 32 per wave (compile-time count, full tiles)
+__device__ __forceinline__ void pp_partial_store(float* __restrict__ dst, int ldn, const f32x16 (&acc)[2][2][2], int mb0, int nb,
+                                                 int lane) {
+  const int h = lane >> 5, c31 = lane & 31;
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float* row = dst + (size_t)(mb0 + hh * 64 + i * 32 + c31) * ldn + nb + 4 * h;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          *reinterpret_cast<float4*>(row + 32 * j + 8 * c) =
+              make_float4(acc[hh][i][j][4 * c], acc[hh][i][j][4 * c + 1], acc[hh][i][j][4 * c + 2], acc[hh][i][j][4 * c + 3]);
+    }
+}
+
 template <> __device__ __forceinline__ void wait_vmcnt<40>() { asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); }
 
 template <bool TA, bool TB, bool TACC, int EPI>
@@ -216,10 +235,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   fa[1] = lds0 + pp_frag_off<TA>(wr * 64 + 32, lane);
   fb = lds0 + pp_frag_off<TB>(wc * 32, lane);
 
-  int m0, n0, nt;
+  int m0, n0, nt, zsplit;
   const bf16* src[4][2];        // staging sources: unit type J (0 A0, 1 B0, 2 B1, 3 A1), wave-instructions w and w + 8
   auto setup = [&](int it) __attribute__((always_inline)) {
     const int z = it / ntile, tile = it - z * ntile;
+    zsplit = z;
     m0 = (tile / nbx) * 256; n0 = (tile % nbx) * 256;
     const int tbeg = z * per;
     nt = min(ktiles, tbeg + per) - tbeg;
@@ -384,13 +404,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     // The ring is free: no wave reads it after its last L section (wave row 1 is at most in its last C section),
     // and every LDS-DMA of this item has been waited for.  Start the next item before storing this one.
     PP_STAMP(1);
-    const int em0 = m0 + wr * 128, en0 = n0 + wc * 64;
+    const int em0 = m0 + wr * 128, en0 = n0 + wc * 64, ez = zsplit;
     item += item_step;
     const bool more = item < item_end;
     const bool store = !(p.atomic & 0x800);            // (diagnostic 0x800: main loop only)
     if (!store) {
       if (more) { setup(item); PP_PROLOGUE(); }
       younger = 8;
+    } else if (TACC && p.partial) {                     // split-K item of a two-stage reduction (fp32 partial, plain stores)
+      if (more) { setup(item); PP_PROLOGUE(); }
+      pp_partial_store(p.partial + (size_t)ez * p.M * p.N, p.N, acc, em0, en0, lane);
+      younger = 40;
     } else if (TACC) {
       PpOut out;
       int ln = lane;
@@ -461,7 +485,12 @@ bool uc2_gemm_pp_supported(int trans_a, int trans_b, int c_f32, int epi) {
 }
 
 void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st) {
-  if (p.c_f32) {
+  if (p.c_f32 && p.partial) {                          // the bf16-output kernels double as partial-tile producers
+    if (!trans_a && !trans_b) pp_launch0<false, false, true, EPI_NONE>(p, st);
+    else if (!trans_a && trans_b) pp_launch0<false, true, true, EPI_NONE>(p, st);
+    else if (trans_a && !trans_b) pp_launch0<true, false, true, EPI_NONE>(p, st);
+    else pp_launch0<true, true, true, EPI_NONE>(p, st);
+  } else if (p.c_f32) {
     if (!trans_a && !trans_b) pp_launch0<false, false, false, EPI_NONE>(p, st);
     else if (!trans_a && trans_b) pp_launch0<false, true, false, EPI_NONE>(p, st);
     else if (trans_a && !trans_b) pp_launch0<true, false, false, EPI_NONE>(p, st);

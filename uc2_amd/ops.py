@@ -108,6 +108,8 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
     for x in (aux_in, aux_out):
         if x is not None:
             ldaux = x.stride(0)
+    if _CUR_VARIANT == 8 and c_f32 and split_k > 1:
+        _ensure_splitk_workspace(a.device, split_k * M * N * 4)
     timer = GEMM_TIMER
     if timer is not None and dtype == torch.bfloat16 and _CUR_VARIANT != -2:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -124,6 +126,21 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
             key = (bool(ta), bool(tb), _CUR_VARIANT, bool(c_f32 and split_k > 1), 0)
         timer.add(key, 2.0 * M * N * K, e0, e1)
     return out
+
+
+_SPLITK_WS = {}
+
+
+def _ensure_splitk_workspace(device, nbytes):
+    """device scratch for the two-stage split-K reduction of the ping-pong kernel (uc2_gemm_set_workspace): grown
+    on demand, one per process (one process per GPU); every user runs on torch's current stream, in order"""
+    ws = _SPLITK_WS.get("ws")
+    if ws is None or ws.numel() < nbytes or ws.device != device:
+        if torch.cuda.is_current_stream_capturing():
+            return
+        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _SPLITK_WS["ws"] = ws
+        _lib.call("uc2_gemm_set_workspace", ws.data_ptr(), ws.numel())
 
 
 def _wgrad_split(dtype, n_out, n_in, rows):
