@@ -53,6 +53,9 @@ int uc2_gemm_set_fetch_only(int diagnostic_mode);
 /* optional caller-owned device workspace for split-K weight gradients (>= split_k*M*N*4 bytes): partial tiles are
  * stored plainly and reduced in a second pass instead of fp32 atomics (bit-reproducible); NULL disables it */
 int uc2_gemm_set_workspace(void* ptr, size_t bytes);
+/* profiling aid: with defer on, uc2_gemm stops after the partial tiles and the caller runs the reduction pass itself */
+int uc2_gemm_defer_reduce(int on);
+int uc2_gemm_splitk_reduce(int M, int N, void* C, int ldc, int split_k, int accumulate, void* stream);
 
 /* ---- LayerNorm fused with dropout + residual (apex FusedLayerNorm, model/layer.py:25; the dense->dropout->
  *      LayerNorm(x + residual) tails at model/layer.py:111-115,152-156; embeddings model/model.py:331,358-362) -----

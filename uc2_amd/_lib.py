@@ -26,6 +26,8 @@ SIGNATURES = {
     "uc2_gemm_set_variant": (I, [I]),
     "uc2_gemm_set_fetch_only": (I, [I]),
     "uc2_gemm_set_workspace": (I, [P, SZ]),
+    "uc2_gemm_defer_reduce": (I, [I]),
+    "uc2_gemm_splitk_reduce": (I, [I, I, P, I, I, I, P]),
     "uc2_ln_fwd": (I, [I, I, I, P, P, P, P, F, F, P, U64, P, P, P, P]),
     "uc2_ln_bwd_workspace": (SZ, [I, I]),
     "uc2_ln_bwd": (I, [I, I, I, P, P, P, P, P, P, F, P, U64, P, P, P, P, P, P, P]),

@@ -292,11 +292,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int ld
     *c = a;
   }
 }
+int g_splitk_defer = 0;           // 1: uc2_gemm leaves the partials in the workspace; the caller runs uc2_gemm_splitk_reduce
+extern "C" int uc2_gemm_defer_reduce(int on) { g_splitk_defer = on ? 1 : 0; return 0; }
 void uc2_splitk_reduce(const GemmArgs& p, hipStream_t st) {        // called by gemm_fast.hip after the partial launch
   const size_t mn4 = (size_t)p.M * p.N / 4;
   const int blocks = (int)((mn4 + 255) / 256 < 2048 ? (mn4 + 255) / 256 : 2048);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.M, p.N, p.ldc, p.split_k, p.partial,
                      reinterpret_cast<float*>(p.C), p.accumulate);
+}
+// second stage on its own (after a uc2_gemm issued under uc2_gemm_defer_reduce(1)): C (=|+=) sum_z workspace[z]
+extern "C" int uc2_gemm_splitk_reduce(int M, int N, void* C, int ldc, int split_k, int accumulate, void* stream) {
+  UC2_CHECK_ARG(C && g_splitk_ws && (size_t)split_k * M * N * sizeof(float) <= g_splitk_ws_bytes);
+  UC2_CHECK_ARG((N & 3) == 0 && (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0);
+  GemmArgs p{};
+  p.M = M; p.N = N; p.C = C; p.ldc = ldc; p.split_k = split_k; p.accumulate = accumulate; p.partial = g_splitk_ws;
+  uc2_splitk_reduce(p, (hipStream_t)stream);
+  UC2_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K,

@@ -316,6 +316,7 @@ void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t
 void uc2_splitk_reduce(const GemmArgs& p, hipStream_t st);                                        // gemm.hip
 extern float* g_splitk_ws;
 extern size_t g_splitk_ws_bytes;
+extern int g_splitk_defer;
 
 // ------------------------------------------------------------------------------------------------------
 // host side: variant selection
@@ -374,7 +375,7 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
         ((uintptr_t)p.C & 15) == 0) {
       pd.partial = g_splitk_ws;                      // two-stage: plain partial stores, then one reduction pass
       uc2_gemm_pp_launch(pd, trans_a, trans_b, st);
-      uc2_splitk_reduce(pd, st);
+      if (!g_splitk_defer) uc2_splitk_reduce(pd, st);
     } else {
       uc2_gemm_pp_launch(pd, trans_a, trans_b, st);
     }

@@ -108,20 +108,30 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
     for x in (aux_in, aux_out):
         if x is not None:
             ldaux = x.stride(0)
+    two_stage = False
     if _CUR_VARIANT == 8 and c_f32 and split_k > 1:
-        _ensure_splitk_workspace(a.device, split_k * M * N * 4)
+        two_stage = _ensure_splitk_workspace(a.device, split_k * M * N * 4)
     timer = GEMM_TIMER
     if timer is not None and dtype == torch.bfloat16 and _CUR_VARIANT != -2:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()                # on torch's current stream == the stream the kernel is launched on
     else:
         e0 = None
-    call("uc2_gemm", dt(dtype), int(ta), int(tb), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc, int(c_f32),
-         ptr(bias), epi, ptr(aux_in), ptr(aux_out), ldaux, int(accumulate), split_k, stream())
+    defer = two_stage and e0 is not None         # time the GEMM kernel alone: run the reduction pass separately
+    if defer:
+        call("uc2_gemm_defer_reduce", 1)
+    try:
+        call("uc2_gemm", dt(dtype), int(ta), int(tb), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc, int(c_f32),
+             ptr(bias), epi, ptr(aux_in), ptr(aux_out), ldaux, int(accumulate), split_k, stream())
+    finally:
+        if defer:
+            call("uc2_gemm_defer_reduce", 0)
     if e0 is not None:
         e1.record()
-        if _CUR_VARIANT == 8:       # ping-pong kernel: transposed accumulators iff bf16 output; the epilogue kind is a template argument
-            key = (bool(ta), bool(tb), 8, bool(c_f32), int(epi))
+        if defer:
+            call("uc2_gemm_splitk_reduce", M, N, ptr(out), ldc, split_k, int(accumulate), stream())
+        if _CUR_VARIANT == 8:       # ping-pong kernel: transposed accumulators unless fp32 atomics; the epilogue kind is a template argument
+            key = (bool(ta), bool(tb), 8, bool(c_f32 and not two_stage), int(epi))
         else:
             key = (bool(ta), bool(tb), _CUR_VARIANT, bool(c_f32 and split_k > 1), 0)
         timer.add(key, 2.0 * M * N * K, e0, e1)
@@ -137,10 +147,11 @@ def _ensure_splitk_workspace(device, nbytes):
     ws = _SPLITK_WS.get("ws")
     if ws is None or ws.numel() < nbytes or ws.device != device:
         if torch.cuda.is_current_stream_capturing():
-            return
+            return ws is not None and ws.device == device and ws.numel() >= nbytes
         ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
         _SPLITK_WS["ws"] = ws
         _lib.call("uc2_gemm_set_workspace", ws.data_ptr(), ws.numel())
+    return True
 
 
 def _wgrad_split(dtype, n_out, n_in, rows):
