@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void attn_fwd_simple(int B, int L, int nh, con
       const float p = __expf(s - mn);
       l = l * alpha + p;
       float pd = p;
-      if (thresh) pd = drop_keep(seed, ((uint64_t)bh * L + q) * L + k, thresh) ? p * keep_scale : 0.f;
+      if (thresh) pd = attn_keep(attn_line_hash(seed, bh, q, UC2_ATTN_SALT_Q), attn_line_hash(seed, bh, k, UC2_ATTN_SALT_K), thresh) ? p * keep_scale : 0.f;
       const float* vr = Vs + k * (D + AT_PAD);
 #pragma unroll
       for (int d = 0; d < D; d += 4) {
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void attn_bwd_simple(int B, int L, int nh, con
       }
       const float p = __expf(s * scale + Ms[k] - lq);
       float dp = dpd;
-      if (thresh) dp = drop_keep(seed, ((uint64_t)bh * L + q) * L + k, thresh) ? dpd * keep_scale : 0.f;
+      if (thresh) dp = attn_keep(attn_line_hash(seed, bh, q, UC2_ATTN_SALT_Q), attn_line_hash(seed, bh, k, UC2_ATTN_SALT_K), thresh) ? dpd * keep_scale : 0.f;
       const float ds = p * (dp - delta) * scale;
 #pragma unroll
       for (int d = 0; d < D; d += 4) {
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void attn_bwd_simple(int B, int L, int nh, con
         s += kr[d] * qv.x + kr[d + 1] * qv.y + kr[d + 2] * qv.z + kr[d + 3] * qv.w;
       }
       float p = __expf(s * scale + mk - Ls[q]);
-      if (thresh) p = drop_keep(seed, ((uint64_t)bh * L + q) * L + k, thresh) ? p * keep_scale : 0.f;
+      if (thresh) p = attn_keep(attn_line_hash(seed, bh, q, UC2_ATTN_SALT_Q), attn_line_hash(seed, bh, k, UC2_ATTN_SALT_K), thresh) ? p * keep_scale : 0.f;
       const float* gr = X1 + q * (D + AT_PAD);
 #pragma unroll
       for (int d = 0; d < D; d += 4) {
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void attn_bwd_simple(int B, int L, int nh, con
       }
       const float p = __expf(s * scale + mk - Ls[q]);
       float dp = dpd;
-      if (thresh) dp = drop_keep(seed, ((uint64_t)bh * L + q) * L + k, thresh) ? dpd * keep_scale : 0.f;
+      if (thresh) dp = attn_keep(attn_line_hash(seed, bh, q, UC2_ATTN_SALT_Q), attn_line_hash(seed, bh, k, UC2_ATTN_SALT_K), thresh) ? dpd * keep_scale : 0.f;
       const float ds = p * (dp - Ds[q]) * scale;
 #pragma unroll
       for (int d = 0; d < D; d += 4) {

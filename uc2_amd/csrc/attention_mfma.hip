@@ -75,6 +75,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
   char* Ks = smem;
   char* Vs = smem + Lp * RS;
   float* Ms = reinterpret_cast<float*>(smem + 2 * Lp * RS);
+  uint32_t* Hk = reinterpret_cast<uint32_t*>(Ms + Lp);          // per-key dropout hashes
   const int bh = blockIdx.x, b = bh / nh, head = bh - b * nh;
   const int H = nh * D, ld = 3 * H;
   const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
@@ -82,7 +83,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
   const int tid = threadIdx.x;
   stage_tile<D>(Ks, base + H, ld, L, Lp, tid, NW * 64);
   stage_tile<D>(Vs, base + 2 * H, ld, L, Lp, tid, NW * 64);
-  for (int k = tid; k < Lp; k += NW * 64) Ms[k] = (k < L) ? (mask ? mask[(size_t)b * L + k] : 0.f) : -1e30f;
+  for (int k = tid; k < Lp; k += NW * 64) {
+    Ms[k] = (k < L) ? (mask ? mask[(size_t)b * L + k] : 0.f) : -1e30f;
+    Hk[k] = attn_line_hash(seed, bh, k, UC2_ATTN_SALT_K);
+  }
   __syncthreads();
 
   const int w = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
@@ -115,18 +119,24 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
   }
   mx = fmaxf(mx, __shfl_xor(mx, 32));
   float sum = 0.f;
+  const uint32_t hq = attn_line_hash(seed, bh, q, UC2_ATTN_SALT_Q);
 #pragma unroll
   for (int kb = 0; kb < NW; ++kb)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float p = __expf(sc[kb][i] - mx);
-      sum += p;
-      float pd = p;
+    for (int g = 0; g < 4; ++g) {
+      bool kp[4] = {true, true, true, true};
       if (thresh) {
-        const int key = 32 * kb + acc_row(i, h);
-        pd = drop_keep(seed, ((uint64_t)bh * L + q) * L + key, thresh) ? p * keep_scale : 0.f;
+        const uint4 hk4 = *reinterpret_cast<const uint4*>(Hk + 32 * kb + 8 * g + 4 * h);
+        kp[0] = attn_keep(hq, hk4.x, thresh); kp[1] = attn_keep(hq, hk4.y, thresh);
+        kp[2] = attn_keep(hq, hk4.z, thresh); kp[3] = attn_keep(hq, hk4.w, thresh);
       }
-      sc[kb][i] = pd;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * g + e;
+        const float p = __expf(sc[kb][i] - mx);
+        sum += p;
+        sc[kb][i] = kp[e] ? (thresh ? p * keep_scale : p) : 0.f;
+      }
     }
   sum += __shfl_xor(sum, 32);
   const float inv = 1.0f / sum;
@@ -175,6 +185,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
   float* Ms = reinterpret_cast<float*>(smem + 4 * Lp * RS);
   float* Ls = Ms + Lp;
   float* Ds = Ls + Lp;
+  uint32_t* Hq = reinterpret_cast<uint32_t*>(Ds + Lp);          // per-query / per-key dropout hashes
+  uint32_t* Hk = Hq + Lp;
   const int bh = blockIdx.x, b = bh / nh, head = bh - b * nh;
   const int H = nh * D, ld = 3 * H;
   const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
@@ -201,6 +213,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
       }
     }
     Ds[k] = dl;
+    Hq[k] = attn_line_hash(seed, bh, k, UC2_ATTN_SALT_Q);
+    Hk[k] = attn_line_hash(seed, bh, k, UC2_ATTN_SALT_K);
   }
   __syncthreads();
 
@@ -213,6 +227,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
 #pragma unroll
     for (int s = 0; s < KS; ++s) { qf[s] = ld_row(Qs, RS, r0, 2 * s + h); gf[s] = ld_row(Gs, RS, r0, 2 * s + h); }
     const float lq = Ls[r0], dl = Ds[r0];
+    const uint32_t hq1 = Hq[r0];
     f32x16 dq[DB];
 #pragma unroll
     for (int db = 0; db < DB; ++db)
@@ -232,15 +247,18 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
       for (int g = 0; g < 4; ++g) {
         const float4 mv = *reinterpret_cast<const float4*>(Ms + 32 * kb + 8 * g + 4 * h);
         const float m4[4] = {mv.x, mv.y, mv.z, mv.w};
+        bool kp[4] = {true, true, true, true};
+        if (thresh) {
+          const uint4 hk4 = *reinterpret_cast<const uint4*>(Hk + 32 * kb + 8 * g + 4 * h);
+          kp[0] = attn_keep(hq1, hk4.x, thresh); kp[1] = attn_keep(hq1, hk4.y, thresh);
+          kp[2] = attn_keep(hq1, hk4.z, thresh); kp[3] = attn_keep(hq1, hk4.w, thresh);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int i = 4 * g + e;
           const float p = __expf(sa[i] * scale + m4[e] - lq);
           float dp = pa[i];
-          if (thresh) {
-            const int key = 32 * kb + acc_row(i, h);
-            dp = drop_keep(seed, ((uint64_t)bh * L + r0) * L + key, thresh) ? dp * keep_scale : 0.f;
-          }
+          if (thresh) dp = kp[e] ? dp * keep_scale : 0.f;
           sa[i] = p * (dp - dl) * scale;            // dS^T
         }
       }
@@ -268,6 +286,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
 #pragma unroll
     for (int s = 0; s < KS; ++s) { kf[s] = ld_row(Ks, RS, r0, 2 * s + h); vf[s] = ld_row(Vs, RS, r0, 2 * s + h); }
     const float mk = Ms[r0];
+    const uint32_t hk2 = Hk[r0];
     f32x16 dk[DB], dv[DB];
 #pragma unroll
     for (int db = 0; db < DB; ++db)
@@ -288,14 +307,15 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
         const float4 lv = *reinterpret_cast<const float4*>(Ls + 32 * qb + 8 * g + 4 * h);
         const float4 dv4 = *reinterpret_cast<const float4*>(Ds + 32 * qb + 8 * g + 4 * h);
         const float l4[4] = {lv.x, lv.y, lv.z, lv.w}, d4[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
+        const uint4 hq4 = *reinterpret_cast<const uint4*>(Hq + 32 * qb + 8 * g + 4 * h);
+        const uint32_t hqv[4] = {hq4.x, hq4.y, hq4.z, hq4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int i = 4 * g + e;
           const float p = __expf(sa[i] * scale + mk - l4[e]);
           float pd = p, dp = pa[i];
           if (thresh) {
-            const int qq = 32 * qb + acc_row(i, h);
-            const bool keep = drop_keep(seed, ((uint64_t)bh * L + qq) * L + r0, thresh);
+            const bool keep = attn_keep(hqv[e], hk2, thresh);
             pd = keep ? p * keep_scale : 0.f;
             dp = keep ? dp * keep_scale : 0.f;
           }
@@ -336,7 +356,7 @@ template <int D, int NW>
 static int launch_fwd(int B, int L, int nh, const void* qkv, const float* mask, float scale, float drop_p,
                       const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse, hipStream_t st) {
   constexpr int RS = D * 2 + 16, Lp = NW * 32;
-  const size_t smem = 2 * Lp * RS + Lp * sizeof(float);
+  const size_t smem = 2 * Lp * RS + 2 * Lp * sizeof(float);
   hipLaunchKernelGGL((attn_fwd_mfma_kernel<D, NW>), dim3(B * nh), dim3(NW * 64), smem, st, L, nh, (const bf16*)qkv, mask,
                      scale, drop_thresh(drop_p), 1.0f / (1.0f - drop_p), seed_ptr, seed_imm, (bf16*)ctx, lse);
   UC2_LAUNCH_CHECK();
@@ -347,7 +367,7 @@ static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, 
                       const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx, const void* dctx,
                       const float* lse, void* dqkv, hipStream_t st) {
   constexpr int RS = D * 2 + 16, Lp = NW * 32;
-  const size_t smem = 4 * Lp * RS + 3 * Lp * sizeof(float);
+  const size_t smem = 4 * Lp * RS + 5 * Lp * sizeof(float);
   auto kern = attn_bwd_mfma_kernel<D, NW>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -105,12 +105,49 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
-// returns true with probability (1 - p); thresh = p * 2^32 (clamped)
+// One hash serves FOUR consecutive indices: two mix32 rounds of the group index (idx >> 2) give 64 bits, element
+// (idx & 3) takes 16 of them and is kept when they are >= thresh >> 16 (drop probability resolved to 2^-16).
+// (The 32-bit integer multiplies of mix32 are quarter-rate; one hash per element made the LayerNorm kernels
+// VALU-bound at twice their memory time.)  thresh = p * 2^32 (clamped), see drop_thresh.
+__device__ __forceinline__ void drop_hash4(uint64_t seed, uint64_t group, uint32_t& r0, uint32_t& r1) {
+  const uint32_t lo = (uint32_t)group, hi = (uint32_t)(group >> 32);
+  r0 = mix32(lo ^ (uint32_t)seed);
+  r1 = mix32(r0 + hi * 0x9E3779B9U + (uint32_t)(seed >> 32));
+}
+// keep flags of indices idx4 .. idx4+3 (idx4 a multiple of 4)
+__device__ __forceinline__ void drop_keep4(uint64_t seed, uint64_t idx4, uint32_t thresh, bool (&keep)[4]) {
+  uint32_t r0, r1;
+  drop_hash4(seed, idx4 >> 2, r0, r1);
+  const uint32_t t16 = thresh >> 16;
+  keep[0] = (r0 & 0xffffu) >= t16; keep[1] = (r0 >> 16) >= t16;
+  keep[2] = (r1 & 0xffffu) >= t16; keep[3] = (r1 >> 16) >= t16;
+}
+// four consecutive indices from any start: one hash when the start is group-aligned (`aligned` is wave-uniform)
+__device__ __forceinline__ void drop_keep4_any(uint64_t seed, uint64_t idx, uint32_t thresh, bool aligned, bool (&keep)[4]);
+// returns true with probability (1 - p) for one index (same function as drop_keep4, element idx & 3)
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
-  uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-  uint32_t h = mix32(lo ^ (uint32_t)seed);
-  h = mix32(h + hi * 0x9E3779B9U + (uint32_t)(seed >> 32));
-  return h >= thresh;
+  uint32_t r0, r1;
+  drop_hash4(seed, idx >> 2, r0, r1);
+  const uint32_t r = (idx & 2) ? r1 : r0;
+  return (((idx & 1) ? (r >> 16) : (r & 0xffffu))) >= (thresh >> 16);
+}
+__device__ __forceinline__ void drop_keep4_any(uint64_t seed, uint64_t idx, uint32_t thresh, bool aligned, bool (&keep)[4]) {
+  if (aligned) { drop_keep4(seed, idx, thresh, keep); return; }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) keep[e] = drop_keep(seed, idx + e, thresh);
+}
+// Attention-probability dropout: keep(q, k) = light(Hq[q] ^ Hk[k]) with one fully mixed 32-bit hash per query row
+// and per key column of a (batch, head) -- L + L full hashes per head instead of L*L; the per-element part is one
+// multiply.  (The MFMA backward visits every element twice, once per orientation, and in one of them a lane's
+// elements are not index-contiguous, so a shared group hash does not help there.)
+__device__ __forceinline__ uint32_t attn_line_hash(uint64_t seed, uint32_t bh, uint32_t idx, uint32_t salt) {
+  const uint32_t h = mix32(idx ^ (uint32_t)seed ^ salt);
+  return mix32(h + bh * 0x9E3779B9U + (uint32_t)(seed >> 32));
+}
+#define UC2_ATTN_SALT_Q 0x00000000U
+#define UC2_ATTN_SALT_K 0x5bd1e995U
+__device__ __forceinline__ bool attn_keep(uint32_t hq, uint32_t hk, uint32_t thresh) {
+  return (((hq ^ hk) * 0x9E3779B1U) >> 16) >= (thresh >> 16);
 }
 static inline uint32_t drop_thresh(float p) {
   if (p <= 0.f) return 0u;

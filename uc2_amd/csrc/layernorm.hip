@@ -30,8 +30,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int H, const T* __re
       const size_t off = (size_t)row * H + c * 4;
       Vec4<T>::load(x + off, v[i]);
       if (thresh) {
+        bool kp4[4];
+        drop_keep4(seed, off, thresh, kp4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[i][e] = drop_keep(seed, off + e, thresh) ? v[i][e] * keep_scale : 0.f;
+        for (int e = 0; e < 4; ++e) v[i][e] = kp4[e] ? v[i][e] * keep_scale : 0.f;
       }
       if (res) {
         float r[4];
@@ -107,11 +109,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
 #pragma unroll
         for (int e = 0; e < 4; ++e) kp[i][e] = true;
         if (thresh) {
+          drop_keep4(seed, off, thresh, kp[i]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            kp[i][e] = drop_keep(seed, off + e, thresh);
-            xv[e] = kp[i][e] ? xv[e] * keep_scale : 0.f;
-          }
+          for (int e = 0; e < 4; ++e) xv[e] = kp[i][e] ? xv[e] * keep_scale : 0.f;
         }
         if (res) {
           float r[4];
