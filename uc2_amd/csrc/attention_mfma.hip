@@ -60,6 +60,30 @@ __device__ __forceinline__ void stage_tile(char* dst, const bf16* __restrict__ s
   }
 }
 
+// Register-staged variant (backward): a workgroup walks over several heads and fetches the NEXT head's tiles
+// into registers while it computes the current one, so the global-load latency (67 % of the wave time of the
+// one-head-per-workgroup version, rocprofv3 SQ_WAIT_ANY) is hidden behind the MFMA/softmax work.
+// Every thread owns NCH = Lp*CPR/nthr (= 4 for D = 64, 2 for D = 32) 16-byte chunks of each tile.
+template <int D, int NCH>
+__device__ __forceinline__ void load_tile_regs(bf16x8 (&r)[NCH], const bf16* __restrict__ src, int ld, int L, int tid, int nthr) {
+  constexpr int CPR = D / 8;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + i * nthr, row = c / CPR, c8 = c - row * CPR;
+    r[i] = zero8();
+    if (row < L) r[i] = *reinterpret_cast<const bf16x8*>(src + (size_t)row * ld + c8 * 8);
+  }
+}
+template <int D, int NCH>
+__device__ __forceinline__ void store_tile_regs(char* dst, const bf16x8 (&r)[NCH], int tid, int nthr) {
+  constexpr int RS = D * 2 + 16, CPR = D / 8;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + i * nthr, row = c / CPR, c8 = c - row * CPR;
+    *reinterpret_cast<bf16x8*>(dst + row * RS + c8 * 16) = r[i];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -175,7 +199,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
                                                                 uint64_t seed_imm, const bf16* __restrict__ ctx,
                                                                 const bf16* __restrict__ dctx,
                                                                 const float* __restrict__ lse,
-                                                                bf16* __restrict__ dqkv) {
+                                                                bf16* __restrict__ dqkv, int nbh, int hpw) {
   constexpr int KS = D / 16, DB = D / 32, RS = D * 2 + 16, Lp = NW * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qs = smem;
@@ -187,36 +211,55 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
   float* Ds = Ls + Lp;
   uint32_t* Hq = reinterpret_cast<uint32_t*>(Ds + Lp);          // per-query / per-key dropout hashes
   uint32_t* Hk = Hq + Lp;
-  const int bh = blockIdx.x, b = bh / nh, head = bh - b * nh;
   const int H = nh * D, ld = 3 * H;
   const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
-  const bf16* base = qkv + (size_t)b * L * ld + head * D;
-  const bf16* dob = dctx + (size_t)b * L * H + head * D;
-  const bf16* ob = ctx + (size_t)b * L * H + head * D;
-  bf16* dbase = dqkv + (size_t)b * L * ld + head * D;
   const int tid = threadIdx.x;
-  stage_tile<D>(Qs, base, ld, L, Lp, tid, NW * 64);
-  stage_tile<D>(Ks, base + H, ld, L, Lp, tid, NW * 64);
-  stage_tile<D>(Vs, base + 2 * H, ld, L, Lp, tid, NW * 64);
-  stage_tile<D>(Gs, dob, H, L, Lp, tid, NW * 64);
-  for (int k = tid; k < Lp; k += NW * 64) {
-    Ms[k] = (k < L) ? (mask ? mask[(size_t)b * L + k] : 0.f) : -1e30f;
-    Ls[k] = (k < L) ? lse[(size_t)bh * L + k] : 0.f;
-    float dl = 0.f;
-    if (k < L) {
-#pragma unroll
-      for (int d = 0; d < D; d += 8) {
-        const bf16x8 g = *reinterpret_cast<const bf16x8*>(dob + (size_t)k * H + d);
-        const bf16x8 o = *reinterpret_cast<const bf16x8*>(ob + (size_t)k * H + d);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dl += (float)g[e] * (float)o[e];
-      }
+  constexpr int NTHR = NW * 64, CPR = D / 8, NCH = Lp * CPR / NTHR;
+  const int bh_end = min(nbh, (int)(blockIdx.x + 1) * hpw);
+  int bh = blockIdx.x * hpw;
+  // ---- fetch of one head into registers: Q, K, V, dO, O tiles (NCH chunks each) + mask / lse of row tid
+  bf16x8 rq[NCH], rk[NCH], rv[NCH], rg[NCH], ro[NCH];
+  float rmask = 0.f, rlse = 0.f;
+  auto fetch = [&](int hd) __attribute__((always_inline)) {
+    const int fb = hd / nh, fh = hd - fb * nh;
+    const bf16* fbase = qkv + (size_t)fb * L * ld + fh * D;
+    load_tile_regs<D, NCH>(rq, fbase, ld, L, tid, NTHR);
+    load_tile_regs<D, NCH>(rk, fbase + H, ld, L, tid, NTHR);
+    load_tile_regs<D, NCH>(rv, fbase + 2 * H, ld, L, tid, NTHR);
+    load_tile_regs<D, NCH>(rg, dctx + (size_t)fb * L * H + fh * D, H, L, tid, NTHR);
+    load_tile_regs<D, NCH>(ro, ctx + (size_t)fb * L * H + fh * D, H, L, tid, NTHR);
+    if (tid < Lp && tid < L) {
+      rmask = mask ? mask[(size_t)fb * L + tid] : 0.f;
+      rlse = lse[(size_t)hd * L + tid];
     }
-    Ds[k] = dl;
-    Hq[k] = attn_line_hash(seed, bh, k, UC2_ATTN_SALT_Q);
-    Hk[k] = attn_line_hash(seed, bh, k, UC2_ATTN_SALT_K);
+  };
+  fetch(bh);
+  for (; bh < bh_end; ++bh) {
+  const int b = bh / nh, head = bh - b * nh;
+  bf16* dbase = dqkv + (size_t)b * L * ld + head * D;
+  // ---- registers -> LDS (the previous head's readers are past the barrier at the end of the loop body)
+  store_tile_regs<D, NCH>(Qs, rq, tid, NTHR);
+  store_tile_regs<D, NCH>(Ks, rk, tid, NTHR);
+  store_tile_regs<D, NCH>(Vs, rv, tid, NTHR);
+  store_tile_regs<D, NCH>(Gs, rg, tid, NTHR);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {                      // delta[row] = sum_d dO*O: 8 values per chunk, CPR consecutive lanes per row
+    float dl = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dl += (float)rg[i][e] * (float)ro[i][e];
+#pragma unroll
+    for (int o = 1; o < CPR; o <<= 1) dl += __shfl_xor(dl, o);
+    const int cidx = tid + i * NTHR, row = cidx / CPR;
+    if (cidx - row * CPR == 0) Ds[row] = dl;
+  }
+  if (tid < Lp) {
+    Ms[tid] = (tid < L) ? rmask : -1e30f;
+    Ls[tid] = (tid < L) ? rlse : 0.f;
+    Hq[tid] = attn_line_hash(seed, bh, tid, UC2_ATTN_SALT_Q);
+    Hk[tid] = attn_line_hash(seed, bh, tid, UC2_ATTN_SALT_K);
   }
   __syncthreads();
+  if (bh + 1 < bh_end) fetch(bh + 1);                  // in flight during the compute below
 
   const int w = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
   const int r0 = 32 * w + c;               // this lane's query (orientation 1) and key (orientation 2)
@@ -345,6 +388,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
         }
     }
   }
+  __syncthreads();                                     // every wave is done with this head's LDS tiles
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -373,9 +418,11 @@ static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, 
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { uc2_set_error(__FILE__, __LINE__, hipGetErrorString(e)); return (int)e; }
   }
-  hipLaunchKernelGGL(kern, dim3(B * nh), dim3(NW * 64), smem, st, L, nh, (const bf16*)qkv, mask, scale,
+  const int nbh = B * nh;
+  const int hpw = nbh >= 4096 ? 4 : (nbh >= 1024 ? 2 : 1);       // heads per workgroup (next head prefetched into registers)
+  hipLaunchKernelGGL(kern, dim3((nbh + hpw - 1) / hpw), dim3(NW * 64), smem, st, L, nh, (const bf16*)qkv, mask, scale,
                      drop_thresh(drop_p), 1.0f / (1.0f - drop_p), seed_ptr, seed_imm, (const bf16*)ctx,
-                     (const bf16*)dctx, lse, (bf16*)dqkv);
+                     (const bf16*)dctx, lse, (bf16*)dqkv, nbh, hpw);
   UC2_LAUNCH_CHECK();
   return 0;
 }
