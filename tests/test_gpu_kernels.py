@@ -395,3 +395,23 @@ def test_gemm_pingpong_persistent():
         lib.uc2_gemm_force_generic(0)
         lib.uc2_gemm_set_variant(-2)
     assert rel_err(o, r) < 1e-4
+
+
+@pytest.mark.parametrize("variant", [8, 7, 99])
+def test_gemm_dgelu_fused_colsum(variant):
+    """EPI_DGELU with aux_out: the column sums of the result (bias gradient) come with the GEMM -- fused in the
+    ping-pong kernel's epilogue, a second pass for the others; both must match an explicit column sum"""
+    lib = ops._lib.load()
+    M, N, K = 1024, 512, 768
+    dy = rnd((M, K), 1, dtype=torch.bfloat16)
+    w = rnd((K, N), 2, 0.05, dtype=torch.bfloat16)
+    pre = rnd((M, N), 3, dtype=torch.bfloat16)
+    acc = rnd((N,), 4)
+    got = acc.clone()
+    try:
+        lib.uc2_gemm_set_variant(variant)
+        out = ops.gemm(dy, w, M, N, K, tb=True, epi=ops.EPI_DGELU, aux_in=pre, aux_out=got)
+    finally:
+        lib.uc2_gemm_set_variant(-2)
+    want = acc + out.float().sum(0)
+    assert rel_err(got, want) < 2e-3

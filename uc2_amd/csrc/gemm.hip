@@ -263,6 +263,7 @@ static void launch_bf16(const GemmArgs& p, hipStream_t st) {
 }
 
 int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st);   // gemm_fast.hip
+extern "C" int uc2_colsum_accum(int dtype, int M, int N, const void* X, int ldx, const uint8_t* rowmask, float* out, void* stream);   // elementwise.hip
 static int g_force_generic = -1;
 // 1 = always use the generic register-staged kernel (A/B tests), 0 = prefer the pipelined one
 extern "C" int uc2_gemm_force_generic(int v) { g_force_generic = v ? 1 : 0; return 0; }
@@ -340,12 +341,20 @@ extern "C" int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K
     else launch_f32<true, true>(p, st);
   } else {
     if (g_force_generic < 0) { const char* e = getenv("UC2_GEMM_GENERIC"); g_force_generic = (e && e[0] == '1') ? 1 : 0; }
-    if (!g_force_generic && uc2_gemm_bf16_fast_try(p, trans_a, trans_b, st)) { UC2_LAUNCH_CHECK(); return 0; }
+    const bool want_colsum = (epilogue == EPI_DGELU && aux_out != nullptr);
+    const int fast = g_force_generic ? 0 : uc2_gemm_bf16_fast_try(p, trans_a, trans_b, st);
+    if (fast) {
+      UC2_LAUNCH_CHECK();
+      if (want_colsum && fast != 2) return uc2_colsum_accum(1, M, N, C, ldc, nullptr, reinterpret_cast<float*>(aux_out), stream);
+      return 0;
+    }
     if (!trans_a && !trans_b) launch_bf16<false, false>(p, st);
     else if (!trans_a && trans_b) launch_bf16<false, true>(p, st);
     else if (trans_a && !trans_b) launch_bf16<true, false>(p, st);
     else launch_bf16<true, true>(p, st);
   }
   UC2_LAUNCH_CHECK();
+  if (epilogue == EPI_DGELU && aux_out != nullptr)      // kernels without the fused column sums: one more pass over C
+    return uc2_colsum_accum(dtype, M, N, C, ldc, nullptr, reinterpret_cast<float*>(aux_out), stream);
   return 0;
 }

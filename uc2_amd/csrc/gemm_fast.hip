@@ -379,7 +379,7 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
     } else {
       uc2_gemm_pp_launch(pd, trans_a, trans_b, st);
     }
-    return 1;
+    return 2;                                         // (2: the kernel also produced the EPI_DGELU column sums)
   }
 #define GF_GO(TA_, TB_) do { if (tacc) gf_launch2<TA_, TB_, true>(pd, variant, st); else gf_launch2<TA_, TB_, false>(pd, variant, st); } while (0)
   if (!trans_a && !trans_b) GF_GO(false, false);

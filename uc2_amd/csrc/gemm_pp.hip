@@ -89,6 +89,23 @@ template <bool TR, int S> __device__ __forceinline__ void pp_read(bf16x8& dst, u
 //   pp_epi_store  : the stores only; full tiles, so their number is a compile-time function of the epilogue kind.
 // Layout after the exchange (v_permlane32_swap, see gemm_common.h): lane (row m, half h) holds columns
 // 32j + 16g + 8h .. +7 of the wave's 64 for j, g in {0,1}.
+// Column sums across the 32 lanes of a lane half, 32 partial sums per lane (index v) -> lane (c31, h) returns the
+// total of v = c31.  Transposing butterfly: at step k a lane keeps the half of its values whose bit (4-k) of v
+// matches its own lane bit and adds the partner's copies of those -- 31 exchanges instead of 5 x 32.
+__device__ __forceinline__ float colsum_butterfly32(float (&v)[32], int lane) {
+#pragma unroll
+  for (int half = 16; half >= 1; half >>= 1) {
+    const bool up = (lane & half) != 0;
+#pragma unroll
+    for (int i = 0; i < half; ++i) {
+      const float lo = v[i], hi = v[i + half];
+      const float keep = up ? hi : lo, send = up ? lo : hi;
+      v[i] = keep + __shfl_xor(send, half);
+    }
+  }
+  return v[0];
+}
+
 struct PpOut {
   bf16x8 o[2][2][2][2];       // [A half][i][j][g]
   bf16x8 pre[2][2][2][2];     // pre-activation values (EPI_GELU with aux_out)
@@ -99,6 +116,12 @@ __device__ __forceinline__ void pp_epi_compute(const GemmArgs& p, const f32x16 (
                                                int lane) {
   const int h = lane >> 5, c31 = lane & 31;
   constexpr bool has_aux = (EPI == EPI_DGELU || EPI == EPI_ADD);
+  // EPI_DGELU: aux_out (fp32 [N]) += column sums of the result = bias gradient of the layer whose pre-activation
+  // gradient this GEMM produces (saves a separate pass over the M x N result)
+  const bool want_cs = (EPI == EPI_DGELU) && p.aux_out != nullptr;
+  float cs[32];
+#pragma unroll
+  for (int v = 0; v < 32; ++v) cs[v] = 0.f;
   bf16x8 ax[2][2][2][2];
   if (has_aux) {
 #pragma unroll
@@ -139,6 +162,10 @@ __device__ __forceinline__ void pp_epi_compute(const GemmArgs& p, const f32x16 (
           } else if (EPI == EPI_DGELU) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= dgelu_bf((float)ax[hh][i][j][g][e]);
+            if (want_cs) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) cs[16 * j + 8 * g + e] += v[e];
+            }
           } else if (EPI == EPI_ADD) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += (float)ax[hh][i][j][g][e];
@@ -151,6 +178,13 @@ __device__ __forceinline__ void pp_epi_compute(const GemmArgs& p, const f32x16 (
           for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
           out.o[hh][i][j][g] = o;
         }
+  if (EPI == EPI_DGELU) {
+    if (want_cs) {                                     // (wave-uniform) one 64-lane atomic per wave and tile
+      const float tot = colsum_butterfly32(cs, lane);
+      const int vv = c31;                              // value index v = 16 j + 8 g + e  ->  column 32 j + 16 g + 8 h + e
+      atomicAdd(reinterpret_cast<float*>(p.aux_out) + nb + 32 * (vv >> 4) + 16 * ((vv >> 3) & 1) + 8 * h + (vv & 7), tot);
+    }
+  }
 }
 
 template <int EPI>

@@ -106,7 +106,7 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
     ldc = ldc if ldc is not None else out.stride(0)
     ldaux = 0
     for x in (aux_in, aux_out):
-        if x is not None:
+        if x is not None and x.dim() == 2:
             ldaux = x.stride(0)
     two_stage = False
     if _CUR_VARIANT == 8 and c_f32 and split_k > 1:
@@ -271,11 +271,14 @@ def linear_fwd(x2, w, bias, epi=EPI_NONE, aux_out=None):
     return _gemm_planned(x2, w, M, N, K, False, False, bias=bias, epi=epi, aux_out=aux_out)
 
 
-def linear_dgrad(dy2, w, epi=EPI_NONE, aux_in=None):
-    """dX[M,K] = dY[M,N] @ W[N,K]  (W in nn.Linear layout)"""
+def linear_dgrad(dy2, w, epi=EPI_NONE, aux_in=None, colsum_out=None):
+    """dX[M,K] = epi(dY[M,N] @ W[N,K])  (W in nn.Linear layout).  With EPI_DGELU, colsum_out (fp32 [K]) += column sums
+    of dX = the bias gradient of the layer below (fused into the GEMM epilogue where the kernel supports it)."""
     M, N = dy2.shape
     K = w.shape[1]
-    return _gemm_planned(dy2, w, M, K, N, False, True, epi=epi, aux_in=aux_in)
+    if colsum_out is not None and epi != EPI_DGELU:
+        raise _lib.Uc2Error("colsum_out needs EPI_DGELU")
+    return _gemm_planned(dy2, w, M, K, N, False, True, epi=epi, aux_in=aux_in, aux_out=colsum_out)
 
 
 def _linear_wgrad_now(dy2, x2, dw, db):
@@ -477,8 +480,8 @@ class BertLayerFn(torch.autograd.Function):
         d_o2, dz2 = ln_bwd(dy2, o2, a, P["g2"].data, mean2, rstd2, G(P["g2"]), G(P["b2"]), p_h, seed, sid + 3,
                            dbias=G(P["fb"]))
         linear_wgrad(d_o2, u, G(P["fw"]), None)
-        d_pre = linear_dgrad(d_o2, st.compute(P["fw"], dtype), EPI_DGELU, pre)
-        linear_wgrad(d_pre, a, G(P["iw"]), G(P["ib"]))
+        d_pre = linear_dgrad(d_o2, st.compute(P["fw"], dtype), EPI_DGELU, pre, colsum_out=G(P["ib"]))   # + d(intermediate bias)
+        linear_wgrad(d_pre, a, G(P["iw"]), None)
         da = linear_dgrad(d_pre, st.compute(P["iw"], dtype), EPI_ADD, dz2)
         # LN1, output projection, attention, fused QKV
         d_o1, dz1 = ln_bwd(da, o1, x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, sid + 2,
