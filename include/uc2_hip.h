@@ -79,7 +79,7 @@ int uc2_attn_fwd(int dtype, int impl, int B, int L, int nh, int D, const void* q
                  float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse, void* stream);
 int uc2_attn_bwd(int dtype, int impl, int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
                  float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx, const void* dctx,
-                 const float* lse, void* dqkv, void* stream);
+                 const float* lse, void* dqkv, float* dbias_qkv, void* stream);
 int uc2_attn_mfma_supported(int L, int D);
 /* head-averaged attention probabilities out[B, L, L] (MultiheadAttention need_weights, model/attention.py:255-260) */
 int uc2_attn_probs_mean(int dtype, int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,

@@ -415,3 +415,20 @@ def test_gemm_dgelu_fused_colsum(variant):
         lib.uc2_gemm_set_variant(-2)
     want = acc + out.float().sum(0)
     assert rel_err(got, want) < 2e-3
+
+
+@pytest.mark.parametrize("impl,dtype", [(2, torch.bfloat16), (1, torch.bfloat16), (1, torch.float32)])
+@pytest.mark.parametrize("B,L,nh,D", [(3, 96, 12, 64), (2, 70, 4, 32)])
+def test_attention_bwd_fused_bias_grad(impl, dtype, B, L, nh, D):
+    """uc2_attn_bwd with dbias_qkv: += column sums of dqkv (padded rows of the MFMA tiles must not leak in)"""
+    H = nh * D
+    qkv = rnd((B * L, 3 * H), 1, 0.7, dtype=dtype)
+    mask = torch.zeros(B, L, device=DEV)
+    mask[0, L - 5:] = -10000.0
+    dctx = rnd((B * L, H), 2, dtype=dtype)
+    ctx, lse = ops.attn_fwd(qkv, mask, B, L, nh, D, impl=impl)
+    acc = rnd((3 * H,), 3)
+    got = acc.clone()
+    dqkv = ops.attn_bwd(qkv, mask, ctx, dctx, lse, B, L, nh, D, impl=impl, dbias=got)
+    want = acc + dqkv.float().sum(0)
+    assert rel_err(got, want) < (1e-5 if dtype == torch.float32 else 3e-3)

@@ -32,7 +32,7 @@ SIGNATURES = {
     "uc2_ln_bwd_workspace": (SZ, [I, I]),
     "uc2_ln_bwd": (I, [I, I, I, P, P, P, P, P, P, F, P, U64, P, P, P, P, P, P, P]),
     "uc2_attn_fwd": (I, [I, I, I, I, I, I, P, P, F, F, P, U64, P, P, P]),
-    "uc2_attn_bwd": (I, [I, I, I, I, I, I, P, P, F, F, P, U64, P, P, P, P, P]),
+    "uc2_attn_bwd": (I, [I, I, I, I, I, I, P, P, F, F, P, U64, P, P, P, P, P, P]),
     "uc2_attn_mfma_supported": (I, [I, I]),
     "uc2_attn_probs_mean": (I, [I, I, I, I, I, P, P, F, P, P]),
     "uc2_position_ids": (I, [I, I, P, I64, P, P]),

@@ -45,6 +45,39 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {   // registers
   for (int j = 0; j < 8; ++j) r[j] = (bf16)a[8 * s + j];
   return r;
 }
+// Column sums across the 32 lanes of a lane half, 32 partial sums per lane (index v): lane (c, h) returns the total
+// of v = c (transposing butterfly, 31 exchanges; same helper as in gemm_pp.hip)
+__device__ __forceinline__ float colsum_butterfly32(float (&v)[32], int lane) {
+#pragma unroll
+  for (int half = 16; half >= 1; half >>= 1) {
+    const bool up = (lane & half) != 0;
+#pragma unroll
+    for (int i = 0; i < half; ++i) {
+      const float lo = v[i], hi = v[i + half];
+      const float keep = up ? hi : lo, send = up ? lo : hi;
+      v[i] = keep + __shfl_xor(send, half);
+    }
+  }
+  return v[0];
+}
+// bias-gradient contribution of one wave's 32 rows x D columns held as DB transposed accumulators (register 4g+e of
+// block db = column 32db + 8g + 4h + e of row r0): dst[col] += sum over the wave's valid rows (D = 64: one atomic
+// per lane; D = 32: the 16 values per lane are padded to the 32-value butterfly)
+template <int DB>
+__device__ __forceinline__ void acc_colsum_atomic(const f32x16 (&a)[DB], bool row_ok, float* __restrict__ dst, int lane) {
+  float v[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) v[i] = 0.f;
+  if (row_ok) {
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[16 * db + r] = a[db][r];
+  }
+  const float tot = colsum_butterfly32(v, lane);
+  const int c = lane & 31, h = lane >> 5, db = c >> 4, r = c & 15;
+  if (db < DB) atomicAdd(dst + 32 * db + 8 * (r >> 2) + 4 * h + (r & 3), tot);
+}
 // row of accumulator register i for lane half h
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
@@ -199,7 +232,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
                                                                 uint64_t seed_imm, const bf16* __restrict__ ctx,
                                                                 const bf16* __restrict__ dctx,
                                                                 const float* __restrict__ lse,
-                                                                bf16* __restrict__ dqkv, int nbh, int hpw) {
+                                                                bf16* __restrict__ dqkv, float* __restrict__ dbias, int nbh, int hpw) {
   constexpr int KS = D / 16, DB = D / 32, RS = D * 2 + 16, Lp = NW * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qs = smem;
@@ -312,6 +345,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
           dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr(Ks, RS, 32 * kb + 16 * s, 32 * db, lane),
                                                            pack8(sa, s), dq[db], 0, 0, 0);
     }
+    if (dbias) acc_colsum_atomic<DB>(dq, r0 < L, dbias + head * D, lane);       // d(query bias)
     if (r0 < L) {
 #pragma unroll
       for (int db = 0; db < DB; ++db)
@@ -376,6 +410,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
                                                            pack8(sa, s), dk[db], 0, 0, 0);
         }
     }
+    if (dbias) {                                                               // d(key bias), d(value bias)
+      acc_colsum_atomic<DB>(dk, r0 < L, dbias + H + head * D, lane);
+      acc_colsum_atomic<DB>(dv, r0 < L, dbias + 2 * H + head * D, lane);
+    }
     if (r0 < L) {
 #pragma unroll
       for (int db = 0; db < DB; ++db)
@@ -410,7 +448,7 @@ static int launch_fwd(int B, int L, int nh, const void* qkv, const float* mask, 
 template <int D, int NW>
 static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, float scale, float drop_p,
                       const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx, const void* dctx,
-                      const float* lse, void* dqkv, hipStream_t st) {
+                      const float* lse, void* dqkv, float* dbias, hipStream_t st) {
   constexpr int RS = D * 2 + 16, Lp = NW * 32;
   const size_t smem = 4 * Lp * RS + 5 * Lp * sizeof(float);
   auto kern = attn_bwd_mfma_kernel<D, NW>;
@@ -422,7 +460,7 @@ static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, 
   const int hpw = nbh >= 4096 ? 4 : (nbh >= 1024 ? 2 : 1);       // heads per workgroup (next head prefetched into registers)
   hipLaunchKernelGGL(kern, dim3((nbh + hpw - 1) / hpw), dim3(NW * 64), smem, st, L, nh, (const bf16*)qkv, mask, scale,
                      drop_thresh(drop_p), 1.0f / (1.0f - drop_p), seed_ptr, seed_imm, (const bf16*)ctx,
-                     (const bf16*)dctx, lse, (bf16*)dqkv, nbh, hpw);
+                     (const bf16*)dctx, lse, (bf16*)dqkv, dbias, nbh, hpw);
   UC2_LAUNCH_CHECK();
   return 0;
 }
@@ -463,12 +501,12 @@ extern "C" int uc2_attn_fwd_mfma(int B, int L, int nh, int D, const void* qkv, c
 
 extern "C" int uc2_attn_bwd_mfma(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
                                  float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx,
-                                 const void* dctx, const float* lse, void* dqkv, void* stream) {
+                                 const void* dctx, const float* lse, void* dqkv, float* dbias, void* stream) {
   UC2_CHECK_ARG(uc2_attn_mfma_supported(L, D));
   UC2_CHECK_ARG(B >= 0 && nh >= 1 && drop_p >= 0.f && drop_p < 1.f);
   UC2_CHECK_ARG(((nh * D) % 8) == 0);
   if (B == 0) return 0;
   UC2_CHECK_ARG(qkv && ctx && dctx && lse && dqkv);
   hipStream_t st = (hipStream_t)stream;
-  AM_DISPATCH(launch_bwd, B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv, st);
+  AM_DISPATCH(launch_bwd, B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv, dbias, st);
 }

@@ -377,10 +377,11 @@ def attn_fwd(qkv, mask2d, B, L, nh, D, drop_p=0.0, seed=None, seed_imm=0, impl=N
     return ctx, lse
 
 
-def attn_bwd(qkv, mask2d, ctx, dctx, lse, B, L, nh, D, drop_p=0.0, seed=None, seed_imm=0, impl=None):
+def attn_bwd(qkv, mask2d, ctx, dctx, lse, B, L, nh, D, drop_p=0.0, seed=None, seed_imm=0, impl=None, dbias=None):
+    """dqkv; with dbias (fp32 [3H]) also dbias += column sums of dqkv = the gradient of the fused q|k|v bias"""
     dqkv = torch.empty_like(qkv)
     call("uc2_attn_bwd", dt(qkv.dtype), ATTN_IMPL if impl is None else impl, B, L, nh, D, ptr(qkv), ptr(mask2d),
-         1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), stream())
+         1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(dbias), stream())
     return dqkv
 
 
@@ -488,10 +489,10 @@ class BertLayerFn(torch.autograd.Function):
                            dbias=G(P["ob"]))
         linear_wgrad(d_o1, ctxv, G(P["ow"]), None)
         dctx = linear_dgrad(d_o1, st.compute(P["ow"], dtype))
-        dqkv = attn_bwd(qkv, mask2d, ctxv, dctx, lse, B, L, nh, D, p_a, seed, sid + 1)
         dwqkv = st.grad_span(P["qw"], P["vw"], (3 * H, H))
         dbqkv = st.grad_span(P["qb"], P["vb"], (3 * H,))
-        linear_wgrad(dqkv, x2, dwqkv, dbqkv)
+        dqkv = attn_bwd(qkv, mask2d, ctxv, dctx, lse, B, L, nh, D, p_a, seed, sid + 1, dbias=dbqkv)   # + d(q|k|v bias)
+        linear_wgrad(dqkv, x2, dwqkv, None)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = linear_dgrad(dqkv, st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype), EPI_ADD, dz1).view(B, L, H)
