@@ -248,7 +248,7 @@ def main():
                        "pairs_per_gpu_per_step": a.batch, "global_batch": a.batch * world,
                        "seq_len": T_TXT + N_REG, "parallelism": "dp%d" % world, "final_loss": round(lossv, 4), "replicas_in_sync": in_sync,
                        "gemm_plans": {"%s%s %dx%dx%d" % ("T" if k[0] else "N", "T" if k[1] else "N", k[2], k[3], k[4]):
-                                      "%s split %d" % ("generic" if v[0] == 99 else "ring v%d" % v[0], v[1])
+                                      "%s split %d" % ("generic" if v[0] == 99 else "ping-pong" if v[0] == 8 else "ring v%d" % v[0], v[1])
                                       for k, v in sorted(ops._TUNE.items())}},
             "mfma_frac_encoder": round(value * ENC_GFLOP_PER_PAIR * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": {"bound": "mfma", "kernel": kname,

@@ -491,8 +491,10 @@ class BertLayerFn(torch.autograd.Function):
         dctx = linear_dgrad(d_o1, st.compute(P["ow"], dtype))
         dwqkv = st.grad_span(P["qw"], P["vw"], (3 * H, H))
         dbqkv = st.grad_span(P["qb"], P["vb"], (3 * H,))
-        dqkv = attn_bwd(qkv, mask2d, ctxv, dctx, lse, B, L, nh, D, p_a, seed, sid + 1, dbias=dbqkv)   # + d(q|k|v bias)
-        linear_wgrad(dqkv, x2, dwqkv, None)
+        # (attn_bwd can also produce d(q|k|v bias) itself, dbias=dbqkv, but its 2304 atomic targets are shared by every
+        #  batch element: measured +65 us per call against 45 us for the separate column-sum pass)
+        dqkv = attn_bwd(qkv, mask2d, ctxv, dctx, lse, B, L, nh, D, p_a, seed, sid + 1)
+        linear_wgrad(dqkv, x2, dwqkv, dbqkv)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = linear_dgrad(dqkv, st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype), EPI_ADD, dz1).view(B, L, H)
