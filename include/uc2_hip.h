@@ -41,7 +41,8 @@ int uc2_device_info(int* cu_count, int* clock_khz, char* arch, int arch_len);
  *   C[M,N] (=|+=) epi( sum_k A(m,k) * B(n,k) + bias[n] )
  *   A(m,k) = A[m*lda+k] (trans_a=0) or A[k*lda+m] (trans_a=1);  B(n,k) = B[n*ldb+k] (trans_b=0) or B[k*ldb+n]
  *   forward Y = X W^T: (0,0); input gradient dX = dY W: (0,1); weight gradient dW += dY^T X: (1,1), accumulate,
- *   split_k > 1 reduces with fp32 atomics.  epilogue: GELU (erf form, optional pre-activation to aux_out),
+ *   split_k > 1 reduces with fp32 atomics.  epilogue: GELU (erf form in fp32; the bf16 kernels evaluate Phi(x) by a sigmoid-polynomial fit,
+ *   |GELU error| <= 3e-5, below bf16 resolution; optional pre-activation to aux_out),
  *   DGELU (multiply by gelu'(aux_in); optional aux_out = fp32 [N] += column sums of the result, i.e. the bias
  *   gradient of the layer whose pre-activation gradient this is), ADD (+ aux_in), TANH.  c_is_f32: fp32 output for bf16 inputs. */
 int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
