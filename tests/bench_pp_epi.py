@@ -21,7 +21,7 @@ def main():
         fn = lambda: ops.gemm(a, b, M, n, k, tb=tb, out=out, bias=bias, epi=epi,
                               aux_in=aux if epi in (ops.EPI_ADD, ops.EPI_DGELU) else None, aux_out=pre)
         row = []
-        for v in (8, 7, 2):
+        for v in (8, 9, 7, 2):
             lib.uc2_gemm_set_variant(v)
             row.append("v%d %6.1f" % (v, 2.0 * M * n * k / timeit(fn) / 1e12))
         lib.uc2_gemm_set_variant(-2)

@@ -432,3 +432,28 @@ def test_attention_bwd_fused_bias_grad(impl, dtype, B, L, nh, D):
     dqkv = ops.attn_bwd(qkv, mask, ctx, dctx, lse, B, L, nh, D, impl=impl, dbias=got)
     want = acc + dqkv.float().sum(0)
     assert rel_err(got, want) < (1e-5 if dtype == torch.float32 else 3e-3)
+
+
+@pytest.mark.parametrize("tb,epi", [(False, "none"), (True, "none"), (True, "add")])
+@pytest.mark.parametrize("M,N,K", [(768, 768, 768), (1536, 256, 3072), (49152 // 4, 768, 768)])
+def test_gemm_pingpong_192_row_tiles(tb, epi, M, N, K):
+    """variant 9 (192-row tiles, 7 LDS-DMA instructions per k-tile): against the generic kernel, twice (race screen)"""
+    lib = ops._lib.load()
+    a = rnd((M, K), 1, dtype=torch.bfloat16)
+    b = rnd((K, N) if tb else (N, K), 2, 0.05, dtype=torch.bfloat16)
+    bias = None if tb else rnd((N,), 3)
+    aux = rnd((M, N), 4, dtype=torch.bfloat16) if epi == "add" else None
+    code = ops.EPI_ADD if epi == "add" else ops.EPI_NONE
+    run = lambda: ops.gemm(a, b, M, N, K, tb=tb, bias=bias, epi=code, aux_in=aux)
+    try:
+        lib.uc2_gemm_force_generic(1)
+        ref = run()
+        lib.uc2_gemm_force_generic(0)
+        lib.uc2_gemm_set_variant(9)
+        o1 = run()
+        o2 = run()
+    finally:
+        lib.uc2_gemm_force_generic(0)
+        lib.uc2_gemm_set_variant(-2)
+    assert torch.equal(o1, o2)
+    assert rel_err(o1.float(), ref.float()) < 3e-3

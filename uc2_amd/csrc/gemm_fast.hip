@@ -311,8 +311,8 @@ static void ws_launch1(const GemmArgs& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(nwg, 1, p.split_k), dim3(512 + NWL * 64), smem, st, p);
 }
 
-bool uc2_gemm_pp_supported(int trans_a, int trans_b, int c_f32, int epi);                       // gemm_pp.hip
-void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st);
+bool uc2_gemm_pp_supported(int trans_a, int trans_b, int c_f32, int epi, int tile_rows);        // gemm_pp.hip
+void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st, int tile_rows);
 void uc2_splitk_reduce(const GemmArgs& p, hipStream_t st);                                        // gemm.hip
 extern float* g_splitk_ws;
 extern size_t g_splitk_ws_bytes;
@@ -355,13 +355,14 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
   if (g_variant == -1) { const char* e = getenv("UC2_GEMM_VARIANT"); g_variant = e ? atoi(e) : -2; }
   int variant = g_variant;
   if (variant == 99) return 0;                       // caller asked for the generic kernel
-  if (variant == 8) {
-    // ping-pong kernel: whole 256x256 tiles, >= 2 k-tiles per split, and (bf16 output) an epilogue made of whole
-    // 16-byte accesses; anything else runs on the ring kernels above / the generic kernel
+  if (variant == 8 || variant == 9) {
+    // ping-pong kernel: whole 256x256 (variant 9: 192x256) tiles, >= 2 k-tiles per split, and (bf16 output) an epilogue
+    // made of whole 16-byte accesses; anything else runs on the ring kernels above / the generic kernel
+    const int rows = variant == 9 ? 192 : 256;
     const int per = (p.K / 64 + p.split_k - 1) / p.split_k;
     if (per < 2 || (p.K / 64) - (p.split_k - 1) * per < 2) return 0;
-    if ((p.M & 255) || (p.N & 255)) return 0;
-    if (!uc2_gemm_pp_supported(trans_a, trans_b, p.c_f32, p.epi)) return 0;
+    if ((p.M % rows) || (p.N & 255)) return 0;
+    if (!uc2_gemm_pp_supported(trans_a, trans_b, p.c_f32, p.epi, rows)) return 0;
     if (!p.c_f32 && (p.accumulate || (p.ldc & 7) || (p.ldaux & 7) || ((uintptr_t)p.C & 15) ||
                      ((uintptr_t)p.aux_in & 15) || ((uintptr_t)p.aux_out & 15) || ((uintptr_t)p.bias & 15)))
       return 0;
@@ -369,15 +370,16 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
   const bool tacc = !(p.c_f32 && p.atomic);
   GemmArgs pd = p;
   if (g_fetch_only) pd.atomic |= (g_fetch_only << 8);
+  if (variant == 9) { uc2_gemm_pp_launch(pd, trans_a, trans_b, st, 192); return 2; }
   if (variant == 8) {
     const size_t need = (size_t)p.split_k * p.M * p.N * sizeof(float);
     if (p.c_f32 && p.split_k > 1 && g_splitk_ws && need <= g_splitk_ws_bytes && (p.N & 3) == 0 && (p.ldc & 3) == 0 &&
         ((uintptr_t)p.C & 15) == 0) {
       pd.partial = g_splitk_ws;                      // two-stage: plain partial stores, then one reduction pass
-      uc2_gemm_pp_launch(pd, trans_a, trans_b, st);
+      uc2_gemm_pp_launch(pd, trans_a, trans_b, st, 256);
       if (!g_splitk_defer) uc2_splitk_reduce(pd, st);
     } else {
-      uc2_gemm_pp_launch(pd, trans_a, trans_b, st);
+      uc2_gemm_pp_launch(pd, trans_a, trans_b, st, 256);
     }
     return 2;                                         // (2: the kernel also produced the EPI_DGELU column sums)
   }

@@ -21,6 +21,10 @@
 // L section retires exactly the units the next phase reads (all but the 4 youngest units), and the barrier
 // that follows publishes them to the other waves.
 //
+// HI = 1 variant: tiles of 192 rows (96 per wave row: A0 = 64 rows, A1 = 32).  The N = 768 GEMMs of the encoder have
+// 576 tiles of 256 rows on 256 CUs (2.25 rounds, the last a quarter full); with 192 rows they are 768 = three full
+// rounds.  Unit A1 is then 8 KiB (one LDS-DMA per wave, 7 per k-tile instead of 8) and phases 2, 3 run 4 MFMAs.
+//
 // The kernel is persistent: one workgroup per CU walks over (output tile, k-split) work items.  The epilogue
 // stores straight from the accumulator registers (gemm_common.h, bf16_tile_epilogue_direct), so the LDS ring is
 // free as soon as the main loop ends: the next item's first six units are issued BEFORE the epilogue's stores
@@ -29,24 +33,25 @@
 // ------------------------------------------------------------------------------------------------------
 #define PP_UNIT 16384
 
-template <int J> __device__ __forceinline__ int pp_map(int ur) {     // unit row -> row/column of the 256-wide tile
-  if (J == 0 || J == 3) return (ur >> 6) * 128 + (J == 3 ? 64 : 0) + (ur & 63);
+template <int J, int HI> __device__ __forceinline__ int pp_map(int ur) {     // unit row -> row/column of the tile
+  if (J == 0) return (ur >> 6) * (64 + 32 * HI) + (ur & 63);                        // A0: 64 rows per wave row
+  else if (J == 3) return HI == 2 ? (ur >> 6) * 128 + 64 + (ur & 63) : (ur >> 5) * 96 + 64 + (ur & 31);   // A1: 32*HI rows per wave row
   else return (ur >> 5) * 64 + (J == 2 ? 32 : 0) + (ur & 31);
 }
 
 // per-lane source of wave-instruction wi (0..15) of a unit; same LDS images and swizzles as gf_src<TR,128,64>
-template <bool TR, int J>
+template <bool TR, int J, int HI>
 __device__ __forceinline__ const bf16* pp_src(const bf16* __restrict__ X, int ld, int rows, int r0, int kbeg, int wi,
                                               int l) {
   if (!TR) {
     const int row = wi * 8 + (l >> 3), cp = l & 7;
     const int c = cp ^ ((row >> 1) & 7);
-    const int gr = min(r0 + pp_map<J>(row), rows - 1);
+    const int gr = min(r0 + pp_map<J, HI>(row), rows - 1);
     return X + (size_t)gr * ld + kbeg + c * 8;
   } else {
     const int krow = wi * 4 + (l >> 4), cp = l & 15;
     const int c = cp ^ ((krow & 3) << 2);
-    const int col = min(r0 + pp_map<J>(c * 8), rows - 8);
+    const int col = min(r0 + pp_map<J, HI>(c * 8), rows - 8);
     return X + (size_t)(kbeg + krow) * ld + col;
   }
 }
@@ -111,7 +116,7 @@ struct PpOut {
   bf16x8 pre[2][2][2][2];     // pre-activation values (EPI_GELU with aux_out)
 };
 
-template <int EPI>
+template <int EPI, int HI>
 __device__ __forceinline__ void pp_epi_compute(const GemmArgs& p, const f32x16 (&acc)[2][2][2], PpOut& out, int mb0, int nb,
                                                int lane) {
   const int h = lane >> 5, c31 = lane & 31;
@@ -132,6 +137,7 @@ __device__ __forceinline__ void pp_epi_compute(const GemmArgs& p, const f32x16 (
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int g = 0; g < 2; ++g) {
+            if (hh == 1 && i >= HI) continue;
             const int m = mb0 + hh * 64 + i * 32 + c31, n = nb + 32 * j + 16 * g + 8 * h;
             ax[hh][i][j][g] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.aux_in) + (size_t)m * p.ldaux + n);
           }
@@ -144,6 +150,7 @@ __device__ __forceinline__ void pp_epi_compute(const GemmArgs& p, const f32x16 (
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
+          if (hh == 1 && i >= HI) continue;
           float v[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -187,7 +194,7 @@ __device__ __forceinline__ void pp_epi_compute(const GemmArgs& p, const f32x16 (
   }
 }
 
-template <int EPI>
+template <int EPI, int HI>
 __device__ __forceinline__ void pp_epi_store(const GemmArgs& p, const PpOut& out, int mb0, int nb, int lane) {
   const int h = lane >> 5, c31 = lane & 31;
   const bool pre = (EPI == EPI_GELU) && p.aux_out;
@@ -195,6 +202,7 @@ __device__ __forceinline__ void pp_epi_store(const GemmArgs& p, const PpOut& out
   for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      if (hh == 1 && i >= HI) continue;
       const int m = mb0 + hh * 64 + i * 32 + c31;
       bf16* crow = reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + nb + 8 * h;
 #pragma unroll
@@ -217,6 +225,7 @@ __device__ __forceinline__ void pp_epi_store(const GemmArgs& p, const PpOut& out
 
 // fp32 partial tile of one split-K item (two-stage reduction): transposed accumulators, lane = row m with 4
 // consecutive columns per register group -> 16-byte plain stores, 32 per wave (compile-time count, full tiles)
+template <int HI>
 __device__ __forceinline__ void pp_partial_store(float* __restrict__ dst, int ldn, const f32x16 (&acc)[2][2][2], int mb0, int nb,
                                                  int lane) {
   const int h = lane >> 5, c31 = lane & 31;
@@ -224,6 +233,7 @@ __device__ __forceinline__ void pp_partial_store(float* __restrict__ dst, int ld
   for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      if (hh == 1 && i >= HI) continue;
       float* row = dst + (size_t)(mb0 + hh * 64 + i * 32 + c31) * ldn + nb + 4 * h;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -235,9 +245,24 @@ __device__ __forceinline__ void pp_partial_store(float* __restrict__ dst, int ld
 }
 
 template <> __device__ __forceinline__ void wait_vmcnt<40>() { asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<1>() { asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<5>() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<7>() { asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<19>() { asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<31>() { asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); }
+// n in 0..8 (wave-uniform; a compile-time constant in the steady-state loop)
+__device__ __forceinline__ void pp_wait_small(int n) {
+  if (n >= 8) wait_vmcnt<8>(); else if (n == 7) wait_vmcnt<7>(); else if (n == 6) wait_vmcnt<6>(); else if (n == 5) wait_vmcnt<5>();
+  else if (n == 4) wait_vmcnt<4>(); else if (n == 3) wait_vmcnt<3>(); else if (n == 2) wait_vmcnt<2>(); else if (n == 1) wait_vmcnt<1>();
+  else wait_vmcnt<0>();
+}
 
-template <bool TA, bool TB, bool TACC, int EPI>
+template <bool TA, bool TB, bool TACC, int EPI, int HI>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
+  constexpr int RW = 64 + 32 * HI, RT = 2 * RW;           // rows per wave row / per tile (128 / 256, or 96 / 192)
+  constexpr int GA1 = HI == 2 ? 2 : 1;                      // LDS-DMA instructions per wave for unit A1
+  constexpr int GKT = 6 + GA1;                             // ... per k-tile
+  constexpr int NST = (2 + HI) * 4;                        // bf16 stores per wave in the direct epilogue
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const bf16* __restrict__ A = reinterpret_cast<const bf16*>(p.A);
   const bf16* __restrict__ B = reinterpret_cast<const bf16*>(p.B);
@@ -246,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   // ---- work items: (tile, k-split), tile-major inside a split.  Workgroups land on XCD blockIdx % 8; each XCD
   //      owns a contiguous range of items (neighbouring tiles share an A row panel in that XCD's L2) and its
   //      workgroups stride through it together.
-  const int nbx = p.N / 256, ntile = nbx * (p.M / 256);
+  const int nbx = p.N / 256, ntile = nbx * (p.M / RT);
   const int nitems = ntile * p.split_k;
   const int ktiles = p.K / 64, per = (ktiles + p.split_k - 1) / p.split_k;
   int item, item_end, item_step;
@@ -264,9 +289,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   const size_t stepa = TA ? (size_t)64 * p.lda : (size_t)64;
   const size_t stepb = TB ? (size_t)64 * p.ldb : (size_t)64;
   const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((lds_void_p)smem);
-  unsigned fa[2], fb;                                            // fragment addresses (buffer 0; the other is + 65536)
-  fa[0] = lds0 + pp_frag_off<TA>(wr * 64, lane);
+  unsigned fa[2], fa1[2], fb;                                    // fragment addresses (buffer 0; the other is + 65536)
+  fa[0] = lds0 + pp_frag_off<TA>(wr * 64, lane);                 // unit A0: 64 rows per wave row
   fa[1] = lds0 + pp_frag_off<TA>(wr * 64 + 32, lane);
+  fa1[0] = lds0 + pp_frag_off<TA>(wr * 32 * HI, lane);           // unit A1: 32*HI rows per wave row
+  fa1[1] = lds0 + pp_frag_off<TA>(wr * 32 * HI + 32, lane);
   fb = lds0 + pp_frag_off<TB>(wc * 32, lane);
 
   int m0, n0, nt, zsplit;
@@ -274,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   auto setup = [&](int it) __attribute__((always_inline)) {
     const int z = it / ntile, tile = it - z * ntile;
     zsplit = z;
-    m0 = (tile / nbx) * 256; n0 = (tile % nbx) * 256;
+    m0 = (tile / nbx) * RT; n0 = (tile % nbx) * 256;
     const int tbeg = z * per;
     nt = min(ktiles, tbeg + per) - tbeg;
     const int kbeg = tbeg * 64;
@@ -282,17 +309,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     asm volatile("" : "+v"(ln));                       // hoisted out of the item loop (it would live, and spill, across the main loop)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      src[0][q] = pp_src<TA, 0>(A, p.lda, p.M, m0, kbeg, w + 8 * q, ln);
-      src[1][q] = pp_src<TB, 1>(B, p.ldb, p.N, n0, kbeg, w + 8 * q, ln);
-      src[2][q] = pp_src<TB, 2>(B, p.ldb, p.N, n0, kbeg, w + 8 * q, ln);
-      src[3][q] = pp_src<TA, 3>(A, p.lda, p.M, m0, kbeg, w + 8 * q, ln);
+      src[0][q] = pp_src<TA, 0, HI>(A, p.lda, p.M, m0, kbeg, w + 8 * q, ln);
+      src[1][q] = pp_src<TB, 1, HI>(B, p.ldb, p.N, n0, kbeg, w + 8 * q, ln);
+      src[2][q] = pp_src<TB, 2, HI>(B, p.ldb, p.N, n0, kbeg, w + 8 * q, ln);
+      src[3][q] = pp_src<TA, 3, HI>(A, p.lda, p.M, m0, kbeg, w + 8 * q, ln);
     }
   };
 
   // issue unit type J of the next k-tile that type has not fetched yet into buffer BUF (0/1)
 #define PP_ISSUE(J, BUF)                                                                                        \
   do {                                                                                                         \
-    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                            \
+    _Pragma("unroll") for (int q = 0; q < ((J) == 3 ? GA1 : 2); ++q) {                                         \
       __builtin_amdgcn_global_load_lds((glb_void_p)src[J][q],                                                  \
                                        (lds_void_p)(smem + (BUF) * 65536 + (J) * PP_UNIT + (w + 8 * q) * 1024), 16, 0, 0); \
       src[J][q] += ((J) == 0 || (J) == 3) ? stepa : stepb;                                                     \
@@ -307,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
 #define PP_MFMA(H, JB, BREG)                                                                                   \
   do {                                                                                                         \
     _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                              \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                          \
+      _Pragma("unroll") for (int i = 0; i < ((H) == 1 ? HI : 2); ++i) {                                        \
         if (TACC) acc[H][i][JB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BREG[s], a[i][s], acc[H][i][JB], 0, 0, 0); \
         else      acc[H][i][JB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][s], BREG[s], acc[H][i][JB], 0, 0, 0); \
       }                                                                                                        \
@@ -319,16 +346,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
       pp_read<TA, 2>(a[i][2], fa[i] + (BASEOFF)); pp_read<TA, 3>(a[i][3], fa[i] + (BASEOFF));                  \
     }                                                                                                          \
   } while (0)
+#define PP_READ_A1(BASEOFF)                                                                                    \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < HI; ++i) {                                                           \
+      pp_read<TA, 0>(a[i][0], fa1[i] + (BASEOFF)); pp_read<TA, 1>(a[i][1], fa1[i] + (BASEOFF));                \
+      pp_read<TA, 2>(a[i][2], fa1[i] + (BASEOFF)); pp_read<TA, 3>(a[i][3], fa1[i] + (BASEOFF));                \
+    }                                                                                                          \
+  } while (0)
 #define PP_READ_B(BREG, BASEOFF)                                                                               \
   do {                                                                                                         \
     pp_read<TB, 0>(BREG[0], fb + (BASEOFF)); pp_read<TB, 1>(BREG[1], fb + (BASEOFF));                          \
     pp_read<TB, 2>(BREG[2], fb + (BASEOFF)); pp_read<TB, 3>(BREG[3], fb + (BASEOFF));                          \
   } while (0)
   // end of an L section: retire the units the next phase reads, publish, then wait for this phase's own reads
-#define PP_SYNC_L(ALLOW)                                                                                       \
+  // ALLOW = units (the oldest of the window f+3 .. f+6) that may stay in flight; P = phase: with HI = 1 the A1 unit
+  // (one DMA instead of two) is the (4-P)&3-th of them
+#define PP_SYNC_L(ALLOW, P)                                                                                    \
   do {                                                                                                         \
-    if ((ALLOW) >= 4) wait_vmcnt<8>(); else if ((ALLOW) == 3) wait_vmcnt<6>(); else if ((ALLOW) == 2) wait_vmcnt<4>(); \
-    else if ((ALLOW) == 1) wait_vmcnt<2>(); else wait_vmcnt<0>();                                              \
+    const int al_ = (ALLOW) > 4 ? 4 : ((ALLOW) < 0 ? 0 : (ALLOW));                                             \
+    pp_wait_small(2 * al_ - ((GA1 == 1 && al_ > ((4 - (P)) & 3)) ? 1 : 0));                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     __builtin_amdgcn_s_barrier();                                                                              \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
@@ -353,24 +389,24 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     PP_READ_A(cb + 0 * PP_UNIT);
     PP_READ_B(b0, cb + 1 * PP_UNIT);
     if (!TAIL || f0 + 6 < nunits) PP_ISSUE(2, nb);
-    PP_SYNC_L(TAIL ? nunits - 3 - f0 : 4);
+    PP_SYNC_L(TAIL ? nunits - 3 - f0 : 4, 0);
     PP_MFMA(0, 0, b0);
     PP_SYNC_C();
     // ---- phase 1
     PP_READ_B(b1, cb + 2 * PP_UNIT);
     if (!TAIL || f0 + 7 < nunits) PP_ISSUE(3, nb);
-    PP_SYNC_L(TAIL ? nunits - 4 - f0 : 4);
+    PP_SYNC_L(TAIL ? nunits - 4 - f0 : 4, 1);
     PP_MFMA(0, 1, b1);
     PP_SYNC_C();
     // ---- phase 2
-    PP_READ_A(cb + 3 * PP_UNIT);
+    PP_READ_A1(cb + 3 * PP_UNIT);
     if (!TAIL || f0 + 8 < nunits) PP_ISSUE(0, nb ^ 1);
-    PP_SYNC_L(TAIL ? nunits - 5 - f0 : 4);
+    PP_SYNC_L(TAIL ? nunits - 5 - f0 : 4, 2);
     PP_MFMA(1, 1, b1);
     PP_SYNC_C();
     // ---- phase 3
     if (!TAIL || f0 + 9 < nunits) PP_ISSUE(1, nb ^ 1);
-    PP_SYNC_L(TAIL ? nunits - 6 - f0 : 4);
+    PP_SYNC_L(TAIL ? nunits - 6 - f0 : 4, 3);
     PP_MFMA(1, 0, b0);
     if (TAIL && kt == nt - 1) {                        // wave row 1 has no partner barrier left after its last C section
       __builtin_amdgcn_s_setprio(0);
@@ -389,10 +425,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
 #define PP_STAMP(I) do { if (dbg && nitem_done == 2) { unsigned long long t64_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t64_) :: "memory"); ts[I] = (unsigned)t64_; } } while (0)
   setup(item);
   PP_PROLOGUE();
-  int younger = 8;                                     // VMEM operations issued after the first two units of the current item
+  int younger = GKT;                                   // VMEM operations issued after the first two units of the current item
   for (;;) {
     // units 0 and 1 of this item: this wave's part has landed, then publish
-    if (younger == 8) wait_vmcnt<8>(); else if (younger == 24) wait_vmcnt<24>(); else if (younger == 40) wait_vmcnt<40>(); else wait_vmcnt<0>();
+    if (younger == GKT) { if (HI == 2) wait_vmcnt<8>(); else wait_vmcnt<7>(); }
+    else if (younger == GKT + NST) { if (HI == 2) wait_vmcnt<24>(); else wait_vmcnt<19>(); }
+    else if (younger == GKT + 2 * NST) { if (HI == 2) wait_vmcnt<40>(); else wait_vmcnt<31>(); }
+    else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();         // wave row 1 runs one barrier interval behind
     __builtin_amdgcn_sched_barrier(0);
@@ -438,34 +477,34 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     // The ring is free: no wave reads it after its last L section (wave row 1 is at most in its last C section),
     // and every LDS-DMA of this item has been waited for.  Start the next item before storing this one.
     PP_STAMP(1);
-    const int em0 = m0 + wr * 128, en0 = n0 + wc * 64, ez = zsplit;
+    const int em0 = m0 + wr * RW, en0 = n0 + wc * 64, ez = zsplit;
     item += item_step;
     const bool more = item < item_end;
     const bool store = !(p.atomic & 0x800);            // (diagnostic 0x800: main loop only)
     if (!store) {
       if (more) { setup(item); PP_PROLOGUE(); }
-      younger = 8;
+      younger = GKT;
     } else if (TACC && p.partial) {                     // split-K item of a two-stage reduction (fp32 partial, plain stores)
       if (more) { setup(item); PP_PROLOGUE(); }
-      pp_partial_store(p.partial + (size_t)ez * p.M * p.N, p.N, acc, em0, en0, lane);
-      younger = 40;
+      pp_partial_store<HI>(p.partial + (size_t)ez * p.M * p.N, p.N, acc, em0, en0, lane);
+      younger = GKT + 2 * NST;
     } else if (TACC) {
       PpOut out;
       int ln = lane;
       asm volatile("" : "+v"(ln));
-      pp_epi_compute<EPI>(p, acc, out, em0, en0, ln);
+      pp_epi_compute<EPI, HI>(p, acc, out, em0, en0, ln);
       PP_STAMP(2);
       if (more) { setup(item); PP_PROLOGUE(); }
       PP_STAMP(3);
       asm volatile("" : "+v"(ln));
-      pp_epi_store<EPI>(p, out, em0, en0, ln);
+      pp_epi_store<EPI, HI>(p, out, em0, en0, ln);
       PP_STAMP(4);
-      younger = (EPI == EPI_GELU && p.aux_out) ? 40 : 24;
+      younger = (EPI == EPI_GELU && p.aux_out) ? GKT + 2 * NST : GKT + NST;
     } else {                                           // fp32 output (accumulate / split-K atomics): row segments per register
       bf16_tile_epilogue<false>(p, acc[0], em0, en0, 0, 0, lane, smem);
       bf16_tile_epilogue<false>(p, acc[1], em0 + 64, en0, 0, 0, lane, smem);
       if (more) { setup(item); PP_PROLOGUE(); }
-      younger = 8;
+      younger = GKT;
     }
     ++nitem_done;
     if (!more) break;
@@ -483,6 +522,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
 #undef PP_PROLOGUE
 #undef PP_MFMA
 #undef PP_READ_A
+#undef PP_READ_A1
 #undef PP_READ_B
 #undef PP_SYNC_L
 #undef PP_SYNC_C
@@ -498,27 +538,39 @@ static int pp_num_cus() {
   return n;
 }
 
-template <bool TA, bool TB, bool TACC, int EPI>
+template <bool TA, bool TB, bool TACC, int EPI, int HI = 2>
 static void pp_launch0(const GemmArgs& p, hipStream_t st) {
+  static_assert(HI == 2 || TACC, "the 192-row variant exists for the bf16-output epilogue only");
   constexpr int smem = 131072;
-  auto kern = gemm_bf16_pp_kernel<TA, TB, TACC, EPI>;
+  auto kern = gemm_bf16_pp_kernel<TA, TB, TACC, EPI, HI>;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
-  const int nitems = (p.N / 256) * (p.M / 256) * p.split_k;
+  const int nitems = (p.N / 256) * (p.M / (128 + 64 * HI)) * p.split_k;
   const int grid = nitems < pp_num_cus() ? nitems : pp_num_cus();
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, p);
 }
 
 // The epilogue kind is a template parameter; only the combinations the encoder uses are instantiated:
 //   X*W^T (forward): none, GELU, +residual, tanh;  dY*W (input gradient): none, dGELU, +residual;  everything else: none.
-bool uc2_gemm_pp_supported(int trans_a, int trans_b, int c_f32, int epi) {
+// tile_rows = 192 (the N = 768 shapes, see the header comment): forward none, input gradient none / +residual.
+bool uc2_gemm_pp_supported(int trans_a, int trans_b, int c_f32, int epi, int tile_rows) {
+  if (tile_rows == 192) {
+    if (c_f32 || trans_a) return false;
+    return trans_b ? (epi == EPI_NONE || epi == EPI_ADD) : (epi == EPI_NONE);
+  }
   if (c_f32) return epi == EPI_NONE;
   if (!trans_a && !trans_b) return epi == EPI_NONE || epi == EPI_GELU || epi == EPI_ADD || epi == EPI_TANH;
   if (!trans_a && trans_b) return epi == EPI_NONE || epi == EPI_DGELU || epi == EPI_ADD;
   return epi == EPI_NONE;
 }
 
-void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st) {
+void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st, int tile_rows) {
+  if (tile_rows == 192) {
+    if (!trans_b) pp_launch0<false, false, true, EPI_NONE, 1>(p, st);
+    else if (p.epi == EPI_ADD) pp_launch0<false, true, true, EPI_ADD, 1>(p, st);
+    else pp_launch0<false, true, true, EPI_NONE, 1>(p, st);
+    return;
+  }
   if (p.c_f32 && p.partial) {                          // the bf16-output kernels double as partial-tile producers
     if (!trans_a && !trans_b) pp_launch0<false, false, true, EPI_NONE>(p, st);
     else if (!trans_a && trans_b) pp_launch0<false, true, true, EPI_NONE>(p, st);

@@ -33,8 +33,8 @@ class GemmTimer:
         ta, tb, variant, atomic, epi = key
         b = lambda x: "true" if x else "false"
         tacc = b(not atomic)
-        if variant == 8:
-            return "gemm_bf16_pp_kernel<%s, %s, %s, %d>" % (b(ta), b(tb), b(not atomic), epi)
+        if variant in (8, 9):
+            return "gemm_bf16_pp_kernel<%s, %s, %s, %d, %d>" % (b(ta), b(tb), b(not atomic), epi, 2 if variant == 8 else 1)
         if variant == 99:
             return "gemm_bf16_kernel<%s, %s, %s>" % (b(ta), b(tb), tacc)
         if variant in (6, 7):
@@ -130,8 +130,8 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
         e1.record()
         if defer:
             call("uc2_gemm_splitk_reduce", M, N, ptr(out), ldc, split_k, int(accumulate), stream())
-        if _CUR_VARIANT == 8:       # ping-pong kernel: transposed accumulators unless fp32 atomics; the epilogue kind is a template argument
-            key = (bool(ta), bool(tb), 8, bool(c_f32 and not two_stage), int(epi))
+        if _CUR_VARIANT in (8, 9):  # ping-pong kernel: transposed accumulators unless fp32 atomics; the epilogue kind is a template argument
+            key = (bool(ta), bool(tb), _CUR_VARIANT, bool(c_f32 and not two_stage), int(epi))
         else:
             key = (bool(ta), bool(tb), _CUR_VARIANT, bool(c_f32 and split_k > 1), 0)
         timer.add(key, 2.0 * M * N * K, e0, e1)
@@ -232,6 +232,8 @@ def gemm_plan(dtype, ta, tb, M, N, K, wgrad=False):
     out = torch.zeros((M, N), dtype=torch.float32 if wgrad else torch.bfloat16, device=dev)
     lib = _lib.load()
     cands = [(v, s) for v in (99, 1, 0, 6) for s in _WGRAD_SPLITS if s * 1024 <= K] if wgrad else list(_FWD_CANDIDATES)
+    if (not wgrad) and M % 192 == 0 and N % 256 == 0 and not ta:
+        cands.append((9, 1))                      # ping-pong kernel with 192-row tiles (tile-count quantisation at N = 768)
     if wgrad and M % 256 == 0 and N % 256 == 0:
         # persistent ping-pong kernel: one (tile, split) item per CU, or two
         tiles = (M // 256) * (N // 256)
