@@ -133,17 +133,39 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(int B, int S, int L, in
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);          // r = b*S + s
   if (r >= B * S) return;
   const int b = r / S, s = r - b * S;
-  for (int c = lane * 4; c < H; c += 256) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < L; ++j) {
-      if (index[(size_t)b * L + j] == s) {
-        float v[4];
-        Vec4<T>::load(dout + ((size_t)b * L + j) * H + c, v);
+  // the positions j with index[b][j] == s, found 64 at a time (one per lane, ballot) instead of every lane scanning
+  // all L entries for every column chunk; up to 4 column chunks (H <= 1024) are accumulated in registers per match
+  float acc[4][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+  for (int cbase = 0; cbase < H; cbase += 1024) {
+    for (int j0 = 0; j0 < L; j0 += 64) {
+      const int j = j0 + lane;
+      unsigned long long m = __ballot(j < L && index[(size_t)b * L + j] == s);
+      while (m) {
+        const int jj = j0 + __builtin_ctzll(m);
+        m &= m - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = cbase + i * 256 + lane * 4;
+          if (c < H) {
+            float v[4];
+            Vec4<T>::load(dout + ((size_t)b * L + jj) * H + c, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][e] += v[e];
+          }
+        }
       }
     }
-    Vec4<T>::store(dsrc + (size_t)r * H + c, acc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = cbase + i * 256 + lane * 4;
+      if (c < H) Vec4<T>::store(dsrc + (size_t)r * H + c, acc[i]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+    }
   }
 }
 extern "C" int uc2_gather_rows_fwd(int dtype, int B, int S, int L, int H, const void* src, const int64_t* index,
