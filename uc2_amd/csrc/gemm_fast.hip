@@ -359,9 +359,13 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
     // ping-pong kernel: whole 256x256 (variant 9: 192x256) tiles, >= 2 k-tiles per split, and (bf16 output) an epilogue
     // made of whole 16-byte accesses; anything else runs on the ring kernels above / the generic kernel
     const int rows = variant == 9 ? 192 : 256;
-    const int per = (p.K / 64 + p.split_k - 1) / p.split_k;
-    if (per < 2 || (p.K / 64) - (p.split_k - 1) * per < 2) return 0;
+    const int ktiles = p.K / 64, per = ((ktiles + p.split_k - 1) / p.split_k + 1) & ~1;   // k-tiles per split: even, >= 2
+    if ((ktiles & 1) || ktiles - (p.split_k - 1) * per < 2) return 0;
     if ((p.M % rows) || (p.N & 255)) return 0;
+    {   // staging sources are 32-bit byte offsets from the operand bases
+      const unsigned long long ea = 2ull * (trans_a ? p.K : p.M) * p.lda, eb = 2ull * (trans_b ? p.K : p.N) * p.ldb;
+      if (ea >= (1ull << 32) || eb >= (1ull << 32)) return 0;
+    }
     if (!uc2_gemm_pp_supported(trans_a, trans_b, p.c_f32, p.epi, rows)) return 0;
     if (!p.c_f32 && (p.accumulate || (p.ldc & 7) || (p.ldaux & 7) || ((uintptr_t)p.C & 15) ||
                      ((uintptr_t)p.aux_in & 15) || ((uintptr_t)p.aux_out & 15) || ((uintptr_t)p.bias & 15)))

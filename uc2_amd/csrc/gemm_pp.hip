@@ -273,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   //      workgroups stride through it together.
   const int nbx = p.N / 256, ntile = nbx * (p.M / RT);
   const int nitems = ntile * p.split_k;
-  const int ktiles = p.K / 64, per = (ktiles + p.split_k - 1) / p.split_k;
+  const int ktiles = p.K / 64, per = ((ktiles + p.split_k - 1) / p.split_k + 1) & ~1;     // k-tiles per split: even
   int item, item_end, item_step;
   {
     const int G = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -286,8 +286,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   }
   if (item >= item_end) return;
 
-  const size_t stepa = TA ? (size_t)64 * p.lda : (size_t)64;
-  const size_t stepb = TB ? (size_t)64 * p.ldb : (size_t)64;
+  const unsigned stepa = (TA ? 64u * (unsigned)p.lda : 64u) * 2u;      // bytes per k-tile
+  const unsigned stepb = (TB ? 64u * (unsigned)p.ldb : 64u) * 2u;
   const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((lds_void_p)smem);
   unsigned fa[2], fa1[2], fb;                                    // fragment addresses (buffer 0; the other is + 65536)
   fa[0] = lds0 + pp_frag_off<TA>(wr * 64, lane);                 // unit A0: 64 rows per wave row
@@ -297,7 +297,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   fb = lds0 + pp_frag_off<TB>(wc * 32, lane);
 
   int m0, n0, nt, zsplit;
-  const bf16* src[4][2];        // staging sources: unit type J (0 A0, 1 B0, 2 B1, 3 A1), wave-instructions w and w + 8
+  unsigned src[4][2];           // staging sources as 32-bit byte offsets from A / B (SGPR base + VGPR offset addressing:
+                                // half the registers of 64-bit pointers); unit type J (0 A0, 1 B0, 2 B1, 3 A1), wave-instructions w, w + 8
   auto setup = [&](int it) __attribute__((always_inline)) {
     const int z = it / ntile, tile = it - z * ntile;
     zsplit = z;
@@ -309,10 +310,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     asm volatile("" : "+v"(ln));                       // hoisted out of the item loop (it would live, and spill, across the main loop)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      src[0][q] = pp_src<TA, 0, HI>(A, p.lda, p.M, m0, kbeg, w + 8 * q, ln);
-      src[1][q] = pp_src<TB, 1, HI>(B, p.ldb, p.N, n0, kbeg, w + 8 * q, ln);
-      src[2][q] = pp_src<TB, 2, HI>(B, p.ldb, p.N, n0, kbeg, w + 8 * q, ln);
-      src[3][q] = pp_src<TA, 3, HI>(A, p.lda, p.M, m0, kbeg, w + 8 * q, ln);
+      src[0][q] = (unsigned)((const char*)pp_src<TA, 0, HI>(A, p.lda, p.M, m0, kbeg, w + 8 * q, ln) - (const char*)A);
+      src[1][q] = (unsigned)((const char*)pp_src<TB, 1, HI>(B, p.ldb, p.N, n0, kbeg, w + 8 * q, ln) - (const char*)B);
+      src[2][q] = (unsigned)((const char*)pp_src<TB, 2, HI>(B, p.ldb, p.N, n0, kbeg, w + 8 * q, ln) - (const char*)B);
+      src[3][q] = (unsigned)((const char*)pp_src<TA, 3, HI>(A, p.lda, p.M, m0, kbeg, w + 8 * q, ln) - (const char*)A);
     }
   };
 
@@ -320,16 +321,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
 #define PP_ISSUE(J, BUF)                                                                                        \
   do {                                                                                                         \
     _Pragma("unroll") for (int q = 0; q < ((J) == 3 ? GA1 : 2); ++q) {                                         \
-      __builtin_amdgcn_global_load_lds((glb_void_p)src[J][q],                                                  \
+      __builtin_amdgcn_global_load_lds((glb_void_p)((const char*)(((J) == 0 || (J) == 3) ? (const void*)A : (const void*)B) + src[J][q]),                                                 \
                                        (lds_void_p)(smem + (BUF) * 65536 + (J) * PP_UNIT + (w + 8 * q) * 1024), 16, 0, 0); \
-      src[J][q] += ((J) == 0 || (J) == 3) ? stepa : stepb;                                                     \
+      src[J][q] += ((J) == 0 || (J) == 3) ? stepa : stepb;   /* bytes */                                                     \
     }                                                                                                          \
   } while (0)
-  // first six units of an item (k-tile 0 whole, A0 and B0 of k-tile 1); the host guarantees nt >= 2
-#define PP_PROLOGUE() do { PP_ISSUE(0, 0); PP_ISSUE(1, 0); PP_ISSUE(2, 0); PP_ISSUE(3, 0); PP_ISSUE(0, 1); PP_ISSUE(1, 1); } while (0)
+  // first six units of an item in stream order (B0, A0, B1, A1 of k-tile 0, B0 and A0 of k-tile 1); the host guarantees nt >= 2
+#define PP_PROLOGUE() do { PP_ISSUE(1, 0); PP_ISSUE(0, 0); PP_ISSUE(2, 0); PP_ISSUE(3, 0); PP_ISSUE(1, 1); PP_ISSUE(0, 1); } while (0)
 
   f32x16 acc[2][2][2];                                 // [A half][i][j]
-  bf16x8 a[2][4], b0[4], b1[4];
+  bf16x8 a[2][4], bx[4], by[4];                        // the two B register sets swap roles (B0 / B1) every k-tile
 
 #define PP_MFMA(H, JB, BREG)                                                                                   \
   do {                                                                                                         \
@@ -379,15 +380,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   } while (0)
 
-  auto body = [&](auto tail_c, int kt) __attribute__((always_inline)) {
+  auto body = [&](auto tail_c, auto swap_c, int kt) __attribute__((always_inline)) {
     constexpr bool TAIL = decltype(tail_c)::value;
+    constexpr bool SW = decltype(swap_c)::value;       // k-tile parity: B0 lives in by, B1 in bx
+    bf16x8 (&b0)[4] = SW ? by : bx;
+    bf16x8 (&b1)[4] = SW ? bx : by;
     const int nunits = 4 * nt;
-    const unsigned cb = (kt & 1) * 65536u;             // this k-tile's buffer
+    unsigned cb = (kt & 1) * 65536u;                   // this k-tile's buffer
+    asm volatile("" : "+s"(cb));                       // opaque: the fragment addresses (base ^ step, + buffer, + unit) are recomputed per
+                                                       // read (1-2 VALU) instead of living in ~40 loop-invariant registers
     const int nb = (kt & 1) ^ 1;                       // buffer of k-tile kt+1 (kt+2 shares this tile's)
     const int f0 = 4 * kt;                             // first phase; phase f issues unit f+6, may leave min(4, nunits-3-f) units in flight
+    // Fragment reads are spread 8 / 4 / 8 / 4 over the phases: B0 of k-tile kt+1 is read in phase 3 of k-tile kt, into
+    // the registers of B1 (dead after phase 2; the current B0 is still needed by this phase's MFMAs) -- the two B
+    // register sets swap roles every k-tile.  The unit order of the stream is therefore B0, A0, B1, A1: every phase
+    // consumes exactly the unit the previous phase's wait retired.
     // ---- phase 0
     PP_READ_A(cb + 0 * PP_UNIT);
-    PP_READ_B(b0, cb + 1 * PP_UNIT);
     if (!TAIL || f0 + 6 < nunits) PP_ISSUE(2, nb);
     PP_SYNC_L(TAIL ? nunits - 3 - f0 : 4, 0);
     PP_MFMA(0, 0, b0);
@@ -400,12 +409,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     PP_SYNC_C();
     // ---- phase 2
     PP_READ_A1(cb + 3 * PP_UNIT);
-    if (!TAIL || f0 + 8 < nunits) PP_ISSUE(0, nb ^ 1);
+    if (!TAIL || f0 + 8 < nunits) PP_ISSUE(1, nb ^ 1);
     PP_SYNC_L(TAIL ? nunits - 5 - f0 : 4, 2);
     PP_MFMA(1, 1, b1);
     PP_SYNC_C();
     // ---- phase 3
-    if (!TAIL || f0 + 9 < nunits) PP_ISSUE(1, nb ^ 1);
+    if (!TAIL || kt + 1 < nt) PP_READ_B(b1, (cb ^ 65536u) + 1 * PP_UNIT);
+    if (!TAIL || f0 + 9 < nunits) PP_ISSUE(0, nb ^ 1);
     PP_SYNC_L(TAIL ? nunits - 6 - f0 : 4, 3);
     PP_MFMA(1, 0, b0);
     if (TAIL && kt == nt - 1) {                        // wave row 1 has no partner barrier left after its last C section
@@ -470,9 +480,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     PP_STAMP(0);
     if (dbg && nitem_done == 3) { unsigned long long t64_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t64_) :: "memory"); ts[6] = (unsigned)t64_; }
     if (!(p.atomic & 0x4000)) {                        // (diagnostic 0x4000: epilogue only)
+      using F = std::false_type; using T = std::true_type;
+      PP_READ_B(bx, 1 * PP_UNIT);                      // B0 of k-tile 0 (later k-tiles get theirs one phase ahead)
       int kt = 0;
-      for (; kt + 2 < nt; ++kt) body(std::false_type{}, kt);
-      for (; kt < nt; ++kt) body(std::true_type{}, kt);
+      for (; kt + 2 < nt; kt += 2) { body(F{}, F{}, kt); body(F{}, T{}, kt + 1); }     // nt is even (host-checked)
+      body(T{}, F{}, kt);
+      body(T{}, T{}, kt + 1);
     }
     // The ring is free: no wave reads it after its last L section (wave row 1 is at most in its last C section),
     // and every LDS-DMA of this item has been waited for.  Start the next item before storing this one.
