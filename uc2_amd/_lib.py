@@ -25,6 +25,7 @@ SIGNATURES = {
     "uc2_gemm_force_generic": (I, [I]),
     "uc2_gemm_set_variant": (I, [I]),
     "uc2_gemm_set_fetch_only": (I, [I]),
+    "uc2_gemm_set_skew": (I, [I]),
     "uc2_gemm_set_workspace": (I, [P, SZ]),
     "uc2_gemm_defer_reduce": (I, [I]),
     "uc2_gemm_splitk_reduce": (I, [I, I, P, I, I, I, P]),

@@ -12,6 +12,7 @@ struct GemmArgs {
   int epi, c_f32, accumulate, split_k, atomic;
   int a_vec, b_vec;      // 16-byte vector loads allowed (alignment checked on the host)
   float* partial;        // split-K partial tiles [split][M][N] fp32 (ping-pong kernel, two-stage reduction), or null
+  int skew;              // ping-pong kernel: start delay step in units of s_sleep(127) (~8k cycles) between the 4 phase groups
 };
 
 // ------------------------------------------------------------------------------------------

@@ -87,8 +87,8 @@ template <bool TR, int S> __device__ __forceinline__ void pp_read(bf16x8& dst, u
 
 // Direct epilogue in two parts, so that the next item's LDS-DMA can be issued in between:
 //   pp_epi_compute: aux_in loads (EPI_ADD / EPI_DGELU), lane-half exchange, bias, activation, conversion.  It leaves
-//                   the wave's 128x64 outputs as 16 packed bf16x8 registers per lane (+16 for the pre-activation
-//                   copy of EPI_GELU) -- every VMEM load of the epilogue is issued here, BEFORE the DMA, because
+//                   the wave's 128x64 outputs as 16 packed bf16x8 registers per lane (the pre-activation copy of
+//                   EPI_GELU is stored on the way) -- every VMEM load of the epilogue is issued here, BEFORE the DMA, because
 //                   vmcnt retires in order: a load issued after the DMA would wait for the whole prologue.
 //                   (The bias is not added here: the accumulators START at the bias, see the kernel.)
 //   pp_epi_store  : the stores only; full tiles, so their number is a compile-time function of the epilogue kind.
@@ -113,7 +113,6 @@ __device__ __forceinline__ float colsum_butterfly32(float (&v)[32], int lane) {
 
 struct PpOut {
   bf16x8 o[2][2][2][2];       // [A half][i][j][g]
-  bf16x8 pre[2][2][2][2];     // pre-activation values (EPI_GELU with aux_out)
 };
 
 template <int EPI, int HI>
@@ -163,7 +162,9 @@ __device__ __forceinline__ void pp_epi_compute(const GemmArgs& p, const f32x16 (
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-            out.pre[hh][i][j][g] = o;
+            // the pre-activation copy leaves right here, while the GELU arithmetic of the remaining values runs (the
+            // stores are older than the next item's LDS-DMA and have mostly drained by the time it is waited for)
+            if (p.aux_out) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.aux_out) + (size_t)(mb0 + hh * 64 + i * 32 + c31) * p.ldaux + nb + 32 * j + 16 * g + 8 * h) = o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = gelu_bf(v[e]);
           } else if (EPI == EPI_DGELU) {
@@ -197,7 +198,6 @@ __device__ __forceinline__ void pp_epi_compute(const GemmArgs& p, const f32x16 (
 template <int EPI, int HI>
 __device__ __forceinline__ void pp_epi_store(const GemmArgs& p, const PpOut& out, int mb0, int nb, int lane) {
   const int h = lane >> 5, c31 = lane & 31;
-  const bool pre = (EPI == EPI_GELU) && p.aux_out;
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
@@ -211,15 +211,6 @@ __device__ __forceinline__ void pp_epi_store(const GemmArgs& p, const PpOut& out
         for (int g = 0; g < 2; ++g) {
           *reinterpret_cast<bf16x8*>(crow + 32 * j + 16 * g) = out.o[hh][i][j][g];
         }
-      if (pre) {
-        bf16* prow = reinterpret_cast<bf16*>(p.aux_out) + (size_t)m * p.ldaux + nb + 8 * h;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int g = 0; g < 2; ++g) {
-            *reinterpret_cast<bf16x8*>(prow + 32 * j + 16 * g) = out.pre[hh][i][j][g];
-          }
-      }
     }
 }
 
@@ -285,6 +276,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     item = beg + slot;
   }
   if (item >= item_end) return;
+  // De-phasing: with equal tiles every CU reaches its epilogue at the same moment and the 256 store bursts (plus the
+  // next tiles' first fetches) queue on HBM while the matrix pipes idle.  Four phase groups (by slot within the XCD)
+  // start p.skew * ~8k cycles apart, so at most a quarter of the chip stores at a time.
+  if (p.skew > 0) {
+    const int g = (blockIdx.x >> 3) & 3;
+    for (int i = 0; i < g * p.skew; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 
   const unsigned stepa = (TA ? 64u * (unsigned)p.lda : 64u) * 2u;      // bytes per k-tile
   const unsigned stepb = (TB ? 64u * (unsigned)p.ldb : 64u) * 2u;
@@ -512,7 +510,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
       asm volatile("" : "+v"(ln));
       pp_epi_store<EPI, HI>(p, out, em0, en0, ln);
       PP_STAMP(4);
-      younger = (EPI == EPI_GELU && p.aux_out) ? GKT + 2 * NST : GKT + NST;
+      younger = GKT + NST;                             // (the pre-activation stores of EPI_GELU are older than the DMA)
     } else {                                           // fp32 output (accumulate / split-K atomics): row segments per register
       bf16_tile_epilogue<false>(p, acc[0], em0, en0, 0, 0, lane, smem);
       bf16_tile_epilogue<false>(p, acc[1], em0 + 64, en0, 0, 0, lane, smem);
