@@ -4,22 +4,24 @@
 // Ping-pong variant: tile 256x256x64, 8 waves = 2 (M) x 4 (N), 128x64 of output per wave (128 accumulator
 // registers), one workgroup per CU, 128 KiB of LDS = 2 k-tile buffers x 4 staging units of 16 KiB.
 //
-// A k-tile is consumed in four phases, one 64x32 quadrant of the wave's output each (8 MFMAs):
-//     phase 0: read A0 (rows 0-63 of the wave's 128) and B0 (columns 0-31 of its 64)   -> A0 x B0
-//     phase 1: read B1                                                                 -> A0 x B1
-//     phase 2: read A1 (overwrites A0)                                                 -> A1 x B1
-//     phase 3: (no reads)                                                              -> A1 x B0
+// A k-tile is consumed in four phases, one 64x32 quadrant of the wave's output each (8 MFMAs); the fragment
+// reads are spread 8 / 4 / 8 / 4 (ds_read_b128 equivalents) over them:
+//     phase 0: read A0 (rows 0-63 of the wave's 128)                         -> A0 x B0   (B0 was read one phase ago)
+//     phase 1: read B1 (columns 32-63 of the wave's 64)                      -> A0 x B1
+//     phase 2: read A1 (overwrites A0)                                       -> A1 x B1
+//     phase 3: read B0 of the NEXT k-tile into the registers of B1 (dead)    -> A1 x B0
+// (the two B register sets swap roles every k-tile; the main loop is unrolled by two, k-tile counts are even).
 // Every phase is  [L: fragment reads + 2 LDS-DMA issues + counted vmcnt] barrier [C: 8 MFMAs] barrier.  The two
 // wave rows run one barrier apart (wave row 1 takes one extra barrier at the start), so in every barrier
 // interval one wave of each SIMD is in its C section while the other is in its L section: the matrix pipe
 // always has a wave feeding it and the other wave's LDS reads / DMA issues cost it nothing.
 //
-// Staging: the k-tile is cut into four units of 128 rows x 64 k in the order the phases consume them
-// (A0-rows of both wave rows, B0-columns of all four wave columns, B1, A1).  Phase f issues unit f+6 (each wave
-// two 1-KiB LDS-DMA instructions), so a unit is issued 5-6 phases before its first read and at least two
-// barrier intervals after the last read of the unit it overwrites; `s_waitcnt vmcnt(8)` at the end of every
-// L section retires exactly the units the next phase reads (all but the 4 youngest units), and the barrier
-// that follows publishes them to the other waves.
+// Staging: the k-tile is cut into four units of 128 rows x 64 k, streamed in the order the phases consume them:
+// B0 (columns 0-31 of all four wave columns), A0 (rows 0-63 of both wave rows), B1, A1 -- one unit per phase.
+// Phase f issues unit f+6 (each wave two 1-KiB LDS-DMA instructions), so a unit is issued 5-6 phases before
+// its first read and at least two barrier intervals after the last read of the unit it overwrites;
+// `s_waitcnt vmcnt(8)` at the end of every L section retires exactly the unit the next phase reads (all but
+// the 4 youngest units), and the barrier that follows publishes it to the other waves.
 //
 // HI = 1 variant: tiles of 192 rows (96 per wave row: A0 = 64 rows, A1 = 32).  The N = 768 GEMMs of the encoder have
 // 576 tiles of 256 rows on 256 CUs (2.25 rounds, the last a quarter full); with 192 rows they are 768 = three full
