@@ -457,7 +457,8 @@ static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, 
     if (e != hipSuccess) { uc2_set_error(__FILE__, __LINE__, hipGetErrorString(e)); return (int)e; }
   }
   const int nbh = B * nh;
-  const int hpw = nbh >= 4096 ? 4 : (nbh >= 1024 ? 2 : 1);       // heads per workgroup (next head prefetched into registers)
+  // heads per workgroup (next head prefetched into registers): about two resident workgroups per CU walk the heads
+  const int hpw = nbh >= 1024 ? (nbh / 512 > 16 ? 16 : nbh / 512) : 1;
   hipLaunchKernelGGL(kern, dim3((nbh + hpw - 1) / hpw), dim3(NW * 64), smem, st, L, nh, (const bf16*)qkv, mask, scale,
                      drop_thresh(drop_p), 1.0f / (1.0f - drop_p), seed_ptr, seed_imm, (const bf16*)ctx,
                      (const bf16*)dctx, lse, (bf16*)dqkv, dbias, nbh, hpw);
