@@ -457,3 +457,41 @@ def test_gemm_pingpong_192_row_tiles(tb, epi, M, N, K):
         lib.uc2_gemm_set_variant(-2)
     assert torch.equal(o1, o2)
     assert rel_err(o1.float(), ref.float()) < 3e-3
+
+
+def test_gemm_pingpong_skew_and_deferred_reduce():
+    """start skew between phase groups changes timing only; the split-K reduction pass run on its own
+    (uc2_gemm_defer_reduce + uc2_gemm_splitk_reduce) equals the fused call"""
+    lib = ops._lib.load()
+    M, N, K = 8192, 768, 768
+    a = rnd((M, K), 1, dtype=torch.bfloat16)
+    b = rnd((N, K), 2, 0.05, dtype=torch.bfloat16)
+    bias = rnd((N,), 3)
+    pre0 = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    pre1 = torch.zeros_like(pre0)
+    try:
+        lib.uc2_gemm_set_variant(8)
+        lib.uc2_gemm_set_skew(0)
+        o0 = ops.gemm(a, b, M, N, K, bias=bias, epi=ops.EPI_GELU, aux_out=pre0)
+        lib.uc2_gemm_set_skew(2)
+        o1 = ops.gemm(a, b, M, N, K, bias=bias, epi=ops.EPI_GELU, aux_out=pre1)
+    finally:
+        lib.uc2_gemm_set_skew(-1)
+        lib.uc2_gemm_set_variant(-2)
+    assert torch.equal(o0, o1) and torch.equal(pre0, pre1)
+    # weight-gradient shape through ops (workspace registered there): fused vs deferred reduction
+    Mo, No, Kt = 768, 768, 16384
+    x = rnd((Kt, Mo), 5, 0.1, dtype=torch.bfloat16)
+    y = rnd((Kt, No), 6, 0.1, dtype=torch.bfloat16)
+    acc = rnd((Mo, No), 7)
+    try:
+        ops._CUR_VARIANT = 8
+        lib.uc2_gemm_set_variant(8)
+        fused = ops.gemm(x, y, Mo, No, Kt, ta=True, tb=True, out=acc.clone(), accumulate=True, split_k=8)
+        ops.GEMM_TIMER = ops.GemmTimer()                 # the timer path defers the reduction pass
+        deferred = ops.gemm(x, y, Mo, No, Kt, ta=True, tb=True, out=acc.clone(), accumulate=True, split_k=8)
+    finally:
+        ops.GEMM_TIMER = None
+        ops._CUR_VARIANT = -2
+        lib.uc2_gemm_set_variant(-2)
+    assert torch.equal(fused, deferred)
