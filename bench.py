@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="pairs per GPU per step")
     ap.add_argument("--task", default="itm", choices=["itm", "mlm"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
