@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      uint32_t thresh, float keep_scale, const uint64_t* __restrict__ seed_ptr,
                                                      uint64_t seed_imm, T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ ws, int want_dbias) {
-  __shared__ float red[4][3][NC * 4 * 64];
+  __shared__ float red[4][NC * 4 * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nch = H >> 2;
   const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
@@ -94,7 +94,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
 #pragma unroll
     for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; dbx[i][e] = 0.f; }
 
+  // gamma stays in registers; per row every load is issued before the first use (column chunks past the row end
+  // are clamped, not branched around: with a branch per chunk hipcc waits for each load before issuing the next,
+  // nine dependent memory round trips per row)
+  float gmr[NC][4];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = min(lane + 64 * i, nch - 1);
+    Vec4<float>::load(gamma + c * 4, gmr[i]);
+  }
+  typedef typename Raw4<T>::type raw_t;
   for (int row = blockIdx.x * 4 + wv; row < M; row += gridDim.x * 4) {
+    raw_t rx[NC], rr[NC], rd[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const size_t off = (size_t)row * H + min(lane + 64 * i, nch - 1) * 4;
+      rx[i] = Raw4<T>::load(x + off);
+      rd[i] = Raw4<T>::load(dy + off);
+    }
+    if (res) {
+#pragma unroll
+      for (int i = 0; i < NC; ++i) rr[i] = Raw4<T>::load(res + (size_t)row * H + min(lane + 64 * i, nch - 1) * 4);
+    }
     const float mean = mean_i[row], rstd = rstd_i[row];
     float xh[NC][4], g[NC][4];
     bool kp[NC][4];
@@ -102,34 +123,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = lane + 64 * i;
-      if (c < nch) {
-        const size_t off = (size_t)row * H + c * 4;
-        float xv[4], dyv[4], gm[4];
-        Vec4<T>::load(x + off, xv);
+      const bool valid = c < nch;
+      const size_t off = (size_t)row * H + c * 4;
+      float xv[4], dyv[4];
+      Raw4<T>::to_f(rx[i], xv);
+      Raw4<T>::to_f(rd[i], dyv);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) kp[i][e] = true;
-        if (thresh) {
-          drop_keep4(seed, off, thresh, kp[i]);
+      for (int e = 0; e < 4; ++e) kp[i][e] = true;
+      if (thresh) {
+        drop_keep4(seed, off, thresh, kp[i]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) xv[e] = kp[i][e] ? xv[e] * keep_scale : 0.f;
-        }
-        if (res) {
-          float r[4];
-          Vec4<T>::load(res + off, r);
+        for (int e = 0; e < 4; ++e) xv[e] = kp[i][e] ? xv[e] * keep_scale : 0.f;
+      }
+      if (res) {
+        float r[4];
+        Raw4<T>::to_f(rr[i], r);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) xv[e] += r[e];
-        }
-        Vec4<T>::load(dy + off, dyv);
-        Vec4<float>::load(gamma + c * 4, gm);
+        for (int e = 0; e < 4; ++e) xv[e] += r[e];
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xh[i][e] = (xv[e] - mean) * rstd;
-          g[i][e] = dyv[e] * gm[e];
-          s1 += g[i][e];
-          s2 += g[i][e] * xh[i][e];
-          dg[i][e] += dyv[e] * xh[i][e];
-          db[i][e] += dyv[e];
-        }
+      for (int e = 0; e < 4; ++e) {
+        const float dyq = valid ? dyv[e] : 0.f;
+        xh[i][e] = valid ? (xv[e] - mean) * rstd : 0.f;
+        g[i][e] = dyq * gmr[i][e];
+        s1 += g[i][e];
+        s2 += g[i][e] * xh[i][e];
+        dg[i][e] += dyq * xh[i][e];
+        db[i][e] += dyq;
       }
     }
     s1 = wave_sum(s1) / (float)H;
@@ -151,21 +171,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
       }
     }
   }
-  // reduce the 4 waves of this workgroup, write one partial row per workgroup
-#pragma unroll
-  for (int i = 0; i < NC; ++i)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      red[wv][0][(i * 64 + lane) * 4 + e] = dg[i][e];
-      red[wv][1][(i * 64 + lane) * 4 + e] = db[i][e];
-      red[wv][2][(i * 64 + lane) * 4 + e] = dbx[i][e];
-    }
-  __syncthreads();
+  // reduce the 4 waves of this workgroup, write one partial row per workgroup.  One accumulator kind at a time
+  // (12 KiB of LDS instead of 36: the static allocation no longer caps the kernel at 4 workgroups per CU).
   const int nout = want_dbias ? 3 : 2;
-  for (int idx = threadIdx.x; idx < nout * H; idx += 256) {
-    const int which = idx / H, col = idx - which * H;      // red index == column (c*4 + e, c = lane + 64*i)
-    const float sum = red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
-    ws[(size_t)blockIdx.x * 3 * H + idx] = sum;
+  for (int which = 0; which < nout; ++which) {
+    if (which) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        red[wv][(i * 64 + lane) * 4 + e] = which == 0 ? dg[i][e] : (which == 1 ? db[i][e] : dbx[i][e]);
+    __syncthreads();
+    for (int col = threadIdx.x; col < H; col += 256)       // red index == column (c*4 + e, c = lane + 64*i)
+      ws[(size_t)blockIdx.x * 3 * H + which * H + col] = red[0][col] + red[1][col] + red[2][col] + red[3][col];
   }
 }
 
