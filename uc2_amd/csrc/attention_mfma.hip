@@ -78,6 +78,23 @@ __device__ __forceinline__ void acc_colsum_atomic(const f32x16 (&a)[DB], bool ro
   const int c = lane & 31, h = lane >> 5, db = c >> 4, r = c & 15;
   if (db < DB) atomicAdd(dst + 32 * db + 8 * (r >> 2) + 4 * h + (r & 3), tot);
 }
+// Store one transposed 32x32 accumulator block (lane = output row, register 4g+e = column 8g + 4h + e) as bf16: the two
+// lane halves exchange 4-column groups (v_permlane32_swap) so every lane owns 8 consecutive columns -- two 16-byte stores
+// (columns 8h.. and 16+8h..) instead of four 8-byte ones.  Must be called by the whole wave; `ok` masks the store.
+__device__ __forceinline__ void store_acc_block(bf16* __restrict__ row_ptr, const f32x16& a, float scale, int h, bool ok) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float fx = a[8 * k + e] * scale, fy = a[8 * k + 4 + e] * scale;
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(fx), __float_as_uint(fy), false, false);
+      o[e] = (bf16)__uint_as_float(sw[0]);
+      o[4 + e] = (bf16)__uint_as_float(sw[1]);
+    }
+    if (ok) *reinterpret_cast<bf16x8*>(row_ptr + 16 * k + 8 * h) = o;
+  }
+}
 // row of accumulator register i for lane half h
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
@@ -138,11 +155,18 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
   const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
   const bf16* base = qkv + (size_t)b * L * ld + head * D;
   const int tid = threadIdx.x;
-  stage_tile<D>(Ks, base + H, ld, L, Lp, tid, NW * 64);
-  stage_tile<D>(Vs, base + 2 * H, ld, L, Lp, tid, NW * 64);
-  for (int k = tid; k < Lp; k += NW * 64) {
-    Ms[k] = (k < L) ? (mask ? mask[(size_t)b * L + k] : 0.f) : -1e30f;
-    Hk[k] = attn_line_hash(seed, bh, k, UC2_ATTN_SALT_K);
+  {   // K and V tiles: all 16-byte loads of the thread in flight together, then the LDS stores (a load -> wait -> store
+      // loop costs eight dependent memory round trips per workgroup)
+    constexpr int NCH = Lp * (D / 8) / (NW * 64);
+    bf16x8 rk[NCH], rv[NCH];
+    load_tile_regs<D, NCH>(rk, base + H, ld, L, tid, NW * 64);
+    load_tile_regs<D, NCH>(rv, base + 2 * H, ld, L, tid, NW * 64);
+    for (int k = tid; k < Lp; k += NW * 64) {
+      Ms[k] = (k < L) ? (mask ? mask[(size_t)b * L + k] : 0.f) : -1e30f;
+      Hk[k] = attn_line_hash(seed, bh, k, UC2_ATTN_SALT_K);
+    }
+    store_tile_regs<D, NCH>(Ks, rk, tid, NW * 64);
+    store_tile_regs<D, NCH>(Vs, rv, tid, NW * 64);
   }
   __syncthreads();
 
@@ -210,13 +234,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
       for (int s = 0; s < 2; ++s)
         o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr(Vs, RS, 32 * kb + 16 * s, 32 * db, lane), pack8(sc[kb], s), o,
                                                     0, 0, 0);
-    if (q < L) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float v[4] = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
-        Vec4<bf16>::store(out + 32 * db + 8 * g + 4 * h, v);
-      }
-    }
+    store_acc_block(out + 32 * db, o, inv, h, q < L);
   }
   if (lse && q < L && h == 0) lse[(size_t)bh * L + q] = mx + __logf(sum);
 }
@@ -346,15 +364,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
                                                            pack8(sa, s), dq[db], 0, 0, 0);
     }
     if (dbias) acc_colsum_atomic<DB>(dq, r0 < L, dbias + head * D, lane);       // d(query bias)
-    if (r0 < L) {
 #pragma unroll
-      for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float v[4] = {dq[db][4 * g], dq[db][4 * g + 1], dq[db][4 * g + 2], dq[db][4 * g + 3]};
-          Vec4<bf16>::store(dbase + (size_t)r0 * ld + 32 * db + 8 * g + 4 * h, v);
-        }
-    }
+    for (int db = 0; db < DB; ++db) store_acc_block(dbase + (size_t)r0 * ld + 32 * db, dq[db], 1.0f, h, r0 < L);
   }
 
   // ---------------- orientation 2: rows = query, cols = key (this wave's 32 keys) -> dK, dV ----------------
@@ -414,16 +425,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
       acc_colsum_atomic<DB>(dk, r0 < L, dbias + H + head * D, lane);
       acc_colsum_atomic<DB>(dv, r0 < L, dbias + 2 * H + head * D, lane);
     }
-    if (r0 < L) {
 #pragma unroll
-      for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float v[4] = {dk[db][4 * g], dk[db][4 * g + 1], dk[db][4 * g + 2], dk[db][4 * g + 3]};
-          Vec4<bf16>::store(dbase + (size_t)r0 * ld + H + 32 * db + 8 * g + 4 * h, v);
-          float u[4] = {dv[db][4 * g], dv[db][4 * g + 1], dv[db][4 * g + 2], dv[db][4 * g + 3]};
-          Vec4<bf16>::store(dbase + (size_t)r0 * ld + 2 * H + 32 * db + 8 * g + 4 * h, u);
-        }
+    for (int db = 0; db < DB; ++db) {
+      store_acc_block(dbase + (size_t)r0 * ld + H + 32 * db, dk[db], 1.0f, h, r0 < L);
+      store_acc_block(dbase + (size_t)r0 * ld + 2 * H + 32 * db, dv[db], 1.0f, h, r0 < L);
     }
   }
   __syncthreads();                                     // every wave is done with this head's LDS tiles
