@@ -21,26 +21,36 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int H, const T* __re
   if (row >= M) return;
   const int nch = H >> 2;
   const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
+  // every load of the row is issued before the first use (chunks past the row end are clamped, not branched around:
+  // a branch per chunk makes hipcc wait for each load before issuing the next)
+  typedef typename Raw4<T>::type raw_t;
+  raw_t rx[LN_MAXC], rr[LN_MAXC];
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) rx[i] = Raw4<T>::load(x + (size_t)row * H + min(lane + 64 * i, nch - 1) * 4);
+  if (res) {
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) rr[i] = Raw4<T>::load(res + (size_t)row * H + min(lane + 64 * i, nch - 1) * 4);
+  }
   float v[LN_MAXC][4];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXC; ++i) {
     const int c = lane + 64 * i;
+    const size_t off = (size_t)row * H + c * 4;
+    Raw4<T>::to_f(rx[i], v[i]);
+    if (thresh) {
+      bool kp4[4];
+      drop_keep4(seed, off, thresh, kp4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] = kp4[e] ? v[i][e] * keep_scale : 0.f;
+    }
+    if (res) {
+      float r[4];
+      Raw4<T>::to_f(rr[i], r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] += r[e];
+    }
     if (c < nch) {
-      const size_t off = (size_t)row * H + c * 4;
-      Vec4<T>::load(x + off, v[i]);
-      if (thresh) {
-        bool kp4[4];
-        drop_keep4(seed, off, thresh, kp4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[i][e] = kp4[e] ? v[i][e] * keep_scale : 0.f;
-      }
-      if (res) {
-        float r[4];
-        Vec4<T>::load(res + off, r);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[i][e] += r[e];
-      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) s += v[i][e];
     }
