@@ -162,7 +162,9 @@ __device__ __forceinline__ uint32_t attn_line_hash(uint64_t seed, uint32_t bh, u
 #define UC2_ATTN_SALT_Q 0x00000000U
 #define UC2_ATTN_SALT_K 0x5bd1e995U
 __device__ __forceinline__ bool attn_keep(uint32_t hq, uint32_t hk, uint32_t thresh) {
-  return (((hq ^ hk) * 0x9E3779B1U) >> 16) >= (thresh >> 16);
+  // full-rate 24-bit multiply (v_mul_u32_u24; v_mul_lo_u32 is quarter rate and this runs once per score element in
+  // VALU-bound kernels): the low 24 bits of two fully mixed hashes, the top 16 bits of the 32-bit product decide
+  return __umul24(hq ^ hk, 0x9E3779U) >= (thresh & 0xffff0000U);
 }
 static inline uint32_t drop_thresh(float p) {
   if (p <= 0.f) return 0u;
