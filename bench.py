@@ -162,6 +162,8 @@ def main():
             dist.init_process_group(backend)
     assert world == a.gpus, "--gpus %d but WORLD_SIZE %d" % (a.gpus, world)
 
+    if os.environ.get("UC2_GEMM_SKEW"):                     # A/B knob (tests/ab_skew.py)
+        ops._lib.call("uc2_gemm_set_skew", int(os.environ["UC2_GEMM_SKEW"]))
     ops.rng.manual_seed(20260101 + rank, dev)              # dropout streams differ per rank
     torch.manual_seed(0)                                   # weights seed 0 (random init, N(0, 0.02))
     model = VLXLMRForPretraining(make_cfg(a.layers), img_dim=IMG_DIM, img_label_dim=1601)

@@ -52,7 +52,7 @@ int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, const voi
 int uc2_gemm_force_generic(int on);
 int uc2_gemm_set_variant(int variant);
 int uc2_gemm_set_fetch_only(int diagnostic_mode);
-int uc2_gemm_set_skew(int step);        /* ping-pong kernel start skew between phase groups: -1 automatic, 0 off, n = n * ~8k cycles */
+int uc2_gemm_set_skew(int step);        /* ping-pong kernel start skew between phase groups: 0 off (default), n = n * ~8k cycles */
 /* optional caller-owned device workspace for split-K weight gradients (>= split_k*M*N*4 bytes): partial tiles are
  * stored plainly and reduced in a second pass instead of fp32 atomics (bit-reproducible); NULL disables it */
 int uc2_gemm_set_workspace(void* ptr, size_t bytes);

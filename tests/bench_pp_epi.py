@@ -29,7 +29,7 @@ def main():
         for sk in (1, 2, 3):
             lib.uc2_gemm_set_skew(sk)
             row.append("v8 skew%d %6.1f" % (sk, 2.0 * M * n * k / timeit(fn) / 1e12))
-        lib.uc2_gemm_set_skew(-1)
+        lib.uc2_gemm_set_skew(0)
         lib.uc2_gemm_set_variant(-2)
         print("%-18s N=%5d K=%5d  " % (name, n, k) + "  ".join(row))
 

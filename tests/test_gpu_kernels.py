@@ -476,7 +476,7 @@ def test_gemm_pingpong_skew_and_deferred_reduce():
         lib.uc2_gemm_set_skew(2)
         o1 = ops.gemm(a, b, M, N, K, bias=bias, epi=ops.EPI_GELU, aux_out=pre1)
     finally:
-        lib.uc2_gemm_set_skew(-1)
+        lib.uc2_gemm_set_skew(0)
         lib.uc2_gemm_set_variant(-2)
     assert torch.equal(o0, o1) and torch.equal(pre0, pre1)
     # weight-gradient shape through ops (workspace registered there): fused vs deferred reduction
