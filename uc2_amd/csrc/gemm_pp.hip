@@ -506,6 +506,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
       int ln = lane;
       asm volatile("" : "+v"(ln));
       pp_epi_compute<EPI, HI>(p, acc, out, em0, en0, ln);
+      // pin the finished outputs here: otherwise hipcc sinks the aux-dependent arithmetic below the DMA issue that
+      // follows, and its wait for the aux loads (vmcnt is in order) becomes a wait for the whole next-item prologue
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+              if (!(hh == 1 && i >= HI)) asm volatile("" : "+v"(out.o[hh][i][j][g]));
       PP_STAMP(2);
       if (more) { setup(item); PP_PROLOGUE(); }
       PP_STAMP(3);
