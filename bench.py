@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- image-text pairs/s of one training step of the UC2 hot path on N MI355X.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps K --warmup W        # N > 1 without WORLD_SIZE: spawns the N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -12,28 +12,32 @@ embeddings -> 12 encoder layers -> pooler + ITM head -> loss -> full backward ->
 parameters.  Dropout 0.1 is ON, bf16 MFMA GEMMs with fp32 master weights, nothing is skipped.
 Inputs are resident in HBM before the timed region.  Weak scaling: per-GPU work is fixed.
 
-Prints ONE JSON line on rank 0 (metric contract in the task description) with two extra objects:
-  roofline     -- the dominant kernel (bf16 MFMA GEMM, forward NT instantiation) timed live with HIP
-                  events on its launch stream over the timed steps, against the dense bf16 MFMA peak
-  cpu_baseline -- the CPU oracle (oracle/uc2_oracle.py, kind "port") timed on the host cores on a
-                  bounded sample of the same workload (rank 0, N=1 only)
+Prints ONE JSON line on rank 0 (metric contract in the task description) with extra objects:
+  roofline      -- the dominant kernel (a bf16 MFMA GEMM instantiation) timed live with HIP events on its launch
+                   stream over the timed steps, against the dense bf16 MFMA peak; `traffic` is carried from the
+                   committed rocprofv3 PMC passes (profiles/), `hbm_kernels` are the HBM-bound kernels' GB/s
+  workloads     -- the same step on the MLM task, and the reference's own regime: 104-pair micro-batches x 3
+                   accumulation micro-steps per optimizer step (config/uc2_pretrain.json:17-19)
+  cpu_baseline  -- the CPU oracle (oracle/uc2_oracle.py, kind "port") timed on the host cores per BASELINE.md
+                   section 3: B = 32, median of 3 after one warm-up, ITM and MLM (rank 0, N = 1 only)
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-ENC_GFLOP_PER_PAIR = 49.94       # (24H^2 + 4LH) * L * 12 layers * 3 (fwd+bwd), SURVEY.md §8d
+PEAK_HBM_GBS = 8000.0            # HBM3E spec; ~6300 GB/s achievable (same guide)
+ENC_GFLOP_PER_PAIR = 49.94       # (24H^2 + 4LH) * L * 12 layers * 3 (fwd+bwd), SURVEY.md section 8d
 BASE = dict(vocab_size=250002, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
             intermediate_size=3072)
 T_TXT, N_REG, IMG_DIM = 60, 36, 2048
+REF_MICRO, REF_ACCUM = 104, 3    # config/uc2_pretrain.json:17-19 (10 240-token bucket / 96, 3 accumulation steps)
 
 
 def parse():
@@ -44,9 +48,27 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024, help="pairs per GPU per step")
     ap.add_argument("--task", default="itm", choices=["itm", "mlm"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--no-extras", action="store_true", help="skip the MLM and reference-regime workloads")
+    ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--layers", type=int, default=12, help=argparse.SUPPRESS)   # debugging only; 12 = the metric's config
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with no launcher: start N fresh rank processes through torch.distributed.run BEFORE
+    anything in this process touches the GPU (a process that has initialised HIP must never exec or fork workers),
+    relay their output, exit with their code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def make_cfg(layers):
@@ -60,7 +82,8 @@ def make_cfg(layers):
 
 
 def synth_batch(B, task, seed, device):
-    """CC-shaped synthetic batch (SURVEY.md §8d), generated directly on the device"""
+    """CC-shaped synthetic batch (SURVEY.md section 8d), generated directly on the device"""
+    import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     ids = torch.randint(5, BASE["vocab_size"], (B, T_TXT), generator=g, device=device)
@@ -88,8 +111,11 @@ def synth_batch(B, task, seed, device):
     return batch
 
 
-def cpu_baseline(task, B, layers):
-    """the CPU oracle on the host cores: fwd+bwd of the same workload on a bounded sample"""
+def cpu_baseline(B, layers):
+    """the CPU oracle on all host cores, B pairs, fwd+bwd of the same synthetic workload, one
+    warm-up + median of 3 timed iterations, ITM-only and MLM-only steps; bounded (an iteration slower than 25 s is
+    not repeated)"""
+    import torch
     from oracle import specs
     from oracle import uc2_oracle as O
     try:
@@ -104,6 +130,14 @@ def cpu_baseline(task, B, layers):
         pass
     cores = max(1, min(avail, 32))        # torch's CPU kernels stop scaling (and oversubscribe) beyond this
     torch.set_num_threads(cores)
+    cpu_model = "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
     geom = dict(BASE)
     geom["num_hidden_layers"] = layers
     cfg = O.Config.make(hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, **geom)
@@ -113,31 +147,41 @@ def cpu_baseline(task, B, layers):
         W[n] = (torch.randn(shp, generator=gen) * 0.02) if len(shp) > 1 else torch.zeros(shp)
         if "LayerNorm.weight" in n or "layer_norm.weight" in n or n.endswith("net.2.weight"):
             W[n] = torch.ones(shp)
-    batch = {k: v for k, v in synth_batch(B, task, 1, torch.device("cpu")).items()}
+    res = {}
+    for task in ("itm", "mlm"):
+        batch = synth_batch(B, task, 1, torch.device("cpu"))
 
-    def once():
-        Wg = {k: v.requires_grad_(True) for k, v in W.items()}
-        for v in Wg.values():
-            v.grad = None
-        l = O.pretrain_forward(Wg, cfg, batch, task, training=True)
-        l = l[0] if isinstance(l, tuple) else l
-        l.mean().backward()
-    t0 = time.perf_counter()
-    once()                                 # warm-up (also bounds the sample: a slow host keeps just this one)
-    t = time.perf_counter() - t0
-    n_timed = 0
-    while n_timed < 2 and t * (n_timed + 1) < 20.0:
+        def once():
+            Wg = {k: v.requires_grad_(True) for k, v in W.items()}
+            for v in Wg.values():
+                v.grad = None
+            l = O.pretrain_forward(Wg, cfg, batch, task, training=True)
+            l = l[0] if isinstance(l, tuple) else l
+            l.mean().backward()
         t0 = time.perf_counter()
-        once()
-        t = min(t, time.perf_counter() - t0) if n_timed else time.perf_counter() - t0
-        n_timed += 1
-    return {"value": round(B / t, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d pairs, %s step fwd+bwd (no optimizer), fp32, dropout 0.1, oracle/uc2_oracle.py, "
-                      "best of %d timed iteration(s) after 1 warm-up (%.2f s/iter)" % (B, task, n_timed, t)}
+        once()                             # warm-up
+        ts = [time.perf_counter() - t0]
+        n_timed = 0
+        while n_timed < 3 and (n_timed == 0 or ts[-1] < 25.0):
+            t0 = time.perf_counter()
+            once()
+            ts.append(time.perf_counter() - t0)
+            n_timed += 1
+        timed = sorted(ts[1:])
+        res[task] = (B / timed[len(timed) // 2], n_timed, timed[len(timed) // 2])
+    return {"value": round(res["itm"][0], 3), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "mlm_value": round(res["mlm"][0], 3), "cpu_model": cpu_model,
+            "sample": "B = %d pairs, fwd+bwd (no optimizer), fp32, dropout 0.1, oracle/uc2_oracle.py on %d threads; "
+                      "one warm-up, median of %d (ITM, %.2f s/iter) and %d (MLM, %.2f s/iter) timed iterations; `value` is "
+                      "the ITM step, `mlm_value` the MLM step" % (B, cores, res["itm"][1], res["itm"][2], res["mlm"][1],
+                                                                  res["mlm"][2])}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
+    import torch
     import torch.distributed as dist
     from uc2_amd import ops
     from uc2_amd.model.model import VLXLMRForPretraining
@@ -152,6 +196,9 @@ def main():
     ndev = torch.cuda.device_count()
     # UC2_DIST_BACKEND=gloo lets several ranks share one GPU (functional check of the N>1 path on a 1-GPU box)
     backend = os.environ.get("UC2_DIST_BACKEND", "nccl")
+    if world > ndev and backend == "nccl":
+        raise SystemExit("bench.py: %d ranks but %d GPUs visible (set UC2_DIST_BACKEND=gloo to share a GPU for a "
+                         "functional check)" % (world, ndev))
     dev = torch.device("cuda", local % max(ndev, 1))
     torch.cuda.set_device(dev)
     if world > 1:
@@ -162,8 +209,6 @@ def main():
             dist.init_process_group(backend)
     assert world == a.gpus, "--gpus %d but WORLD_SIZE %d" % (a.gpus, world)
 
-    if os.environ.get("UC2_GEMM_SKEW"):                     # A/B knob (tests/ab_skew.py)
-        ops._lib.call("uc2_gemm_set_skew", int(os.environ["UC2_GEMM_SKEW"]))
     ops.rng.manual_seed(20260101 + rank, dev)              # dropout streams differ per rank
     torch.manual_seed(0)                                   # weights seed 0 (random init, N(0, 0.02))
     model = VLXLMRForPretraining(make_cfg(a.layers), img_dim=IMG_DIM, img_label_dim=1601)
@@ -173,46 +218,92 @@ def main():
     broadcast_tensors([p.data for p in model.parameters()], 0)        # pretrain.py:457
     opt = AdamW(param_groups(model, 0.01), lr=4e-5, betas=(0.9, 0.98))
     sync = GradSync(model) if world > 1 else None
-    batches = [synth_batch(a.batch, a.task, 1000 * (rank + 1) + i, dev) for i in range(2)]
     st.sync_shadow()
     st.auto_sync = False            # AdamW rewrites the bf16 copies in its own pass from here on
 
-    def step(i):
-        b = batches[i % len(batches)]
-        if sync is not None:
-            sync.arm()
-        loss = model(b, a.task, compute_loss=True)
-        loss = loss[0] if isinstance(loss, tuple) else loss
-        loss.mean().backward()
+    def opt_step(micro_batches, task):
+        """one optimizer step over `micro_batches` (gradients summed, pretrain.py:553-559); the all-reduce is armed
+        for the last micro-step only (delay_unscale, pretrain.py:556-566)"""
+        loss = None
+        for j, b in enumerate(micro_batches):
+            if sync is not None and j == len(micro_batches) - 1:
+                sync.arm()
+            loss = model(b, task, compute_loss=True)
+            loss = loss[0] if isinstance(loss, tuple) else loss
+            loss.mean().backward()
         grads = [p.grad.data for p in model.parameters() if p.requires_grad and p.grad is not None]
         all_reduce_and_rescale_tensors(grads, float(1))              # pretrain.py:564-566
         _, coef = clip_grad_norm_([p for p in model.parameters() if p.grad is not None], 5.0, fused=True)
         opt.step(grad_scale=coef, zero_grad=True)
         return loss
 
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, warmup, steps):
+        """W untimed + EXACTLY K timed calls of fn(i), bracketed by barrier + synchronize; max over ranks"""
+        for i in range(warmup):
+            fn(i)
+        fence()
+        t0 = time.perf_counter()
+        out = None
+        for i in range(steps):
+            out = fn(warmup + i)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt, out
+
+    # ------------------------------------------------------------------ headline: --task at --batch pairs per step
+    batches = [synth_batch(a.batch, a.task, 1000 * (rank + 1) + i, dev) for i in range(2)]
     for i in range(a.warmup):
-        step(i)
-    timer = ops.GemmTimer()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ops.GEMM_TIMER = timer
+        opt_step([batches[i % 2]], a.task)
+    gtimer, htimer = ops.GemmTimer(), ops.HbmTimer()
+    fence()
+    ops.GEMM_TIMER, ops.HBM_TIMER = gtimer, htimer
     t0 = time.perf_counter()
     for i in range(a.steps):
-        loss = step(a.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+        loss = opt_step([batches[(a.warmup + i) % 2]], a.task)
+    fence()
     dt = time.perf_counter() - t0
-    ops.GEMM_TIMER = None
+    ops.GEMM_TIMER, ops.HBM_TIMER = None, None
     if world > 1:
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     lossv = float(loss.mean().item())
     assert lossv == lossv, "loss is NaN"
+
+    # ------------------------------------------------------------------ other workloads (extra keys, not `value`)
+    workloads = {}
+    if not a.no_extras and a.layers == 12:
+        k2, w2 = min(a.steps, 5), min(a.warmup, 2)
+        other = "mlm" if a.task == "itm" else "itm"
+        del batches
+        ob = [synth_batch(a.batch, other, 5000 * (rank + 1) + i, dev) for i in range(2)]
+        d2, _ = timed(lambda i: opt_step([ob[i % 2]], other), w2, k2)
+        workloads[other] = {"pairs_per_s": round(a.batch * world * k2 / d2, 1), "ms_per_step": round(d2 / k2 * 1e3, 2),
+                            "pairs_per_gpu_per_step": a.batch, "steps": k2,
+                            "note": "same step on the %s task (12/33 of the pretrain mix is MLM)" % other.upper()}
+        del ob
+        rb = {t: [synth_batch(REF_MICRO, t, 9000 * (rank + 1) + i, dev) for i in range(REF_ACCUM)] for t in ("itm", "mlm")}
+        for t in ("itm", "mlm"):
+            d3, _ = timed(lambda i: opt_step(rb[t], t), max(w2, 2), k2)
+            workloads["reference_regime_" + t] = {
+                "pairs_per_s": round(REF_MICRO * REF_ACCUM * world * k2 / d3, 1), "ms_per_optimizer_step": round(d3 / k2 * 1e3, 2),
+                "micro_batch_pairs": REF_MICRO, "accumulation_steps": REF_ACCUM, "steps": k2,
+                "mfma_frac_encoder": round(REF_MICRO * REF_ACCUM * world * k2 / d3 * ENC_GFLOP_PER_PAIR * 1e9
+                                           / (world * PEAK_BF16_TFLOPS * 1e12), 4),
+                "note": "the reference's own regime: %d-pair micro-batches x %d accumulation micro-steps per optimizer step "
+                        "(config/uc2_pretrain.json:17-19), all-reduce + clip + AdamW once per window" % (REF_MICRO, REF_ACCUM)}
+        del rb
+
     in_sync = True
     if world > 1:          # data-parallel invariant: every replica holds bit-identical weights after the steps
         cs = st.data.double().sum().reshape(1)
@@ -227,18 +318,22 @@ def main():
     if rank == 0:
         pairs = a.batch * world * a.steps
         value = pairs / dt
-        groups = timer.summary()
+        groups = gtimer.summary()
         kname, n_l, fl, sec = groups[0] if groups else ("none", 0, 0.0, 0.0)
         ach = fl / sec / 1e12 if sec > 0 else 0.0
         all_f = sum(g[2] for g in groups)
         all_t = sum(g[3] for g in groups)
-        traffic = None
-        try:        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
+        traffic, traffic_src = None, None
+        try:        # HBM bytes per launch of the dominant kernel: NOT measured in this run -- carried from the committed
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))      # rocprofv3 --pmc passes
             if pm.get("kernel", "").replace(" ", "") == kname.replace(" ", ""):
                 traffic = pm.get("hbm_bytes_per_launch")
+                traffic_src = "carried from profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate " \
+                              "passes, round %s), not measured in this run" % pm.get("round", "?")
         except Exception:
             pass
+        hbm = [{"kernel": n, "launches": c, "GB_per_s": round(b / t / 1e9, 1), "frac_of_8TBs": round(b / t / 1e9 / PEAK_HBM_GBS, 3),
+                "ms_per_step": round(t / a.steps * 1e3, 2)} for (n, c, b, t) in htimer.summary() if t > 0]
         out = {
             "metric": "image-text pairs/sec fwd+bwd, 12L/768H seq_len=96",
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -255,17 +350,19 @@ def main():
             "mfma_frac_encoder": round(value * ENC_GFLOP_PER_PAIR * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "launches": n_l, "avg_us": round(sec / max(n_l, 1) * 1e6, 2),
                          "all_gemm_kernels": {"achieved": round(all_f / all_t / 1e12, 1) if all_t > 0 else 0.0,
                                               "share_of_step_time": round(all_t / dt, 3),
                                               "by_kernel": [{"kernel": g[0], "launches": g[1],
                                                              "tflops": round(g[2] / g[3] / 1e12, 1),
                                                              "ms_per_step": round(g[3] / a.steps * 1e3, 2)}
-                                                            for g in groups[:6]]}},
+                                                            for g in groups[:8]]},
+                         "hbm_kernels": hbm},
+            "workloads": workloads,
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.task, a.cpu_batch, a.layers)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.layers)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -47,31 +47,41 @@ int uc2_device_info(int* cu_count, int* clock_khz, char* arch, int arch_len);
  *   gradient of the layer whose pre-activation gradient this is), ADD (+ aux_in), TANH.  c_is_f32: fp32 output for bf16 inputs. */
 int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
              void* C, int ldc, int c_is_f32, const float* bias, int epilogue, const void* aux_in, void* aux_out,
-             int ldaux, int accumulate, int split_k, void* stream);
-/* kernel selection knobs for A/B tests (tests/bench_gemm.py): not needed in production */
-int uc2_gemm_force_generic(int on);
-int uc2_gemm_set_variant(int variant);
-int uc2_gemm_set_fetch_only(int diagnostic_mode);
-int uc2_gemm_set_skew(int step);        /* ping-pong kernel start skew between phase groups: 0 off (default), n = n * ~8k cycles */
-/* optional caller-owned device workspace for split-K weight gradients (>= split_k*M*N*4 bytes): partial tiles are
- * stored plainly and reduced in a second pass instead of fp32 atomics (bit-reproducible); NULL disables it */
-int uc2_gemm_set_workspace(void* ptr, size_t bytes);
-/* profiling aid: with defer on, uc2_gemm stops after the partial tiles and the caller runs the reduction pass itself */
-int uc2_gemm_defer_reduce(int on);
-int uc2_gemm_splitk_reduce(int M, int N, void* C, int ldc, int split_k, int accumulate, void* stream);
+             int ldaux, int accumulate, int split_k, int variant, void* workspace, size_t workspace_bytes, int flags,
+             void* stream);
+/* Per-call plan -- the library keeps NO process-global kernel-selection state and reads no environment variables:
+ *   variant    UC2_GEMM_AUTO = the library's default kernel for the shape; UC2_GEMM_GENERIC = the register-staged
+ *              kernel (any shape/alignment); 0..9 = one specific kernel (0-2 LDS-DMA rings, 6/7 wave-specialised
+ *              rings, 8 = persistent ping-pong 256x256, 9 = ping-pong with 192-row tiles).  A variant that does not
+ *              support the shape falls back to the generic kernel.  uc2_amd/ops.py::gemm_plan picks it per shape.
+ *   workspace  optional caller-owned device memory (>= split_k*M*N*4 bytes, 16-byte aligned) for split-K weight
+ *              gradients: partial tiles are stored plainly and reduced in a second pass instead of fp32 atomics
+ *              (bit-reproducible); NULL = atomics.
+ *   flags      UC2_GEMM_DEFER_REDUCE: stop after the partial tiles, the caller runs uc2_gemm_splitk_reduce itself
+ *              (lets a profiler time the two passes separately); UC2_GEMM_SKEW(n): ping-pong start skew between phase
+ *              groups, n * ~8k cycles; UC2_GEMM_DIAG(m): diagnostic launch modes (tests/bench_pp.py), 0 in production. */
+enum { UC2_GEMM_AUTO = -2, UC2_GEMM_GENERIC = 99 };
+enum { UC2_GEMM_DEFER_REDUCE = 1 };
+#define UC2_GEMM_SKEW(n) (((n) & 15) << 4)
+#define UC2_GEMM_DIAG(m) (((m) & 0xFFF) << 8)
+int uc2_gemm_splitk_reduce(int M, int N, void* C, int ldc, int split_k, int accumulate, const void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 /* ---- LayerNorm fused with dropout + residual (apex FusedLayerNorm, model/layer.py:25; the dense->dropout->
  *      LayerNorm(x + residual) tails at model/layer.py:111-115,152-156; embeddings model/model.py:331,358-362) -----
- *   y = LN(dropout(x) + residual) * gamma + beta ; mean/rstd [M] saved for the backward.
+ *   drop_after == 0: y = LN(dropout(x) + residual) * gamma + beta     (encoder tails, model/layer.py:113-114,154-155)
+ *   drop_after == 1: y = dropout(LN(x + residual) * gamma + beta)     (embedding tails, model/model.py:331-333,361-363)
+ *   mean/rstd [M] saved for the backward.
  *   backward: dx (grad of x), dres (grad of residual; may be NULL; equals dx when drop_p == 0), dgamma/dbeta
  *   accumulated (+=), and optionally dbias += column-sum(dx) = bias gradient of the dense layer producing x. */
 int uc2_ln_fwd(int dtype, int M, int H, const void* x, const void* residual, const float* gamma, const float* beta,
-               float eps, float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, void* y, float* mean,
-               float* rstd, void* stream);
+               float eps, float drop_p, int drop_after, const uint64_t* seed_ptr, uint64_t seed_imm, void* y,
+               float* mean, float* rstd, void* stream);
 size_t uc2_ln_bwd_workspace(int M, int H);
 int uc2_ln_bwd(int dtype, int M, int H, const void* dy, const void* x, const void* residual, const float* gamma,
-               const float* mean, const float* rstd, float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm,
-               void* dx, void* dres, float* dgamma, float* dbeta, float* dbias, void* ws, void* stream);
+               const float* mean, const float* rstd, float drop_p, int drop_after, const uint64_t* seed_ptr,
+               uint64_t seed_imm, void* dx, void* dres, float* dgamma, float* dbeta, float* dbias, void* ws,
+               void* stream);
 
 /* ---- fused scaled-dot-product attention over the packed QKV projection (BertSelfAttention.forward,
  *      model/layer.py:75-101; additive key mask model/model.py:433-436) --------------------------------------------
@@ -92,7 +102,8 @@ int uc2_position_ids(int B, int T, const int64_t* ids, int64_t pad, int64_t* out
 int uc2_embed_fwd(int dtype, int rows, int H, const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
                   int type_const, const float* word, const float* pos, const float* type, void* out, void* stream);
 int uc2_embed_bwd(int dtype, int rows, int H, const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
-                  const void* dpre, float* dword, float* dpos, float* dtype_tab, void* stream);
+                  const void* dpre, float* dword, float* dpos, float* dtype_tab, int64_t word_pad, int64_t pos_pad,
+                  void* stream);     /* word_pad / pos_pad: nn.Embedding padding_idx rows get no gradient (-1 = none) */
 int uc2_add_rowvec(int a_dtype, int dtype, int rows, int H, const void* a, const void* b, const float* vec,
                    const uint8_t* rowmask, void* out, void* stream);
 int uc2_gather_rows_fwd(int dtype, int B, int S, int L, int H, const void* src, const int64_t* index, void* out,
@@ -101,8 +112,12 @@ int uc2_gather_rows_bwd(int dtype, int B, int S, int L, int H, const void* dout,
                         void* stream);
 
 /* ---- heads and losses (model/model.py:583-596, 653-657, 668-688, 697-732, 738-775; model/itm.py:45-53) ----- */
+/* scatter 0: dst[i] = src[rows[i]] (gather); 1: dst[rows[i]] = src[i]; 2: dst[rows[i]] += src[i] (rows unique) */
 int uc2_select_rows(int dtype, int n, int H, const void* src, int ld_src, const int64_t* rows, void* dst, int ld_dst,
                     int scatter, void* stream);
+/* fp32 vector gather (mode 0: dst[i] = src[idx[i]]) / scatter-add (mode 1: dst[idx[i]] += src[i], idx unique):
+ * the bias entries of the column subset kept by forward_mmxlm_soft (model/model.py:639-642) */
+int uc2_gather_f32(int n, const float* src, const int64_t* idx, float* dst, int mode, void* stream);
 int uc2_colsum_accum(int dtype, int M, int N, const void* X, int ldx, const uint8_t* rowmask, float* out,
                      void* stream);
 int uc2_ce_fwd(int dtype, int n, int V, const void* logits, int ld, const int64_t* labels, int64_t ignore_index,
@@ -118,6 +133,7 @@ int uc2_mse(int dtype, size_t n, const void* pred, const float* target, const fl
 int uc2_triplet(int dtype, int n, int sample_size, float margin, const void* score, const float* gout, float* loss,
                 void* dscore, void* stream);
 int uc2_dtanh(int dtype, size_t n, const void* y, const void* dy, void* dx, void* stream);
+int uc2_gelu(int dtype, size_t n, const void* x, void* y, void* stream);       /* model/layer.py:31-37, stand-alone */
 int uc2_dgelu(int dtype, size_t n, const void* pre, const void* dy, void* dx, void* stream);
 int uc2_cast(int from_dtype, int to_dtype, size_t n, const void* in, void* out, void* stream);
 

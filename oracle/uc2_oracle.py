@@ -44,6 +44,8 @@ class Config(dict):
 
 BASE = dict(vocab_size=250002, hidden_size=768, num_hidden_layers=12,
             num_attention_heads=12, intermediate_size=3072)       # config/uc2-base.json
+LARGE = dict(vocab_size=250002, hidden_size=1024, num_hidden_layers=24,
+             num_attention_heads=16, intermediate_size=4096)      # BASELINE.json configs[4] (XLM-R-large sizes; no reference config file)
 TINY = dict(vocab_size=1000, hidden_size=128, num_hidden_layers=2,
             num_attention_heads=4, intermediate_size=512)          # BASELINE.json configs[0]
 
@@ -145,8 +147,10 @@ def text_embeddings(input_ids, position_ids, W, cfg, token_type_ids=None,
         token_type_ids = torch.zeros_like(input_ids)
     if position_ids is None:
         position_ids = position_ids_from_input_ids(input_ids, cfg.pad_token_id)
-    e = (W[p + "word_embeddings.weight"][input_ids]
-         + W[p + "position_embeddings.weight"][position_ids]
+    # nn.Embedding(..., padding_idx=pad_token_id) for words AND positions (model/model.py:296-298): the
+    # padding row is read like any other but receives no gradient
+    e = (F.embedding(input_ids, W[p + "word_embeddings.weight"], padding_idx=cfg.pad_token_id)
+         + F.embedding(position_ids, W[p + "position_embeddings.weight"], padding_idx=cfg.pad_token_id)
          + W[p + "new_token_type_embeddings.weight"][token_type_ids])
     e = layer_norm(e, W[p + "LayerNorm.weight"], W[p + "LayerNorm.bias"], cfg.layer_norm_eps)
     return dropout(e, cfg.hidden_dropout_prob, training)
@@ -225,10 +229,99 @@ def masked_hidden(hidden, mask):
     return hidden[mask.unsqueeze(-1).expand_as(hidden)].contiguous().view(-1, hidden.size(-1))
 
 
-def pretrain_forward(W, cfg, batch, task, compute_loss=True, training=False):
+# --------------------------------------------------------------------------- #
+# optimal-transport regulariser of the ITM head (model/ot.py)
+# --------------------------------------------------------------------------- #
+def cost_matrix_cosine(x, y, eps=1e-5):
+    """model/ot.py:8-19: 1 - cosine similarity of every (x_i, y_j) pair, [B,Lx,D],[B,Ly,D] -> [B,Lx,Ly]."""
+    xn = F.normalize(x, p=2, dim=-1, eps=eps)
+    yn = F.normalize(y, p=2, dim=-1, eps=eps)
+    return 1 - xn.matmul(yn.transpose(1, 2))
+
+
+@torch.no_grad()
+def ipot(C, x_len, x_pad, y_len, y_pad, joint_pad, beta, iteration, k):
+    """model/ot.py:32-63: inexact proximal point iterations for the transport plan T [B,N,M]."""
+    b, m, n = C.size()
+    sigma = torch.ones(b, m, dtype=C.dtype) / x_len.unsqueeze(1)
+    T = torch.ones(b, n, m, dtype=C.dtype)
+    A = torch.exp(-C.transpose(1, 2) / beta)
+    sigma = sigma.masked_fill(x_pad, 0)
+    jp = joint_pad.transpose(1, 2)
+    T = T.masked_fill(jp, 0)
+    A = A.masked_fill(jp, 0)
+    x_len = x_len.unsqueeze(1).unsqueeze(2)
+    y_len = y_len.unsqueeze(1).unsqueeze(2)
+    x_mask = (x_pad.to(C.dtype) * 1e4).unsqueeze(1)
+    y_mask = (y_pad.to(C.dtype) * 1e4).unsqueeze(1)
+    for _ in range(iteration):
+        Q = A * T
+        sigma = sigma.view(b, m, 1)
+        for _ in range(k):
+            delta = 1 / (y_len * Q.matmul(sigma).view(b, 1, n) + y_mask)
+            sigma = 1 / (x_len * delta.matmul(Q) + x_mask)
+        T = delta.view(b, n, 1) * Q * sigma
+    return T.masked_fill(jp, 0)
+
+
+def optimal_transport_dist(txt_emb, img_emb, txt_pad, img_pad, beta=0.5, iteration=50, k=1):
+    """model/ot.py:66-82: trace(cost @ T) with T from IPOT on the detached cost."""
+    cost = cost_matrix_cosine(txt_emb, img_emb)
+    joint_pad = txt_pad.unsqueeze(-1) | img_pad.unsqueeze(-2)
+    cost = cost.masked_fill(joint_pad, 0)
+    txt_len = (txt_pad.size(1) - txt_pad.sum(dim=1)).to(cost.dtype)
+    img_len = (img_pad.size(1) - img_pad.sum(dim=1)).to(cost.dtype)
+    T = ipot(cost.detach(), txt_len, txt_pad, img_len, img_pad, joint_pad, beta, iteration, k)
+    return torch.diagonal(cost.matmul(T.detach()), dim1=1, dim2=2).sum(-1)
+
+
+def itm_ot_loss(seq, input_ids, img_feat, targets, ot_inputs, ot_pos_only=False):
+    """model/model.py:701-729: scatter the compact sequence back to [txt | img], OT distance per pair,
+    split by the ITM target."""
+    b, _, H = seq.shape
+    tl, il = input_ids.size(1), img_feat.size(1)
+    max_l = max(ot_inputs["scatter_max"] + 1, tl + il)
+    sc = ot_inputs["ot_scatter"].unsqueeze(-1).expand_as(seq)
+    ctx = torch.zeros(b, max_l, H, dtype=seq.dtype).scatter(1, sc, seq)
+    dist = optimal_transport_dist(ctx[:, :tl], ctx[:, tl:tl + il], ot_inputs["txt_pad"].bool(), ot_inputs["img_pad"].bool())
+    if ot_pos_only:
+        return dist.masked_select(targets == 1)
+    return dist.masked_select(targets == 1), dist.masked_select(targets == 0)
+
+
+def multi_head_attention(query, key, value, W, nheads, key_padding_mask=None, attn_mask=None):
+    """MultiheadAttention.forward / multi_head_attention_forward (model/attention.py:12-264) for the packed
+    in_proj case: (L,N,E) layout, q scaled by d^-1/2 BEFORE the product (:139), additive float attn_mask
+    [L,S] (:186-190), boolean key_padding_mask -> -inf (:222-229), dropout 0.  Returns (out (L,N,E),
+    head-averaged weights (N,L,S))."""
+    L, N, E = query.shape
+    S = key.shape[0]
+    d = E // nheads
+    Wi, bi = W["in_proj_weight"], W.get("in_proj_bias")
+    b3 = (lambda i: None if bi is None else bi[i * E:(i + 1) * E])
+    q = linear(query, Wi[:E], b3(0)) * (float(d) ** -0.5)
+    k = linear(key, Wi[E:2 * E], b3(1))
+    v = linear(value, Wi[2 * E:], b3(2))
+    q = q.contiguous().view(L, N * nheads, d).transpose(0, 1)
+    k = k.contiguous().view(S, N * nheads, d).transpose(0, 1)
+    v = v.contiguous().view(S, N * nheads, d).transpose(0, 1)
+    w = torch.bmm(q, k.transpose(1, 2))
+    if attn_mask is not None:
+        w = w + attn_mask.unsqueeze(0)
+    if key_padding_mask is not None:
+        w = w.view(N, nheads, L, S).masked_fill(key_padding_mask[:, None, None, :], float("-inf")).view(N * nheads, L, S)
+    w = torch.softmax(w, dim=-1)
+    o = torch.bmm(w, v).transpose(0, 1).contiguous().view(L, N, E)
+    o = linear(o, W["out_proj.weight"], W.get("out_proj.bias"))
+    return o, w.view(N, nheads, L, S).sum(dim=1) / nheads
+
+
+VALID_XLMR_TOKEN_IDS = list(range(5, 50))     # stand-in for model/const_variable.py (tokenizer download), as in the fixtures
+
+
+def pretrain_forward(W, cfg, batch, task, compute_loss=True, training=False, ot_pos_only=False):
     """VLXLMRForPretraining.forward, model/model.py:495-775.  Returns what the
-    reference returns: unreduced losses, or raw scores when compute_loss=False.
-    (OT branch and the *-soft tasks are outside the hot path: SURVEY.md §2.1.)"""
+    reference returns: unreduced losses, or raw scores when compute_loss=False."""
     g = lambda k: batch.get(k, None)
     input_ids = g("input_ids")
     position_ids = g("position_ids") if task == "tlm" else None
@@ -259,12 +352,23 @@ def pretrain_forward(W, cfg, batch, task, compute_loss=True, training=False):
         if compute_loss:
             return F.mse_loss(pred, g("feat_targets"), reduction="none")
         return pred
+    if task in ("mmxlm-soft", "vmlm-soft"):
+        # forward_mmxlm_soft, model/model.py:627-651
+        seq = model_forward(W, cfg, input_ids, position_ids, img_feat, img_pos_feat, am, gi,
+                            img_masks=g("img_masks"), training=training)
+        scores = lm_head(masked_hidden(seq, g("tgt_masks")), W, cfg)[:, VALID_XLMR_TOKEN_IDS]
+        if compute_loss:
+            return F.kl_div(F.log_softmax(scores, dim=-1), g("label_targets"), reduction="none")
+        return scores
     if task == "itm":
         seq = model_forward(W, cfg, input_ids, position_ids, img_feat, img_pos_feat, am, gi, training=training)
         scores = linear(pooler(seq, W), W["itm_output.weight"], W["itm_output.bias"])
+        ot_loss = None
+        if g("ot_inputs") is not None:
+            ot_loss = itm_ot_loss(seq, input_ids, img_feat, g("targets"), g("ot_inputs"), ot_pos_only)
         if compute_loss:
-            return F.cross_entropy(scores, g("targets"), reduction="none"), None
-        return scores, None
+            return F.cross_entropy(scores, g("targets"), reduction="none"), ot_loss
+        return scores, ot_loss
     if task.startswith("mrc"):
         seq = model_forward(W, cfg, input_ids, position_ids, img_feat, img_pos_feat, am, gi,
                             img_masks=g("img_masks"), training=training)

@@ -41,22 +41,18 @@ def main():
         fn = lambda: ops.gemm(a, b, m, n, k, ta=ta, tb=tb, out=out, accumulate=wg, split_k=split)
         for rep in range(2):
             for v in VARIANTS:
-                lib.uc2_gemm_set_variant(v)
-                t = timeit(fn)
+                with ops.force_variant(v):
+                    t = timeit(fn)
                 if rep == 1:
                     res.append(2.0 * m * n * k / t / 1e12)
         diag = {}
         for mode, label in ((1, "fetch only"), (17, "fetch + epilogue"), (32, "compute only (ws)")):
-            lib.uc2_gemm_set_fetch_only(mode)
             diag[label] = []
             for v in VARIANTS:
-                lib.uc2_gemm_set_variant(v)
-                diag[label].append(2.0 * m * n * k / timeit(fn) / 1e12)
-        lib.uc2_gemm_set_fetch_only(0)
-        lib.uc2_gemm_force_generic(1)
-        tg = 2.0 * m * n * k / timeit(fn) / 1e12
-        lib.uc2_gemm_force_generic(0)
-        lib.uc2_gemm_set_variant(-2)
+                with ops.force_variant(v, flags=mode << 8):
+                    diag[label].append(2.0 * m * n * k / timeit(fn) / 1e12)
+        with ops.force_variant(ops.GEMM_GENERIC):
+            tg = 2.0 * m * n * k / timeit(fn) / 1e12
         print("%s M=%6d N=%5d K=%6d split=%2d  " % (name, m, n, k, split) + " ".join("v%d %6.1f" % (v, r) for v, r in zip(VARIANTS, res)) + "  generic %6.1f" % tg)
         for label, fo in diag.items():
             print("      %-16s (equivalent TF/s):           " % label + " ".join("v%d %6.1f" % (v, r) for v, r in zip(VARIANTS, fo)))

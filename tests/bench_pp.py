@@ -23,16 +23,12 @@ def main():
         wg = ta and tb
         out = torch.zeros((m, n), dtype=torch.float32 if wg else torch.bfloat16, device="cuda")
         split = 9 if wg else 1
-        fn = lambda: ops.gemm(a, b, m, n, k, ta=ta, tb=tb, out=out, accumulate=wg, split_k=split)
         row = []
         for v in variants:
-            lib.uc2_gemm_set_variant(v)
             for mode in (0, 8, 64, 8 + 32, 8 + 128, 8 + 32 + 128):
-                lib.uc2_gemm_set_fetch_only(mode)
+                fn = lambda: ops.gemm(a, b, m, n, k, ta=ta, tb=tb, out=out, accumulate=wg, split_k=split, variant=v, flags=mode << 8)
                 t = timeit(fn)
                 row.append("v%d/%s %6.1f" % (v, {0: "full", 8: "loop", 64: "epi", 40: "loop-nodma", 136: "loop-nord", 168: "loop-mfma"}[mode], 2.0 * m * n * k / t / 1e12))
-        lib.uc2_gemm_set_fetch_only(0)
-        lib.uc2_gemm_set_variant(-2)
         print("%-11s M=%6d N=%5d K=%6d  " % (name, m, n, k) + "  ".join(row))
 
 if __name__ == "__main__":

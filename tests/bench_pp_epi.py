@@ -21,16 +21,12 @@ def main():
         fn = lambda: ops.gemm(a, b, M, n, k, tb=tb, out=out, bias=bias, epi=epi,
                               aux_in=aux if epi in (ops.EPI_ADD, ops.EPI_DGELU) else None, aux_out=pre)
         row = []
-        lib.uc2_gemm_set_skew(0)
         for v in (8, 9, 7, 2):
-            lib.uc2_gemm_set_variant(v)
-            row.append("v%d %6.1f" % (v, 2.0 * M * n * k / timeit(fn) / 1e12))
-        lib.uc2_gemm_set_variant(8)
+            with ops.force_variant(v):
+                row.append("v%d %6.1f" % (v, 2.0 * M * n * k / timeit(fn) / 1e12))
         for sk in (1, 2, 3):
-            lib.uc2_gemm_set_skew(sk)
-            row.append("v8 skew%d %6.1f" % (sk, 2.0 * M * n * k / timeit(fn) / 1e12))
-        lib.uc2_gemm_set_skew(0)
-        lib.uc2_gemm_set_variant(-2)
+            with ops.force_variant(8, flags=sk << 4):
+                row.append("v8 skew%d %6.1f" % (sk, 2.0 * M * n * k / timeit(fn) / 1e12))
         print("%-18s N=%5d K=%5d  " % (name, n, k) + "  ".join(row))
 
 if __name__ == "__main__":

@@ -14,9 +14,6 @@ for name, m, n in [("qkv", 2304, 768), ("ffn1", 3072, 768), ("ffn2", 768, 3072),
     for v in (0, 1, 99):
         res = []
         for split in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
-            if v == 99: lib.uc2_gemm_force_generic(1)
-            else: lib.uc2_gemm_force_generic(0); lib.uc2_gemm_set_variant(v)
-            fn = lambda: ops.gemm(a, b, m, n, M, ta=True, tb=True, out=out, accumulate=True, split_k=split)
+            fn = lambda: ops.gemm(a, b, m, n, M, ta=True, tb=True, out=out, accumulate=True, split_k=split, variant=v)
             res.append("%d:%.0f" % (split, 2.0 * m * n * M / timeit(fn, 10) / 1e12))
         print("wgrad %-5s M'=%d N'=%d K'=%d  %s  %s" % (name, m, n, M, "generic" if v == 99 else "v%d" % v, " ".join(res)))
-lib.uc2_gemm_force_generic(0); lib.uc2_gemm_set_variant(-2)

@@ -268,8 +268,138 @@ def case_base(mm, out):
     run_pretrain_case(mm, BASE, 4, 60, 36, ["itm", "mlm"], "base4", out, False)
 
 
+LARGE = dict(vocab_size=250002, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+             intermediate_size=4096)
+
+
+def case_large(mm, out):
+    """BASELINE.json configs[4] geometry (no reference config file exists: VLXLMRConfig.from_dict with the
+    XLM-R-large sizes): 24L/1024H/16 heads/4096 FFN, 80 tokens + 50 regions (L = 130), B = 2"""
+    run_pretrain_case(mm, LARGE, 2, 80, 50, ["itm", "mlm"], "large2", out, False)
+
+
+def install_uint8_mask_shim():
+    """model/ot.py:27-29 indexes with a uint8 eye mask; torch >= 2 only accepts bool masks there.  Cast uint8 masks to
+    bool inside masked_select (the torch 1.x meaning of a uint8 mask), nothing else changes."""
+    orig = torch.Tensor.masked_select
+
+    def masked_select(self, mask):
+        return orig(self, mask.bool() if mask.dtype == torch.uint8 else mask)
+    torch.Tensor.masked_select = masked_select
+
+
+def case_more(mm, out):
+    """round-2 additions: the task / branch holes of the first fixture set"""
+    install_uint8_mask_shim()
+    cfg = ref_config(mm, TINY)
+    model = mm.VLXLMRForPretraining(cfg, img_dim=2048, img_label_dim=1601)
+    synth.det_init_(model)
+    model.train()
+    # ---- tlm (batch position_ids, model/model.py:498-499), tlm-ni (text only, :513-518), variable length
+    for task in ("tlm", "tlm-ni"):
+        b = strip(synth.make_batch(1000, 8, 32, 36, task=task, seed=1, variable_len=True))
+        key = "tiny8var/%s" % task
+        out[key + "/position_ids"] = b["position_ids"].numpy()
+        model.zero_grad()
+        loss = model(b, task, compute_loss=True)
+        scores = model(b, task, compute_loss=False)
+        out[key + "/argmax"] = scores.argmax(-1).numpy()
+        put(out, key + "/scores", scores)
+        put(out, key + "/loss", loss, full=True)
+        loss.mean().backward()
+        grads_to(out, key, model)
+        print("  %s: loss.mean=%.6f" % (key, loss.mean().item()))
+    # ---- vmlm-soft (model/model.py:627-651): KL over the VALID_XLMR_TOKEN_IDS columns of the MLM head
+    b = strip(synth.make_batch(1000, 8, 32, 36, task="vmlm-soft", seed=1, n_soft=len(VALID_IDS)))
+    key = "tiny8/vmlm-soft"
+    model.zero_grad()
+    loss = model(b, "vmlm-soft", compute_loss=True)
+    scores = model(b, "vmlm-soft", compute_loss=False)
+    put(out, key + "/scores", scores, full=True)
+    put(out, key + "/loss", loss, full=True)
+    (1000 * loss.mean()).backward()                  # pretrain.py:549-550
+    grads_to(out, key, model)
+    print("  %s: loss.mean=%.6f" % (key, loss.mean().item()))
+    # ---- ITM with the OT regulariser (model/model.py:701-729, model/ot.py), variable length, both ot_pos_only settings
+    b = strip(synth.make_batch(1000, 8, 32, 36, task="itm", seed=1, variable_len=True, ot=True))
+    for pos_only in (False, True):
+        key = "tiny8var/itm-ot%s" % ("-pos" if pos_only else "")
+        model.ot_pos_only = pos_only
+        model.zero_grad()
+        itm_loss, ot_loss = model(b, "itm", compute_loss=True)
+        put(out, key + "/loss", itm_loss, full=True)
+        if pos_only:
+            put(out, key + "/ot", ot_loss, full=True)
+            ot = ot_loss.mean()
+        else:
+            put(out, key + "/ot_pos", ot_loss[0], full=True)
+            put(out, key + "/ot_neg", ot_loss[1], full=True)
+            ot = (ot_loss[0].sum() - ot_loss[1].sum()) / (ot_loss[0].size(0) + ot_loss[1].size(0))   # pretrain.py:531-533
+        (itm_loss.mean() + 0.1 * ot).backward()      # itm_ot_lambda = 0.1
+        grads_to(out, key, model)
+        print("  %s: itm %.6f ot %.6f" % (key, itm_loss.mean().item(), ot.item()))
+    model.ot_pos_only = False
+    # ---- VLXLMRModel.forward text-only and image-only branches (model/model.py:439-446), variable length
+    b = strip(synth.make_batch(1000, 8, 32, 36, task="mrfr", seed=3, variable_len=True))
+    R = model.roberta
+    T = b["input_ids"].shape[1]
+    tl, nb = synth.make_batch(1000, 8, 32, 36, task="mrfr", seed=3, variable_len=True)["_txt_lens"], None
+    am_t = (torch.arange(T).unsqueeze(0) < torch.tensor(tl).unsqueeze(1)).long()
+    nbs = synth.make_batch(1000, 8, 32, 36, task="mrfr", seed=3, variable_len=True)["_num_bbs"]
+    am_i = (torch.arange(b["img_feat"].shape[1]).unsqueeze(0) < torch.tensor(nbs).unsqueeze(1)).long()
+    model.zero_grad()
+    seq_t = R(b["input_ids"], None, None, None, am_t, output_all_encoded_layers=False)
+    put(out, "txtonly/seq", seq_t, full=True)
+    (seq_t * synth.det_normal(tuple(seq_t.shape), 55)).sum().backward()
+    grads_to(out, "txtonly", model)
+    model.zero_grad()
+    seq_i = R(None, None, b["img_feat"], b["img_pos_feat"], am_i, img_masks=b["img_masks"], output_all_encoded_layers=False)
+    put(out, "imgonly/seq", seq_i, full=True)
+    (seq_i * synth.det_normal(tuple(seq_i.shape), 56)).sum().backward()
+    grads_to(out, "imgonly", model)
+    # all layers + pooled (the stored pooled vector was not compared before)
+    layers = R(b["input_ids"], None, b["img_feat"], b["img_pos_feat"], b["attn_masks"], b["gather_index"],
+               img_masks=b["img_masks"], output_all_encoded_layers=True)
+    assert len(layers) == 2
+    put(out, "alllayers/0", layers[0], full=True)
+    put(out, "alllayers/1", layers[1], full=True)
+    # ---- MultiheadAttention input / weight gradients (model/attention.py:267-401)
+    att = importlib.import_module("model.attention")
+    E, nh, L, N = 128, 4, 10, 3
+    m = att.MultiheadAttention(E, nh, dropout=0.0)
+    synth.det_init_(m)
+    q = synth.det_normal((L, N, E), 77).requires_grad_(True)
+    kpm = torch.zeros(N, L, dtype=torch.bool)
+    kpm[1, 7:] = True
+    kpm[2, 4:] = True
+    o, w = m(q, q, q, key_padding_mask=kpm)
+    (o * synth.det_normal((L, N, E), 78)).sum().backward()
+    put(out, "mha/dq", q.grad, full=True)
+    for n, p in m.named_parameters():
+        put(out, "mha/grad/" + n, p.grad, full=p.numel() <= 70000)
+    # general variants: cross-attention with an additive attn_mask and separate key/value inputs
+    m2 = att.MultiheadAttention(E, nh, dropout=0.0)
+    synth.det_init_(m2)
+    S = 7
+    q2 = synth.det_normal((L, N, E), 80).requires_grad_(True)
+    k2 = synth.det_normal((S, N, E), 81).requires_grad_(True)
+    v2 = synth.det_normal((S, N, E), 82).requires_grad_(True)
+    amask = synth.det_normal((L, S), 83)
+    kpm2 = torch.zeros(N, S, dtype=torch.bool)
+    kpm2[2, 5:] = True
+    o2, w2 = m2(q2, k2, v2, key_padding_mask=kpm2, attn_mask=amask)
+    put(out, "mha_cross/out", o2, full=True)
+    put(out, "mha_cross/weights", w2, full=True)
+    (o2 * synth.det_normal((L, N, E), 84)).sum().backward()
+    put(out, "mha_cross/dq", q2.grad, full=True)
+    put(out, "mha_cross/dk", k2.grad, full=True)
+    put(out, "mha_cross/dv", v2.grad, full=True)
+    for n, p in m2.named_parameters():
+        put(out, "mha_cross/grad/" + n, p.grad, full=p.numel() <= 70000)
+
+
 def main():
-    which = sys.argv[1:] or ["tiny", "gather", "adamw", "mha", "base"]
+    which = sys.argv[1:] or ["tiny", "gather", "adamw", "mha", "base", "more", "large"]
     install_shims()
     sys.path.insert(0, REF)
     mm = importlib.import_module("model.model")
@@ -289,6 +419,10 @@ def main():
             case_mha(out)
         elif w == "base":
             case_base(mm, out)
+        elif w == "large":
+            case_large(mm, out)
+        elif w == "more":
+            case_more(mm, out)
         else:
             raise SystemExit("unknown case " + w)
         path = os.path.join(HERE, "golden_%s.npz" % w)

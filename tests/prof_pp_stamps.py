@@ -12,12 +12,9 @@ def main():
     b = torch.randn((k, n) if tb else (n, k), device="cuda").to(torch.bfloat16)
     out = torch.zeros((m, n), dtype=torch.bfloat16, device="cuda")
     dbg = torch.zeros((8, 16), dtype=torch.int32, device="cuda")
-    lib.uc2_gemm_set_variant(8)
-    lib.uc2_gemm_set_fetch_only(256)
     for _ in range(3):
-        ops.gemm(a, b, m, n, k, ta=ta, tb=tb, out=out, aux_out=dbg)
+        ops.gemm(a, b, m, n, k, ta=ta, tb=tb, out=out, aux_out=dbg, variant=8, flags=256 << 8)      # UC2_GEMM_DIAG(256): stamps
     torch.cuda.synchronize()
-    lib.uc2_gemm_set_fetch_only(0)
     t = dbg.cpu().numpy().astype("int64") & 0xffffffff
     for w in range(8):
         d = lambda i, j: int(t[w, i] - t[w, j])

@@ -130,6 +130,33 @@ def test_layernorm_dropout_consistency():
     assert torch.allclose(dx[keep], dres[keep] / (1 - p), rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_output_dropout(dtype):
+    """drop_after: y = dropout(LN(x + res)) -- the reference's embedding tails (model/model.py:331-333,361-363):
+    every element is either 0 or LN(x)/(1-p); the backward is the plain LN backward of the masked, rescaled dy"""
+    M, H, p = 260, 768, 0.1
+    x = rnd((M, H), 1, dtype=dtype)
+    g, b = (1 + 0.1 * rnd((H,), 3)), 0.5 + rnd((H,), 4, 0.1)
+    seed = torch.tensor([99], dtype=torch.int64, device=DEV)
+    y0, mean, rstd = ops.ln_fwd(x, None, g, b, 1e-5)
+    y, mean2, rstd2 = ops.ln_fwd(x, None, g, b, 1e-5, p, seed, 5, drop_after=True)
+    assert torch.equal(mean, mean2) and torch.equal(rstd, rstd2)          # statistics are those of the undropped input
+    keep = y != 0
+    rate = 1.0 - keep.float().mean().item()
+    assert abs(rate - p) < 0.01, rate
+    assert rel_err(y[keep].float(), y0[keep].float() / (1 - p)) < tol(dtype, 1e-6, 6e-3)
+    dy = rnd((M, H), 5, dtype=dtype)
+    dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    dx, dres = ops.ln_bwd(dy, x, None, g, mean, rstd, dg, db, p, seed, 5, drop_after=True)
+    xs = x.float().requires_grad_(True)
+    gs, bs = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xs, (H,), gs, bs, 1e-5)
+    ref.backward(dy.float() * keep.float() / (1 - p))
+    assert rel_err(dx.float(), xs.grad) < tol(dtype, 2e-5, 1e-2)
+    assert rel_err(dg, gs.grad) < tol(dtype, 2e-5, 1e-2)
+    assert rel_err(db, bs.grad) < tol(dtype, 2e-5, 1e-2)
+
+
 # ------------------------------------------------------------------------------------------ attention
 def attn_ref(qkv, mask, B, L, nh, D):
     H = nh * D
@@ -300,24 +327,20 @@ def test_attention_mfma_equals_simple_under_dropout(B, L, nh, D):
     assert rel_err(g2.float(), g1.float()) < 2e-2
 
 
+GENERIC = ops.GEMM_GENERIC
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 6, 7, 8])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 512, 1024), (2048, 768, 768), (1000, 768, 768), (776, 2304, 832), (128, 136, 64)])
 def test_gemm_pipelined_equals_generic(ta, tb, M, N, K, variant):
     """the LDS-DMA pipelined kernels (every tile/stage variant) and the generic register-staged kernel
-    compute the same bf16 result, bit for bit"""
-    lib = ops._lib.load()
-    lib.uc2_gemm_set_variant(variant)
+    compute the same bf16 result, bit for bit; the kernel is named per call (no library-global selection)"""
     a = rnd((K, M) if ta else (M, K), 1, dtype=torch.bfloat16)
     b = rnd((K, N) if tb else (N, K), 2, dtype=torch.bfloat16)
     bias = rnd((N,), 3)
-    try:
-        lib.uc2_gemm_force_generic(1)
-        ref = ops.gemm(a, b, M, N, K, ta=ta, tb=tb, bias=bias)
-        lib.uc2_gemm_force_generic(0)
-        out = ops.gemm(a, b, M, N, K, ta=ta, tb=tb, bias=bias)
-    finally:
-        lib.uc2_gemm_force_generic(0)
+    ref = ops.gemm(a, b, M, N, K, ta=ta, tb=tb, bias=bias, variant=GENERIC)
+    out = ops.gemm(a, b, M, N, K, ta=ta, tb=tb, bias=bias, variant=variant)
     if variant == 8:
         # the ping-pong kernel starts its accumulators at the bias (fp32 sum in a different order): 1 bf16 ulp
         assert rel_err(out.float(), ref.float()) < 2e-3 and (out.float() - ref.float()).abs().max() <= 0.0625 * ref.float().abs().max()
@@ -325,11 +348,9 @@ def test_gemm_pipelined_equals_generic(ta, tb, M, N, K, variant):
         assert torch.equal(out, ref)
     acc_ref = rnd((M, N), 4)
     acc = acc_ref.clone()
-    lib.uc2_gemm_force_generic(1)
-    ops.gemm(a, b, M, N, K, ta=ta, tb=tb, out=acc_ref, accumulate=True, split_k=2 if K >= 128 else 1)
-    lib.uc2_gemm_force_generic(0)
-    ops.gemm(a, b, M, N, K, ta=ta, tb=tb, out=acc, accumulate=True, split_k=2 if K >= 128 else 1)
-    lib.uc2_gemm_set_variant(-2)
+    sk = 2 if K >= 128 else 1
+    ops.gemm(a, b, M, N, K, ta=ta, tb=tb, out=acc_ref, accumulate=True, split_k=sk, variant=GENERIC)
+    ops.gemm(a, b, M, N, K, ta=ta, tb=tb, out=acc, accumulate=True, split_k=sk, variant=variant)
     assert rel_err(acc, acc_ref) < 1e-5
 
 
@@ -337,7 +358,6 @@ def test_gemm_pipelined_equals_generic(ta, tb, M, N, K, variant):
 @pytest.mark.parametrize("M,N,K", [(512, 768, 768), (1024, 256, 3072)])
 def test_gemm_pingpong_epilogues(epi, M, N, K):
     """ping-pong kernel (variant 8): every fused epilogue against the generic kernel"""
-    lib = ops._lib.load()
     tb = epi == "dgelu"
     a = rnd((M, K), 1, dtype=torch.bfloat16)
     b = rnd((K, N) if tb else (N, K), 2, 0.05, dtype=torch.bfloat16)
@@ -345,19 +365,13 @@ def test_gemm_pingpong_epilogues(epi, M, N, K):
     aux = rnd((M, N), 4, dtype=torch.bfloat16)
     code = {"none": ops.EPI_NONE, "gelu": ops.EPI_GELU, "add": ops.EPI_ADD, "tanh": ops.EPI_TANH, "dgelu": ops.EPI_DGELU}[epi]
 
-    def run():
+    def run(variant):
         pre = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV) if epi == "gelu" else None
-        o = ops.gemm(a, b, M, N, K, tb=tb, bias=bias, epi=code, aux_in=aux if epi in ("add", "dgelu") else None, aux_out=pre)
+        o = ops.gemm(a, b, M, N, K, tb=tb, bias=bias, epi=code, aux_in=aux if epi in ("add", "dgelu") else None, aux_out=pre,
+                     variant=variant)
         return o, pre
-    try:
-        lib.uc2_gemm_force_generic(1)
-        ref, ref_pre = run()
-        lib.uc2_gemm_force_generic(0)
-        lib.uc2_gemm_set_variant(8)
-        out, pre = run()
-    finally:
-        lib.uc2_gemm_force_generic(0)
-        lib.uc2_gemm_set_variant(-2)
+    ref, ref_pre = run(GENERIC)
+    out, pre = run(8)
     assert rel_err(out.float(), ref.float()) < 3e-3
     if pre is not None:
         assert rel_err(pre.float(), ref_pre.float()) < 3e-3
@@ -365,35 +379,22 @@ def test_gemm_pingpong_epilogues(epi, M, N, K):
 
 def test_gemm_pingpong_persistent():
     """more work items than CUs: every workgroup walks several tiles (next tile's staging overlaps the stores)"""
-    lib = ops._lib.load()
     M, N, K = 16384, 2304, 768            # 576 tiles
     a = rnd((M, K), 1, dtype=torch.bfloat16)
     b = rnd((N, K), 2, 0.05, dtype=torch.bfloat16)
     bias = rnd((N,), 3)
-    try:
-        lib.uc2_gemm_set_variant(7)
-        ref = ops.gemm(a, b, M, N, K, bias=bias)
-        lib.uc2_gemm_set_variant(8)
-        outs = [ops.gemm(a, b, M, N, K, bias=bias) for _ in range(5)]
-    finally:
-        lib.uc2_gemm_set_variant(-2)
+    ref = ops.gemm(a, b, M, N, K, bias=bias, variant=7)
+    outs = [ops.gemm(a, b, M, N, K, bias=bias, variant=8) for _ in range(5)]
     for o in outs:
         assert torch.equal(o, outs[0])                       # race screen: identical every run
         assert rel_err(o.float(), ref.float()) < 2e-3
-    # split-K weight-gradient shape: fp32 accumulate with atomics, several items per workgroup
+    # split-K weight-gradient shape: fp32 accumulate, several items per workgroup
     Mo, No, Kt = 768, 768, 32768
     x = rnd((Kt, Mo), 5, 0.1, dtype=torch.bfloat16)
     y = rnd((Kt, No), 6, 0.1, dtype=torch.bfloat16)
     acc0 = rnd((Mo, No), 7)
-    try:
-        lib.uc2_gemm_force_generic(1)
-        r = ops.gemm(x, y, Mo, No, Kt, ta=True, tb=True, out=acc0.clone(), accumulate=True, split_k=4)
-        lib.uc2_gemm_force_generic(0)
-        lib.uc2_gemm_set_variant(8)
-        o = ops.gemm(x, y, Mo, No, Kt, ta=True, tb=True, out=acc0.clone(), accumulate=True, split_k=64)
-    finally:
-        lib.uc2_gemm_force_generic(0)
-        lib.uc2_gemm_set_variant(-2)
+    r = ops.gemm(x, y, Mo, No, Kt, ta=True, tb=True, out=acc0.clone(), accumulate=True, split_k=4, variant=GENERIC)
+    o = ops.gemm(x, y, Mo, No, Kt, ta=True, tb=True, out=acc0.clone(), accumulate=True, split_k=64, variant=8)
     assert rel_err(o, r) < 1e-4
 
 
@@ -401,18 +402,13 @@ def test_gemm_pingpong_persistent():
 def test_gemm_dgelu_fused_colsum(variant):
     """EPI_DGELU with aux_out: the column sums of the result (bias gradient) come with the GEMM -- fused in the
     ping-pong kernel's epilogue, a second pass for the others; both must match an explicit column sum"""
-    lib = ops._lib.load()
     M, N, K = 1024, 512, 768
     dy = rnd((M, K), 1, dtype=torch.bfloat16)
     w = rnd((K, N), 2, 0.05, dtype=torch.bfloat16)
     pre = rnd((M, N), 3, dtype=torch.bfloat16)
     acc = rnd((N,), 4)
     got = acc.clone()
-    try:
-        lib.uc2_gemm_set_variant(variant)
-        out = ops.gemm(dy, w, M, N, K, tb=True, epi=ops.EPI_DGELU, aux_in=pre, aux_out=got)
-    finally:
-        lib.uc2_gemm_set_variant(-2)
+    out = ops.gemm(dy, w, M, N, K, tb=True, epi=ops.EPI_DGELU, aux_in=pre, aux_out=got, variant=variant)
     want = acc + out.float().sum(0)
     assert rel_err(got, want) < 2e-3
 
@@ -438,60 +434,46 @@ def test_attention_bwd_fused_bias_grad(impl, dtype, B, L, nh, D):
 @pytest.mark.parametrize("M,N,K", [(768, 768, 768), (1536, 256, 3072), (49152 // 4, 768, 768)])
 def test_gemm_pingpong_192_row_tiles(tb, epi, M, N, K):
     """variant 9 (192-row tiles, 7 LDS-DMA instructions per k-tile): against the generic kernel, twice (race screen)"""
-    lib = ops._lib.load()
     a = rnd((M, K), 1, dtype=torch.bfloat16)
     b = rnd((K, N) if tb else (N, K), 2, 0.05, dtype=torch.bfloat16)
     bias = None if tb else rnd((N,), 3)
     aux = rnd((M, N), 4, dtype=torch.bfloat16) if epi == "add" else None
     code = ops.EPI_ADD if epi == "add" else ops.EPI_NONE
-    run = lambda: ops.gemm(a, b, M, N, K, tb=tb, bias=bias, epi=code, aux_in=aux)
-    try:
-        lib.uc2_gemm_force_generic(1)
-        ref = run()
-        lib.uc2_gemm_force_generic(0)
-        lib.uc2_gemm_set_variant(9)
-        o1 = run()
-        o2 = run()
-    finally:
-        lib.uc2_gemm_force_generic(0)
-        lib.uc2_gemm_set_variant(-2)
+    run = lambda v: ops.gemm(a, b, M, N, K, tb=tb, bias=bias, epi=code, aux_in=aux, variant=v)
+    ref = run(GENERIC)
+    o1 = run(9)
+    o2 = run(9)
     assert torch.equal(o1, o2)
     assert rel_err(o1.float(), ref.float()) < 3e-3
 
 
 def test_gemm_pingpong_skew_and_deferred_reduce():
     """start skew between phase groups changes timing only; the split-K reduction pass run on its own
-    (uc2_gemm_defer_reduce + uc2_gemm_splitk_reduce) equals the fused call"""
-    lib = ops._lib.load()
+    (UC2_GEMM_DEFER_REDUCE + uc2_gemm_splitk_reduce) equals the fused call; without a workspace the same call
+    reduces with fp32 atomics (same result up to summation order)"""
     M, N, K = 8192, 768, 768
     a = rnd((M, K), 1, dtype=torch.bfloat16)
     b = rnd((N, K), 2, 0.05, dtype=torch.bfloat16)
     bias = rnd((N,), 3)
     pre0 = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
     pre1 = torch.zeros_like(pre0)
-    try:
-        lib.uc2_gemm_set_variant(8)
-        lib.uc2_gemm_set_skew(0)
-        o0 = ops.gemm(a, b, M, N, K, bias=bias, epi=ops.EPI_GELU, aux_out=pre0)
-        lib.uc2_gemm_set_skew(2)
-        o1 = ops.gemm(a, b, M, N, K, bias=bias, epi=ops.EPI_GELU, aux_out=pre1)
-    finally:
-        lib.uc2_gemm_set_skew(0)
-        lib.uc2_gemm_set_variant(-2)
+    o0 = ops.gemm(a, b, M, N, K, bias=bias, epi=ops.EPI_GELU, aux_out=pre0, variant=8)
+    o1 = ops.gemm(a, b, M, N, K, bias=bias, epi=ops.EPI_GELU, aux_out=pre1, variant=8, flags=2 << 4)     # UC2_GEMM_SKEW(2)
     assert torch.equal(o0, o1) and torch.equal(pre0, pre1)
-    # weight-gradient shape through ops (workspace registered there): fused vs deferred reduction
+    # weight-gradient shape through ops (which hands its workspace to the call): fused vs deferred reduction
     Mo, No, Kt = 768, 768, 16384
     x = rnd((Kt, Mo), 5, 0.1, dtype=torch.bfloat16)
     y = rnd((Kt, No), 6, 0.1, dtype=torch.bfloat16)
     acc = rnd((Mo, No), 7)
+    fused = ops.gemm(x, y, Mo, No, Kt, ta=True, tb=True, out=acc.clone(), accumulate=True, split_k=8, variant=8)
     try:
-        ops._CUR_VARIANT = 8
-        lib.uc2_gemm_set_variant(8)
-        fused = ops.gemm(x, y, Mo, No, Kt, ta=True, tb=True, out=acc.clone(), accumulate=True, split_k=8)
         ops.GEMM_TIMER = ops.GemmTimer()                 # the timer path defers the reduction pass
-        deferred = ops.gemm(x, y, Mo, No, Kt, ta=True, tb=True, out=acc.clone(), accumulate=True, split_k=8)
+        deferred = ops.gemm(x, y, Mo, No, Kt, ta=True, tb=True, out=acc.clone(), accumulate=True, split_k=8, variant=8)
     finally:
         ops.GEMM_TIMER = None
-        ops._CUR_VARIANT = -2
-        lib.uc2_gemm_set_variant(-2)
     assert torch.equal(fused, deferred)
+    # raw C-ABI call without a workspace: atomics
+    out = acc.clone()
+    ops.call("uc2_gemm", 1, 1, 1, Mo, No, Kt, ops.ptr(x), Mo, ops.ptr(y), No, ops.ptr(out), No, 1, None, 0, None, None, 0,
+             1, 8, 8, None, 0, 0, ops.stream())
+    assert rel_err(out, fused) < 1e-5

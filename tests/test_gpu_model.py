@@ -106,6 +106,29 @@ def test_bert_layer_dropout_runs_and_is_reproducible():
     assert torch.equal(layer(x, ext), layer(x, ext))
 
 
+def test_embedding_dropout_sits_after_layernorm():
+    """training mode, p > 0: the reference computes dropout(LayerNorm(emb)) (model/model.py:331-333,361-363), so every
+    embedding output element is 0 or eval_output / (1 - p)"""
+    p = 0.25
+    model = VLXLMRForPretraining(make_cfg(O.TINY, drop=p), img_dim=2048, img_label_dim=1601)
+    synth.det_init_(model)
+    model.to(DEV)
+    b = to_dev(synth.make_batch(1000, 6, 32, 36, task="mrfr", seed=4))
+    R = model.roberta
+    model.eval()
+    with torch.no_grad():
+        t0 = R._compute_txt_embeddings(b["input_ids"], None)
+        i0 = R._compute_img_embeddings(b["img_feat"], b["img_pos_feat"], b["img_masks"])
+    model.train()
+    with torch.no_grad():
+        t1 = R._compute_txt_embeddings(b["input_ids"], None)
+        i1 = R._compute_img_embeddings(b["img_feat"], b["img_pos_feat"], b["img_masks"])
+    for e0, e1 in ((t0, t1), (i0, i1)):
+        keep = e1 != 0
+        assert abs((1 - keep.float().mean().item()) - p) < 0.02
+        assert torch.allclose(e1[keep], e0[keep] / (1 - p), rtol=1e-5, atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------------ whole model vs golden
 def run_task(model, batch, task):
     b = to_dev(batch)
@@ -202,6 +225,207 @@ def test_pretrain_base_geometry_fp32_vs_golden(task):
         check_against_golden(g, "%s/grad/%s" % (key, name), P[name].grad, 3e-3)
     del model
     torch.cuda.empty_cache()
+
+
+def _grad_checks(g, key, model, tol, min_n=30, what=""):
+    n = 0
+    for name, p in model.named_parameters():
+        k = "%s/grad/%s" % (key, name)
+        if k + "/sum3" not in g.files:
+            continue
+        if name.endswith("key.bias"):                  # mathematically zero: rounding noise only
+            n += 1
+            continue
+        if float(g[k + "/sum3"][2]) < 1e-7:
+            assert p.grad is None or p.grad.norm().item() < 1e-5, name
+        else:
+            assert p.grad is not None, name
+            check_against_golden(g, k, p.grad, tol, what=what)
+        n += 1
+    assert n > min_n, n
+
+
+def test_more_tasks_fp32_vs_golden():
+    """round-2 fixtures from the reference: tlm (batch position_ids, model/model.py:498-499), tlm-ni (text-only
+    branch, :513-518), vmlm-soft (:627-651); variable length; losses 1e-3, argmax bit-exact, gradients 3e-3"""
+    g = golden("more")
+    model = build_pretrain(O.TINY, torch.float32)
+    for task in ("tlm", "tlm-ni"):
+        b = to_dev(synth.make_batch(1000, 8, 32, 36, task=task, seed=1, variable_len=True))
+        key = "tiny8var/%s" % task
+        model.zero_grad()
+        scores = model(b, task, compute_loss=False)
+        check_against_golden(g, key + "/scores", scores, TOL32)
+        assert np.array_equal(scores.argmax(-1).cpu().numpy(), g[key + "/argmax"])
+        model.zero_grad()
+        loss = model(b, task, compute_loss=True)
+        check_against_golden(g, key + "/loss", loss, TOL32)
+        loss.mean().backward()
+        _grad_checks(g, key, model, 3e-3, what=task)
+    b = to_dev(synth.make_batch(1000, 8, 32, 36, task="vmlm-soft", seed=1, n_soft=45))
+    key = "tiny8/vmlm-soft"
+    model.zero_grad()
+    check_against_golden(g, key + "/scores", model(b, "vmlm-soft", compute_loss=False), TOL32)
+    model.zero_grad()
+    loss = model(b, "vmlm-soft", compute_loss=True)
+    check_against_golden(g, key + "/loss", loss, TOL32)
+    (1000 * loss.mean()).backward()                     # pretrain.py:549-550
+    _grad_checks(g, key, model, 3e-3, what="vmlm-soft")
+
+
+def test_text_only_image_only_all_layers_fp32_vs_golden():
+    """VLXLMRModel.forward's text-only / image-only branches (model/model.py:439-446) with gradients (padding rows
+    of the embedding tables get none: nn.Embedding padding_idx), and output_all_encoded_layers=True"""
+    g = golden("more")
+    model = build_pretrain(O.TINY, torch.float32)
+    full = synth.make_batch(1000, 8, 32, 36, task="mrfr", seed=3, variable_len=True)
+    b = to_dev(full)
+    R = model.roberta
+    T, NR = b["input_ids"].shape[1], b["img_feat"].shape[1]
+    am_t = (torch.arange(T).unsqueeze(0) < torch.tensor(full["_txt_lens"]).unsqueeze(1)).long().to(DEV)
+    am_i = (torch.arange(NR).unsqueeze(0) < torch.tensor(full["_num_bbs"]).unsqueeze(1)).long().to(DEV)
+    model.zero_grad()
+    seq_t = R(b["input_ids"], None, None, None, am_t, output_all_encoded_layers=False)
+    check_against_golden(g, "txtonly/seq", seq_t, TOL32)
+    (seq_t * synth.det_normal(tuple(seq_t.shape), 55).to(DEV)).sum().backward()
+    _grad_checks(g, "txtonly", model, 3e-3, min_n=25)
+    model.zero_grad()
+    seq_i = R(None, None, b["img_feat"], b["img_pos_feat"], am_i, img_masks=b["img_masks"], output_all_encoded_layers=False)
+    check_against_golden(g, "imgonly/seq", seq_i, TOL32)
+    (seq_i * synth.det_normal(tuple(seq_i.shape), 56).to(DEV)).sum().backward()
+    _grad_checks(g, "imgonly", model, 3e-3, min_n=25)
+    layers = R(b["input_ids"], None, b["img_feat"], b["img_pos_feat"], b["attn_masks"], b["gather_index"],
+               img_masks=b["img_masks"], output_all_encoded_layers=True)
+    assert len(layers) == 2
+    check_against_golden(g, "alllayers/0", layers[0], TOL32)
+    check_against_golden(g, "alllayers/1", layers[1], TOL32)
+    # pooled output of the ITM golden (stored by round 1, compared here for the first time)
+    g0 = golden("tiny")
+    bi = to_dev(synth.make_batch(1000, 8, 32, 36, task="itm", seed=1))
+    seq = R(bi["input_ids"], None, bi["img_feat"], bi["img_pos_feat"], bi["attn_masks"], bi["gather_index"],
+            output_all_encoded_layers=False)
+    check_against_golden(g0, "tiny8/itm/pooled", R.pooler(seq), TOL32)
+
+
+def test_bf16_base_12_layers_vs_golden():
+    """THE MEASURED MODE against the reference: bf16 MFMA GEMMs / MFMA attention / polynomial GELU, 12 layers,
+    768 hidden, vocabulary 250 002 (BASELINE.json configs[1] geometry, B = 4), against the reference's fp32 vectors
+    (tests/golden/golden_base.npz).  bf16 carries 8 significant bits, so element-wise 1e-3 is out of reach by
+    construction; the tolerances below are the tightest that hold, the measured errors are printed.
+    ITM labels must agree exactly; MLM argmax agreement over the 250 002-way head is reported and held >= 90 %."""
+    g = golden("base")
+    model = build_pretrain(O.BASE, torch.bfloat16)
+    report = {}
+    for task in ("itm", "mlm"):
+        batch = synth.make_batch(250002, 4, 60, 36, task=task, seed=1)
+        seq, scores, loss = run_task(model, batch, task)
+        key = "base4/%s" % task
+        report[task + " seq slice rel (max)"] = check_against_golden(g, key + "/seq", seq, 8e-2)
+        report[task + " loss slice rel (max)"] = check_against_golden(g, key + "/loss", loss, 5e-2)
+        ref_mean = float(g[key + "/loss/sum3"][0]) / loss.numel()
+        report[task + " mean-loss rel"] = abs(loss.mean().item() - ref_mean) / abs(ref_mean)
+        assert report[task + " mean-loss rel"] < 5e-3
+        am = scores.argmax(-1).cpu().numpy()
+        agree = float((am == g[key + "/argmax"]).mean())
+        report[task + " argmax agreement"] = agree
+        if task == "itm":
+            assert agree == 1.0                           # ITM labels bit-exact
+        else:
+            assert agree >= 0.9
+        P = dict(model.named_parameters())
+        for name in ("roberta.encoder.layer.0.attention.self.query.weight", "roberta.encoder.layer.11.output.dense.weight",
+                     "roberta.img_embeddings.img_linear.weight", "roberta.embeddings.LayerNorm.weight"):
+            report["%s grad L2 rel %s" % (task, name.split("roberta.")[1])] = check_against_golden(
+                g, "%s/grad/%s" % (key, name), P[name].grad, 0.12 if task == "mlm" else 0.35, metric="l2")
+    for k, v in report.items():
+        print("bf16-12L %-70s %.4g" % (k, v))
+    del model
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_large_geometry_vs_golden(dtype):
+    """BASELINE.json configs[4] geometry: 24L / 1024H / 16 heads / 4096 FFN, 80 tokens + 50 regions (L = 130), B = 2,
+    against vectors the reference produced through VLXLMRConfig.from_dict (tests/golden/golden_large.npz).
+    fp32: north-star tolerance, argmax bit-exact; bf16: reported, ITM labels exact"""
+    g = golden("large")
+    model = build_pretrain(O.LARGE, dtype)
+    f32 = dtype == torch.float32
+    for task in ("itm", "mlm"):
+        batch = synth.make_batch(250002, 2, 80, 50, task=task, seed=1)
+        seq, scores, loss = run_task(model, batch, task)
+        key = "large2/%s" % task
+        e1 = check_against_golden(g, key + "/seq", seq, TOL32 if f32 else 0.1)
+        e2 = check_against_golden(g, key + "/loss", loss, TOL32 if f32 else 6e-2)
+        agree = float((scores.argmax(-1).cpu().numpy() == g[key + "/argmax"]).mean())
+        print("large %s %s: seq %.3g loss %.3g argmax agreement %.3f" % (str(dtype)[6:], task, e1, e2, agree))
+        if f32 or task == "itm":
+            assert agree == 1.0
+        else:
+            assert agree >= 0.85
+        P = dict(model.named_parameters())
+        for name in ("roberta.encoder.layer.0.attention.self.query.weight", "roberta.encoder.layer.23.output.dense.weight",
+                     "roberta.img_embeddings.img_linear.weight"):
+            if f32:
+                check_against_golden(g, "%s/grad/%s" % (key, name), P[name].grad, 3e-3)
+            else:
+                check_against_golden(g, "%s/grad/%s" % (key, name), P[name].grad, 0.15 if task == "mlm" else 0.5, metric="l2")
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_submodule_forwards_compose_to_the_fused_layer():
+    """BertSelfAttention / BertSelfOutput / BertAttention / BertIntermediate / BertOutput have working forward()s
+    (model/layer.py:75-156); composed the reference's way they reproduce the fused BertLayerFn node bit for bit in
+    fp32 (same kernels, same order) -- outputs and every gradient"""
+    for dtype in (torch.float32, torch.bfloat16):
+        cfg = make_cfg(O.TINY)
+        layer = BertLayer(cfg)
+        synth.det_init_(layer)
+        layer.to(DEV).train()
+        set_compute_dtype(layer, dtype)
+        x = synth.det_normal((3, 68, 128), 21).to(DEV).to(dtype)
+        am = torch.ones(3, 68, dtype=torch.long)
+        am[1, 50:] = 0
+        ext = O.extended_mask(am).to(DEV)
+        dy = synth.det_normal((3, 68, 128), 22).to(DEV).to(dtype)
+        x1 = x.clone().requires_grad_(True)
+        layer.zero_grad()
+        y1 = layer(x1, ext)
+        y1.backward(dy)
+        g1 = {n: p.grad.clone() for n, p in layer.named_parameters()}
+        for p in layer.parameters():
+            p.grad = None
+        uc2_amd.store.store_of(layer).zero_grad()
+        x2 = x.clone().requires_grad_(True)
+        y2 = layer.forward_unfused(x2, ext)
+        y2.backward(dy)
+        assert torch.equal(y1, y2)
+        assert rel_err(x2.grad.float(), x1.grad.float()) < (1e-6 if dtype == torch.float32 else 1e-2)
+        for n, p in layer.named_parameters():
+            if n.endswith("key.bias"):
+                continue
+            assert rel_err(p.grad, g1[n]) < (1e-5 if dtype == torch.float32 else 2e-2), n
+
+
+def test_gelu_module_and_sequential_heads():
+    """GELU is a real activation (model/layer.py:31-50): calling the head Sequentials the plain way equals the
+    fused-epilogue path the model uses"""
+    from uc2_amd.model.layer import GELU
+    model = build_pretrain(O.TINY, torch.float32)
+    x = synth.det_normal((50, 128), 31).to(DEV)
+    ref = torch.nn.functional.gelu(x)
+    assert max_rel(GELU()(x), ref) < 1e-5
+    rc = model.region_classifier
+    assert max_rel(rc.net(x), rc(x)) < 1e-5
+    fr = model.feat_regress
+    h = fr.net(x)
+    assert max_rel(h, fr.net[2](fr.net[0](x, act=ops.EPI_GELU))) < 1e-5
+    xg = x.clone().requires_grad_(True)
+    GELU()(xg).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    torch.nn.functional.gelu(xr).sum().backward()
+    assert max_rel(xg.grad, xr.grad) < 1e-4
 
 
 # ------------------------------------------------------------------------------------------ optimizer
@@ -307,5 +531,12 @@ def test_multihead_attention_vs_golden():
     o, w = m(qg, qg, qg, key_padding_mask=kpm)
     check_against_golden(g, "mha/out", o, TOL32)
     check_against_golden(g, "mha/weights", w, TOL32)
-    o.sum().backward()
-    assert qg.grad is not None and torch.isfinite(qg.grad).all() and m.in_proj_weight.grad is not None
+    g2 = golden("more")
+    for p in m.parameters():
+        p.grad = None
+    qg = q.clone().requires_grad_(True)
+    o, _ = m(qg, qg, qg, key_padding_mask=kpm)
+    (o * synth.det_normal((L, N, E), 78).to(DEV)).sum().backward()
+    check_against_golden(g2, "mha/dq", qg.grad, 3e-3)                      # backward parity (reference gradients)
+    for n, p in m.named_parameters():
+        check_against_golden(g2, "mha/grad/" + n, p.grad, 3e-3)

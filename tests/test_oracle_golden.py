@@ -160,6 +160,133 @@ def test_adamw_clip_sched():
         assert np.allclose(mine, g["sched/%s" % decay], rtol=1e-12, atol=0)
 
 
+def _check_grads(g, key, grads, tol=2e-4, min_n=40):
+    n = 0
+    for name, gr in grads.items():
+        k = "%s/grad/%s" % (key, name)
+        if k + "/sum3" in g.files:
+            if name.endswith("key.bias"):     # mathematically zero (softmax is shift invariant): rounding noise only
+                qb = float(g[k.replace("key.bias", "query.bias") + "/sum3"][2])
+                assert gr.norm().item() < 1e-3 * qb and float(g[k + "/sum3"][2]) < 1e-3 * qb
+            elif float(g[k + "/sum3"][2]) < 1e-7:
+                assert gr.norm().item() < 1e-6
+            else:
+                check_against_golden(g, k, gr, tol)
+            n += 1
+    assert n > min_n, n
+
+
+def test_more_tasks_and_branches():
+    """round-2 fixtures (tests/golden/golden_more.npz): tlm (batch position_ids), tlm-ni (text only), vmlm-soft,
+    ITM + OT regulariser, the text-only / image-only encoder branches, all-layer output"""
+    g = golden("more")
+    cfg = cfg_of(O.TINY)
+    W = make_weights(specs.pretrain_shapes(cfg))
+    for task in ("tlm", "tlm-ni"):
+        b = strip(synth.make_batch(1000, 8, 32, 36, task=task, seed=1, variable_len=True))
+        key = "tiny8var/%s" % task
+        assert np.array_equal(b["position_ids"].numpy(), g[key + "/position_ids"])
+        scores = O.pretrain_forward(W, cfg, b, task, compute_loss=False)
+        assert np.array_equal(scores.argmax(-1).numpy(), g[key + "/argmax"])
+        check_against_golden(g, key + "/scores", scores, TOL)
+
+        def loss_fn(Wg):
+            l = O.pretrain_forward(Wg, cfg, b, task)
+            loss_fn.loss = l.detach()
+            return l.mean()
+        _, grads = O.grads_of(loss_fn, W)
+        check_against_golden(g, key + "/loss", loss_fn.loss, TOL * 5)
+        _check_grads(g, key, grads)
+    # soft labels
+    b = strip(synth.make_batch(1000, 8, 32, 36, task="vmlm-soft", seed=1, n_soft=len(O.VALID_XLMR_TOKEN_IDS)))
+    key = "tiny8/vmlm-soft"
+    check_against_golden(g, key + "/scores", O.pretrain_forward(W, cfg, b, "vmlm-soft", compute_loss=False), TOL)
+
+    def loss_fn(Wg):
+        l = O.pretrain_forward(Wg, cfg, b, "vmlm-soft")
+        loss_fn.loss = l.detach()
+        return 1000 * l.mean()
+    _, grads = O.grads_of(loss_fn, W)
+    check_against_golden(g, key + "/loss", loss_fn.loss, 1e-4)
+    _check_grads(g, key, grads)
+    W["roberta.img_embeddings.mask_embedding.weight"][0].zero_()      # model/model.py:354 zeroes it in place in the reference run
+    # ITM + OT
+    b = strip(synth.make_batch(1000, 8, 32, 36, task="itm", seed=1, variable_len=True, ot=True))
+    for pos_only in (False, True):
+        key = "tiny8var/itm-ot%s" % ("-pos" if pos_only else "")
+
+        def loss_fn(Wg):
+            l, ot = O.pretrain_forward(Wg, cfg, b, "itm", ot_pos_only=pos_only)
+            loss_fn.out = (l.detach(), ot)
+            otl = ot.mean() if pos_only else (ot[0].sum() - ot[1].sum()) / (ot[0].size(0) + ot[1].size(0))
+            return l.mean() + 0.1 * otl
+        _, grads = O.grads_of(loss_fn, W)
+        l, ot = loss_fn.out
+        check_against_golden(g, key + "/loss", l, TOL * 5)
+        if pos_only:
+            check_against_golden(g, key + "/ot", ot.detach(), 1e-4)
+        else:
+            check_against_golden(g, key + "/ot_pos", ot[0].detach(), 1e-4)
+            check_against_golden(g, key + "/ot_neg", ot[1].detach(), 1e-4)
+        _check_grads(g, key, grads, tol=5e-4)
+    # text-only / image-only branches, all layers
+    full = synth.make_batch(1000, 8, 32, 36, task="mrfr", seed=3, variable_len=True)
+    b = strip(full)
+    T, R = b["input_ids"].shape[1], b["img_feat"].shape[1]
+    am_t = (torch.arange(T).unsqueeze(0) < torch.tensor(full["_txt_lens"]).unsqueeze(1)).long()
+    am_i = (torch.arange(R).unsqueeze(0) < torch.tensor(full["_num_bbs"]).unsqueeze(1)).long()
+    check_against_golden(g, "txtonly/seq", O.model_forward(W, cfg, b["input_ids"], None, None, None, am_t), TOL)
+    check_against_golden(g, "imgonly/seq", O.model_forward(W, cfg, None, None, b["img_feat"], b["img_pos_feat"], am_i,
+                                                           img_masks=b["img_masks"]), TOL)
+    _, grads = O.grads_of(lambda Wg: (O.model_forward(Wg, cfg, b["input_ids"], None, None, None, am_t)
+                                      * synth.det_normal((8, T, 128), 55)).sum(), W)
+    _check_grads(g, "txtonly", grads, min_n=30)
+    _, grads = O.grads_of(lambda Wg: (O.model_forward(Wg, cfg, None, None, b["img_feat"], b["img_pos_feat"], am_i,
+                                                      img_masks=b["img_masks"]) * synth.det_normal((8, R, 128), 56)).sum(), W)
+    _check_grads(g, "imgonly", grads, min_n=30)
+    layers = O.model_forward(W, cfg, b["input_ids"], None, b["img_feat"], b["img_pos_feat"], b["attn_masks"], b["gather_index"],
+                             img_masks=b["img_masks"], output_all_encoded_layers=True)
+    check_against_golden(g, "alllayers/0", layers[0], TOL)
+    check_against_golden(g, "alllayers/1", layers[1], TOL)
+
+
+def test_multihead_attention_variants():
+    """model/attention.py: packed self-attention with key padding (+ gradients) and the general form
+    (separate key/value inputs, additive attn_mask), against the reference's outputs and gradients"""
+    g = golden("more")
+    g0 = golden("mha")
+    E, nh, L, N, S = 128, 4, 10, 3, 7
+    names = {"in_proj_weight": (3 * E, E), "in_proj_bias": (3 * E,), "out_proj.weight": (E, E), "out_proj.bias": (E,)}
+    W = make_weights(names)
+    q = synth.det_normal((L, N, E), 77)
+    kpm = torch.zeros(N, L, dtype=torch.bool)
+    kpm[1, 7:] = True
+    kpm[2, 4:] = True
+    o, w = O.multi_head_attention(q, q, q, W, nh, key_padding_mask=kpm)
+    check_against_golden(g0, "mha/out", o, TOL)
+    check_against_golden(g0, "mha/weights", w, TOL)
+    qg = q.clone().requires_grad_(True)
+    Wg = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in W.items())
+    o, _ = O.multi_head_attention(qg, qg, qg, Wg, nh, key_padding_mask=kpm)
+    (o * synth.det_normal((L, N, E), 78)).sum().backward()
+    check_against_golden(g, "mha/dq", qg.grad, 1e-4)
+    for n in names:
+        check_against_golden(g, "mha/grad/" + n, Wg[n].grad, 1e-4)
+    q2, k2, v2 = [synth.det_normal(shp, sd).requires_grad_(True) for shp, sd in (((L, N, E), 80), ((S, N, E), 81), ((S, N, E), 82))]
+    amask = synth.det_normal((L, S), 83)
+    kpm2 = torch.zeros(N, S, dtype=torch.bool)
+    kpm2[2, 5:] = True
+    Wg = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in W.items())
+    o2, w2 = O.multi_head_attention(q2, k2, v2, Wg, nh, key_padding_mask=kpm2, attn_mask=amask)
+    check_against_golden(g, "mha_cross/out", o2, TOL)
+    check_against_golden(g, "mha_cross/weights", w2, TOL)
+    (o2 * synth.det_normal((L, N, E), 84)).sum().backward()
+    for key, t in (("dq", q2), ("dk", k2), ("dv", v2)):
+        check_against_golden(g, "mha_cross/" + key, t.grad, 1e-4)
+    for n in names:
+        check_against_golden(g, "mha_cross/grad/" + n, Wg[n].grad, 1e-4)
+
+
 def test_allreduce_mean():
     ts = [synth.det_normal((1000,), 100 + r) for r in range(4)]
     out = O.allreduce_mean(ts, 1.0)

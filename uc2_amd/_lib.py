@@ -13,6 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libuc2_hip.so")
 _lib = None
+ABI_VERSION = 2          # include/uc2_hip.h; bumped whenever a signature changes
 
 P, I, F, U64, I64, SZ = c_void_p, c_int, c_float, c_uint64, c_int64, c_size_t
 
@@ -21,27 +22,22 @@ SIGNATURES = {
     "uc2_abi_version": (I, []),
     "uc2_last_error": (c_char_p, []),
     "uc2_device_info": (I, [P, P, P, I]),
-    "uc2_gemm": (I, [I, I, I, I, I, I, P, I, P, I, P, I, I, P, I, P, P, I, I, I, P]),
-    "uc2_gemm_force_generic": (I, [I]),
-    "uc2_gemm_set_variant": (I, [I]),
-    "uc2_gemm_set_fetch_only": (I, [I]),
-    "uc2_gemm_set_skew": (I, [I]),
-    "uc2_gemm_set_workspace": (I, [P, SZ]),
-    "uc2_gemm_defer_reduce": (I, [I]),
-    "uc2_gemm_splitk_reduce": (I, [I, I, P, I, I, I, P]),
-    "uc2_ln_fwd": (I, [I, I, I, P, P, P, P, F, F, P, U64, P, P, P, P]),
+    "uc2_gemm": (I, [I, I, I, I, I, I, P, I, P, I, P, I, I, P, I, P, P, I, I, I, I, P, SZ, I, P]),
+    "uc2_gemm_splitk_reduce": (I, [I, I, P, I, I, I, P, SZ, P]),
+    "uc2_ln_fwd": (I, [I, I, I, P, P, P, P, F, F, I, P, U64, P, P, P, P]),
     "uc2_ln_bwd_workspace": (SZ, [I, I]),
-    "uc2_ln_bwd": (I, [I, I, I, P, P, P, P, P, P, F, P, U64, P, P, P, P, P, P, P]),
+    "uc2_ln_bwd": (I, [I, I, I, P, P, P, P, P, P, F, I, P, U64, P, P, P, P, P, P, P]),
     "uc2_attn_fwd": (I, [I, I, I, I, I, I, P, P, F, F, P, U64, P, P, P]),
     "uc2_attn_bwd": (I, [I, I, I, I, I, I, P, P, F, F, P, U64, P, P, P, P, P, P]),
     "uc2_attn_mfma_supported": (I, [I, I]),
     "uc2_attn_probs_mean": (I, [I, I, I, I, I, P, P, F, P, P]),
     "uc2_position_ids": (I, [I, I, P, I64, P, P]),
     "uc2_embed_fwd": (I, [I, I, I, P, P, P, I, P, P, P, P, P]),
-    "uc2_embed_bwd": (I, [I, I, I, P, P, P, P, P, P, P, P]),
+    "uc2_embed_bwd": (I, [I, I, I, P, P, P, P, P, P, P, I64, I64, P]),
     "uc2_gather_rows_fwd": (I, [I, I, I, I, I, P, P, P, P]),
     "uc2_gather_rows_bwd": (I, [I, I, I, I, I, P, P, P, P]),
     "uc2_select_rows": (I, [I, I, I, P, I, P, P, I, I, P]),
+    "uc2_gather_f32": (I, [I, P, P, P, I, P]),
     "uc2_colsum_accum": (I, [I, I, I, P, I, P, P, P]),
     "uc2_add_rowvec": (I, [I, I, I, I, P, P, P, P, P, P]),
     "uc2_ce_fwd": (I, [I, I, I, P, I, P, I64, P, P, P, P]),
@@ -51,6 +47,7 @@ SIGNATURES = {
     "uc2_mse": (I, [I, SZ, P, P, P, P, P, P]),
     "uc2_triplet": (I, [I, I, I, F, P, P, P, P, P]),
     "uc2_dtanh": (I, [I, SZ, P, P, P, P]),
+    "uc2_gelu": (I, [I, SZ, P, P, P]),
     "uc2_dgelu": (I, [I, SZ, P, P, P, P]),
     "uc2_cast": (I, [I, I, SZ, P, P, P]),
     "uc2_adamw_chunk_bytes": (SZ, []),
@@ -83,6 +80,9 @@ def load():
             raise Uc2Error("uc2_amd: symbol %s missing from %s" % (name, LIB_PATH)) from e
         fn.restype = res
         fn.argtypes = args
+    if lib.uc2_abi_version() != ABI_VERSION:
+        raise Uc2Error("uc2_amd: %s has ABI version %d, this package needs %d: rebuild it (make -C uc2_amd/csrc)"
+                       % (LIB_PATH, lib.uc2_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

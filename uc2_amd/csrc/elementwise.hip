@@ -68,12 +68,14 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(int rows, int H, const i
                                                         const int64_t* __restrict__ pos_ids,
                                                         const int64_t* __restrict__ type_ids,
                                                         const T* __restrict__ dpre, float* __restrict__ dword,
-                                                        float* __restrict__ dpos, float* __restrict__ dtype) {
+                                                        float* __restrict__ dpos, float* __restrict__ dtype,
+                                                        int64_t word_pad, int64_t pos_pad) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
-  float* w = dword ? dword + (size_t)ids[r] * H : nullptr;
-  float* p = dpos ? dpos + (size_t)pos_ids[r] * H : nullptr;
+  // nn.Embedding(padding_idx=...) rows receive no gradient (model/model.py:296-298)
+  float* w = (dword && ids[r] != word_pad) ? dword + (size_t)ids[r] * H : nullptr;
+  float* p = (dpos && pos_ids[r] != pos_pad) ? dpos + (size_t)pos_ids[r] * H : nullptr;
   float* ty = (dtype && type_ids) ? dtype + (size_t)type_ids[r] * H : nullptr;
   for (int c = lane; c < H; c += 64) {           // one dword per lane: 256 contiguous bytes per wave-instruction
     const float g = to_f<T>(dpre[(size_t)r * H + c]);
@@ -97,13 +99,13 @@ extern "C" int uc2_embed_fwd(int dtype, int rows, int H, const int64_t* ids, con
 }
 extern "C" int uc2_embed_bwd(int dtype, int rows, int H, const int64_t* ids, const int64_t* pos_ids,
                              const int64_t* type_ids, const void* dpre, float* dword, float* dpos, float* dtype_tab,
-                             void* stream) {
+                             int64_t word_pad, int64_t pos_pad, void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
   if (rows <= 0) return 0;
   UC2_CHECK_ARG(ids && pos_ids && dpre);
   dim3 grid((rows + 3) / 4);
-  if (dtype == 0) hipLaunchKernelGGL(embed_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, rows, H, ids, pos_ids, type_ids, (const float*)dpre, dword, dpos, dtype_tab);
-  else hipLaunchKernelGGL(embed_bwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, rows, H, ids, pos_ids, type_ids, (const bf16*)dpre, dword, dpos, dtype_tab);
+  if (dtype == 0) hipLaunchKernelGGL(embed_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, rows, H, ids, pos_ids, type_ids, (const float*)dpre, dword, dpos, dtype_tab, word_pad, pos_pad);
+  else hipLaunchKernelGGL(embed_bwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, rows, H, ids, pos_ids, type_ids, (const bf16*)dpre, dword, dpos, dtype_tab, word_pad, pos_pad);
   UC2_LAUNCH_CHECK();
   return 0;
 }
@@ -210,6 +212,12 @@ __global__ __launch_bounds__(256) void select_rows_kernel(int n, int H, const T*
   for (int c = lane * 4; c < H; c += 256) {
     float v[4];
     Vec4<T>::load(s + c, v);
+    if (scatter == 2) {                 // accumulate: dst[rows[i]] += src[i]  (rows unique)
+      float o[4];
+      Vec4<T>::load(d + c, o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += o[e];
+    }
     Vec4<T>::store(d + c, v);
   }
 }
@@ -222,6 +230,24 @@ extern "C" int uc2_select_rows(int dtype, int n, int H, const void* src, int ld_
   dim3 grid((n + 3) / 4);
   if (dtype == 0) hipLaunchKernelGGL(select_rows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, n, H, (const float*)src, ld_src, rows, (float*)dst, ld_dst, scatter);
   else hipLaunchKernelGGL(select_rows_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, n, H, (const bf16*)src, ld_src, rows, (bf16*)dst, ld_dst, scatter);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+// element gather / scatter-add on an fp32 vector: mode 0: dst[i] = src[idx[i]]; mode 1: dst[idx[i]] += src[i]
+// (idx unique) -- bias entries of a column subset of the tied decoder (model/model.py:639-642)
+__global__ void gather_f32_kernel(int n, const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                  float* __restrict__ dst, int mode) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (mode == 0) dst[i] = src[idx[i]];
+  else dst[idx[i]] += src[i];
+}
+extern "C" int uc2_gather_f32(int n, const float* src, const int64_t* idx, float* dst, int mode, void* stream) {
+  UC2_CHECK_ARG(mode == 0 || mode == 1);
+  if (n <= 0) return 0;
+  UC2_CHECK_ARG(src && idx && dst);
+  hipLaunchKernelGGL(gather_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, src, idx, dst, mode);
   UC2_LAUNCH_CHECK();
   return 0;
 }
@@ -565,6 +591,22 @@ extern "C" int uc2_dtanh(int dtype, size_t n, const void* y, const void* dy, voi
   UC2_CHECK_ARG(y && dy && dx);
   if (dtype == 0) hipLaunchKernelGGL(dtanh_kernel<float>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, n, (const float*)y, (const float*)dy, (float*)dx);
   else hipLaunchKernelGGL(dtanh_kernel<bf16>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, n, (const bf16*)y, (const bf16*)dy, (bf16*)dx);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+// gelu as a stand-alone activation (model/layer.py:31-37; the GELU module of the head Sequentials)
+template <typename T>
+__global__ void gelu_kernel(size_t n, const T* __restrict__ x, T* __restrict__ y) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = from_f<T>(gelu_t<T>(to_f<T>(x[i])));
+}
+extern "C" int uc2_gelu(int dtype, size_t n, const void* x, void* y, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  if (n == 0) return 0;
+  UC2_CHECK_ARG(x && y);
+  if (dtype == 0) hipLaunchKernelGGL(gelu_kernel<float>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, n, (const float*)x, (float*)y);
+  else hipLaunchKernelGGL(gelu_kernel<bf16>, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, n, (const bf16*)x, (bf16*)y);
   UC2_LAUNCH_CHECK();
   return 0;
 }

@@ -264,19 +264,10 @@ static void launch_bf16(const GemmArgs& p, hipStream_t st) {
 
 int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st);   // gemm_fast.hip
 extern "C" int uc2_colsum_accum(int dtype, int M, int N, const void* X, int ldx, const uint8_t* rowmask, float* out, void* stream);   // elementwise.hip
-static int g_force_generic = -1;
-// 1 = always use the generic register-staged kernel (A/B tests), 0 = prefer the pipelined one
-extern "C" int uc2_gemm_force_generic(int v) { g_force_generic = v ? 1 : 0; return 0; }
 
-// Split-K workspace (caller-owned device memory): with it, the ping-pong kernel's weight-gradient items store
-// their fp32 partial tiles with plain stores and uc2_splitk_reduce adds them into C -- no atomics, so the
-// result is bit-reproducible, and 64 MB of partials cost ~25 us instead of ~50 us of fp32 atomics.
-float* g_splitk_ws = nullptr;
-size_t g_splitk_ws_bytes = 0;
-extern "C" int uc2_gemm_set_workspace(void* ptr, size_t bytes) {
-  g_splitk_ws = reinterpret_cast<float*>(ptr); g_splitk_ws_bytes = ptr ? bytes : 0;
-  return 0;
-}
+// Split-K workspace (caller-owned device memory, passed with each call): with it, the ping-pong kernel's
+// weight-gradient items store their fp32 partial tiles with plain stores and uc2_splitk_reduce adds them into C --
+// no atomics, so the result is bit-reproducible, and 64 MB of partials cost ~25 us instead of ~50 us of fp32 atomics.
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int ldc, int split, const float* __restrict__ ws,
                                                             float* __restrict__ C, int accumulate) {
@@ -293,20 +284,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int ld
     *c = a;
   }
 }
-int g_splitk_defer = 0;           // 1: uc2_gemm leaves the partials in the workspace; the caller runs uc2_gemm_splitk_reduce
-extern "C" int uc2_gemm_defer_reduce(int on) { g_splitk_defer = on ? 1 : 0; return 0; }
 void uc2_splitk_reduce(const GemmArgs& p, hipStream_t st) {        // called by gemm_fast.hip after the partial launch
   const size_t mn4 = (size_t)p.M * p.N / 4;
   const int blocks = (int)((mn4 + 255) / 256 < 2048 ? (mn4 + 255) / 256 : 2048);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.M, p.N, p.ldc, p.split_k, p.partial,
                      reinterpret_cast<float*>(p.C), p.accumulate);
 }
-// second stage on its own (after a uc2_gemm issued under uc2_gemm_defer_reduce(1)): C (=|+=) sum_z workspace[z]
-extern "C" int uc2_gemm_splitk_reduce(int M, int N, void* C, int ldc, int split_k, int accumulate, void* stream) {
-  UC2_CHECK_ARG(C && g_splitk_ws && (size_t)split_k * M * N * sizeof(float) <= g_splitk_ws_bytes);
-  UC2_CHECK_ARG((N & 3) == 0 && (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0);
+// second stage on its own (after a uc2_gemm issued with UC2_GEMM_DEFER_REDUCE): C (=|+=) sum_z workspace[z]
+extern "C" int uc2_gemm_splitk_reduce(int M, int N, void* C, int ldc, int split_k, int accumulate, const void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  UC2_CHECK_ARG(C && workspace && (size_t)split_k * M * N * sizeof(float) <= workspace_bytes);
+  UC2_CHECK_ARG((N & 3) == 0 && (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 && ((uintptr_t)workspace & 15) == 0);
   GemmArgs p{};
-  p.M = M; p.N = N; p.C = C; p.ldc = ldc; p.split_k = split_k; p.accumulate = accumulate; p.partial = g_splitk_ws;
+  p.M = M; p.N = N; p.C = C; p.ldc = ldc; p.split_k = split_k; p.accumulate = accumulate;
+  p.partial = reinterpret_cast<float*>(const_cast<void*>(workspace));
   uc2_splitk_reduce(p, (hipStream_t)stream);
   UC2_LAUNCH_CHECK();
   return 0;
@@ -315,8 +306,10 @@ extern "C" int uc2_gemm_splitk_reduce(int M, int N, void* C, int ldc, int split_
 extern "C" int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K,
                         const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_is_f32,
                         const float* bias, int epilogue, const void* aux_in, void* aux_out, int ldaux,
-                        int accumulate, int split_k, void* stream) {
+                        int accumulate, int split_k, int variant, void* workspace, size_t workspace_bytes, int flags,
+                        void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  UC2_CHECK_ARG(variant == -2 || variant == 99 || (variant >= 0 && variant <= 9));
   UC2_CHECK_ARG(M >= 0 && N >= 0 && K >= 0);
   UC2_CHECK_ARG(epilogue >= EPI_NONE && epilogue <= EPI_TANH);
   UC2_CHECK_ARG(!((epilogue == EPI_DGELU || epilogue == EPI_ADD) && aux_in == nullptr));
@@ -329,7 +322,9 @@ extern "C" int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K
   p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux ? ldaux : ldc;
   p.epi = epilogue; p.c_f32 = (dtype == 0) ? 1 : c_is_f32; p.accumulate = accumulate;
-  p.split_k = split_k; p.atomic = (split_k > 1) ? 1 : 0; p.partial = nullptr; p.skew = 0;
+  p.split_k = split_k; p.atomic = (split_k > 1) ? 1 : 0; p.partial = nullptr;
+  p.variant = variant; p.ws = reinterpret_cast<float*>(workspace); p.ws_bytes = workspace ? workspace_bytes : 0;
+  p.defer = flags & 1; p.skew = (flags >> 4) & 15; p.diag = (flags >> 8) & 0xFFF;
   p.a_vec = (((uintptr_t)A & 15) == 0) && ((lda & 7) == 0);
   p.b_vec = (((uintptr_t)B & 15) == 0) && ((ldb & 7) == 0);
   hipStream_t st = (hipStream_t)stream;
@@ -340,9 +335,8 @@ extern "C" int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K
     else if (trans_a && !trans_b) launch_f32<true, false>(p, st);
     else launch_f32<true, true>(p, st);
   } else {
-    if (g_force_generic < 0) { const char* e = getenv("UC2_GEMM_GENERIC"); g_force_generic = (e && e[0] == '1') ? 1 : 0; }
     const bool want_colsum = (epilogue == EPI_DGELU && aux_out != nullptr);
-    const int fast = g_force_generic ? 0 : uc2_gemm_bf16_fast_try(p, trans_a, trans_b, st);
+    const int fast = variant == 99 ? 0 : uc2_gemm_bf16_fast_try(p, trans_a, trans_b, st);
     if (fast) {
       UC2_LAUNCH_CHECK();
       if (want_colsum && fast != 2) return uc2_colsum_accum(1, M, N, C, ldc, nullptr, reinterpret_cast<float*>(aux_out), stream);

@@ -13,6 +13,11 @@ struct GemmArgs {
   int a_vec, b_vec;      // 16-byte vector loads allowed (alignment checked on the host)
   float* partial;        // split-K partial tiles [split][M][N] fp32 (ping-pong kernel, two-stage reduction), or null
   int skew;              // ping-pong kernel: start delay step in units of s_sleep(127) (~8k cycles) between the 4 phase groups
+  // per-call plan (include/uc2_hip.h uc2_gemm): nothing about kernel selection is process-global
+  int variant;           // UC2_GEMM_AUTO (-2), 99 = generic register-staged kernel, 0..9 = a specific kernel
+  float* ws; size_t ws_bytes;   // caller-owned split-K workspace for THIS call (or null)
+  int defer;             // leave the split-K partials in ws (the caller runs uc2_gemm_splitk_reduce)
+  int diag;              // diagnostic launch mode (main loop only / epilogue only / stamps), 0 in production
 };
 
 // ------------------------------------------------------------------------------------------

@@ -314,19 +314,10 @@ static void ws_launch1(const GemmArgs& p, hipStream_t st) {
 bool uc2_gemm_pp_supported(int trans_a, int trans_b, int c_f32, int epi, int tile_rows);        // gemm_pp.hip
 void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st, int tile_rows);
 void uc2_splitk_reduce(const GemmArgs& p, hipStream_t st);                                        // gemm.hip
-extern float* g_splitk_ws;
-extern size_t g_splitk_ws_bytes;
-extern int g_splitk_defer;
 
 // ------------------------------------------------------------------------------------------------------
 // host side: variant selection
 // ------------------------------------------------------------------------------------------------------
-static int g_skew = 0;              // ping-pong start skew step (0 = off); uc2_gemm_set_skew
-extern "C" int uc2_gemm_set_skew(int v) { g_skew = v; return 0; }
-static int g_fetch_only = 0;
-extern "C" int uc2_gemm_set_fetch_only(int v) { g_fetch_only = v; return 0; }
-static int g_variant = -1;          // -1 = read UC2_GEMM_VARIANT; -2 = per-shape heuristic (default); 0..5 = fixed; 99 = generic kernel
-extern "C" int uc2_gemm_set_variant(int v) { g_variant = v; return 0; }
 
 template <bool TA, bool TB, bool TACC, int BM, int BK, int NSTAGE>
 static void gf_launch1(const GemmArgs& p, hipStream_t st) {
@@ -354,8 +345,7 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
   if (!p.a_vec || !p.b_vec) return 0;
   if (trans_a ? ((p.M & 7) != 0 || p.M < 8) : (p.M < 1)) return 0;
   if (trans_b ? ((p.N & 7) != 0 || p.N < 8) : (p.N < 1)) return 0;
-  if (g_variant == -1) { const char* e = getenv("UC2_GEMM_VARIANT"); g_variant = e ? atoi(e) : -2; }
-  int variant = g_variant;
+  const int variant = p.variant;                     // per call (uc2_gemm's `variant` argument), never process state
   if (variant == 99) return 0;                       // caller asked for the generic kernel
   if (variant == 8 || variant == 9) {
     // ping-pong kernel: whole 256x256 (variant 9: 192x256) tiles, >= 2 k-tiles per split, and (bf16 output) an epilogue
@@ -375,18 +365,17 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
   }
   const bool tacc = !(p.c_f32 && p.atomic);
   GemmArgs pd = p;
-  if (g_fetch_only) pd.atomic |= (g_fetch_only << 8);
-  // off unless asked for: back-to-back launches of the double-store GELU GEMM gained 16 % from de-phasing, inside the
-  // training step (tests/ab_skew.py) no kernel moved
-  pd.skew = g_skew > 0 ? g_skew : 0;
+  if (p.diag) pd.atomic |= (p.diag << 8);
+  // skew is off unless the call asks for it: back-to-back launches of the double-store GELU GEMM gained 16 % from
+  // de-phasing, inside the training step no kernel moved
   if (variant == 9) { uc2_gemm_pp_launch(pd, trans_a, trans_b, st, 192); return 2; }
   if (variant == 8) {
     const size_t need = (size_t)p.split_k * p.M * p.N * sizeof(float);
-    if (p.c_f32 && p.split_k > 1 && g_splitk_ws && need <= g_splitk_ws_bytes && (p.N & 3) == 0 && (p.ldc & 3) == 0 &&
-        ((uintptr_t)p.C & 15) == 0) {
-      pd.partial = g_splitk_ws;                      // two-stage: plain partial stores, then one reduction pass
+    if (p.c_f32 && p.split_k > 1 && p.ws && need <= p.ws_bytes && (p.N & 3) == 0 && (p.ldc & 3) == 0 &&
+        ((uintptr_t)p.C & 15) == 0 && ((uintptr_t)p.ws & 15) == 0) {
+      pd.partial = p.ws;                             // two-stage: plain partial stores, then one reduction pass
       uc2_gemm_pp_launch(pd, trans_a, trans_b, st, 256);
-      if (!g_splitk_defer) uc2_splitk_reduce(pd, st);
+      if (!p.defer) uc2_splitk_reduce(pd, st);
     } else {
       uc2_gemm_pp_launch(pd, trans_a, trans_b, st, 256);
     }

@@ -15,7 +15,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int H, const T* __restrict__ x, const T* __restrict__ res,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, uint32_t thresh, float keep_scale, const uint64_t* __restrict__ seed_ptr,
-                                                     uint64_t seed_imm, T* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+                                                     uint64_t seed_imm, T* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                     int drop_after) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int H, const T* __re
     const int c = lane + 64 * i;
     const size_t off = (size_t)row * H + c * 4;
     Raw4<T>::to_f(rx[i], v[i]);
-    if (thresh) {
+    if (thresh && !drop_after) {
       bool kp4[4];
       drop_keep4(seed, off, thresh, kp4);
 #pragma unroll
@@ -80,6 +81,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int H, const T* __re
       Vec4<float>::load(beta + c * 4, b);
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+      if (thresh && drop_after) {          // y = dropout(LN(x + res)): the embedding tails, model/model.py:331-333,361-363
+        bool kp4[4];
+        drop_keep4(seed, (size_t)row * H + c * 4, thresh, kp4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = kp4[e] ? o[e] * keep_scale : 0.f;
+      }
       Vec4<T>::store(y + (size_t)row * H + c * 4, o);
     }
   }
@@ -93,7 +100,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
                                                      const T* __restrict__ res, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      uint32_t thresh, float keep_scale, const uint64_t* __restrict__ seed_ptr,
-                                                     uint64_t seed_imm, T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ ws, int want_dbias) {
+                                                     uint64_t seed_imm, T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ ws, int want_dbias,
+                                                     int drop_after) {
   __shared__ float red[4][NC * 4 * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nch = H >> 2;
@@ -142,8 +150,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
       for (int e = 0; e < 4; ++e) kp[i][e] = true;
       if (thresh) {
         drop_keep4(seed, off, thresh, kp[i]);
+        if (drop_after) {                  // mask sits on the output: dy_eff = keep ? dy / (1-p) : 0, x is not masked
 #pragma unroll
-        for (int e = 0; e < 4; ++e) xv[e] = kp[i][e] ? xv[e] * keep_scale : 0.f;
+          for (int e = 0; e < 4; ++e) dyv[e] = kp[i][e] ? dyv[e] * keep_scale : 0.f;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xv[e] = kp[i][e] ? xv[e] * keep_scale : 0.f;
+        }
       }
       if (res) {
         float r[4];
@@ -173,7 +186,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           dz[e] = rstd * (g[i][e] - s1 - xh[i][e] * s2);
-          dxv[e] = thresh ? (kp[i][e] ? dz[e] * keep_scale : 0.f) : dz[e];
+          dxv[e] = (thresh && !drop_after) ? (kp[i][e] ? dz[e] * keep_scale : 0.f) : dz[e];
           dbx[i][e] += dxv[e];
         }
         if (dx) Vec4<T>::store(dx + off, dxv);
@@ -226,8 +239,8 @@ static int ln_bwd_blocks(int M) {
 }
 
 extern "C" int uc2_ln_fwd(int dtype, int M, int H, const void* x, const void* residual, const float* gamma,
-                          const float* beta, float eps, float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, void* y, float* mean,
-                          float* rstd, void* stream) {
+                          const float* beta, float eps, float drop_p, int drop_after, const uint64_t* seed_ptr, uint64_t seed_imm,
+                          void* y, float* mean, float* rstd, void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
   UC2_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= LN_MAXC * 256);
   UC2_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
@@ -239,10 +252,10 @@ extern "C" int uc2_ln_fwd(int dtype, int M, int H, const void* x, const void* re
   hipStream_t st = (hipStream_t)stream;
   if (dtype == 0)
     hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, st, M, H, (const float*)x, (const float*)residual, gamma,
-                       beta, eps, th, ks, seed_ptr, seed_imm, (float*)y, mean, rstd);
+                       beta, eps, th, ks, seed_ptr, seed_imm, (float*)y, mean, rstd, drop_after);
   else
     hipLaunchKernelGGL(ln_fwd_kernel<bf16>, grid, block, 0, st, M, H, (const bf16*)x, (const bf16*)residual, gamma,
-                       beta, eps, th, ks, seed_ptr, seed_imm, (bf16*)y, mean, rstd);
+                       beta, eps, th, ks, seed_ptr, seed_imm, (bf16*)y, mean, rstd, drop_after);
   UC2_LAUNCH_CHECK();
   return 0;
 }
@@ -250,9 +263,9 @@ extern "C" int uc2_ln_fwd(int dtype, int M, int H, const void* x, const void* re
 extern "C" size_t uc2_ln_bwd_workspace(int M, int H) { return (size_t)ln_bwd_blocks(M) * 3 * H * sizeof(float); }
 
 extern "C" int uc2_ln_bwd(int dtype, int M, int H, const void* dy, const void* x, const void* residual,
-                          const float* gamma, const float* mean, const float* rstd, float drop_p, const uint64_t* seed_ptr,
-                          uint64_t seed_imm, void* dx, void* dres, float* dgamma, float* dbeta, float* dbias, void* ws,
-                          void* stream) {
+                          const float* gamma, const float* mean, const float* rstd, float drop_p, int drop_after,
+                          const uint64_t* seed_ptr, uint64_t seed_imm, void* dx, void* dres, float* dgamma, float* dbeta,
+                          float* dbias, void* ws, void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
   UC2_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= LN_MAXC * 256);
   UC2_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
@@ -266,7 +279,7 @@ extern "C" int uc2_ln_bwd(int dtype, int M, int H, const void* dy, const void* x
 #define LN_BWD_LAUNCH(TT, NCC)                                                                                      \
   hipLaunchKernelGGL((ln_bwd_kernel<TT, NCC>), dim3(nb), dim3(256), 0, st, M, H, (const TT*)dy, (const TT*)x,        \
                      (const TT*)residual, gamma, mean, rstd, th, ks, seed_ptr, seed_imm, (TT*)dx, (TT*)dres,         \
-                     (float*)ws, dbias ? 1 : 0)
+                     (float*)ws, dbias ? 1 : 0, drop_after)
   if (dtype == 0) {
     if (nc == 1) LN_BWD_LAUNCH(float, 1); else if (nc == 2) LN_BWD_LAUNCH(float, 2);
     else if (nc == 3) LN_BWD_LAUNCH(float, 3); else LN_BWD_LAUNCH(float, 4);

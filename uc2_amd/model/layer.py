@@ -24,9 +24,11 @@ class BertLayerNorm(nn.Module):
         self.eps = eps
         self.normalized_shape = (hidden_size,)
 
-    def forward(self, x, residual=None, drop_p=0.0, seed_imm=0, beta_extra=None):
+    def forward(self, x, residual=None, drop_p=0.0, seed_imm=0, beta_extra=None, drop_after=False):
+        """LN(dropout_p(x) + residual); drop_after=True puts the dropout on the output (the embedding tails)"""
         x = ops.cast(x, compute_dtype_of(self)) if x.dtype != compute_dtype_of(self) else x
-        return ops.LayerNormFn.apply(x, residual, self, self.eps, drop_p, seed_imm, self.weight, self.bias, beta_extra)
+        return ops.LayerNormFn.apply(x, residual, self, self.eps, drop_p, seed_imm, self.weight, self.bias, beta_extra,
+                                     drop_after)
 
 
 LayerNorm = BertLayerNorm
@@ -43,18 +45,26 @@ class Linear(nn.Linear):
 
 
 def gelu(x):
-    raise RuntimeError("uc2_amd fuses GELU into the GEMM epilogue; call Linear(x, act=ops.EPI_GELU)")
+    """model/layer.py:31-37 (erf form)"""
+    return ops.GeluFn.apply(x)
 
 
 class GELU(nn.Module):
-    """placeholder so that nn.Sequential indices (net.0, net.2, net.3) match the reference state_dict"""
+    """model/layer.py:40-50 (GELU module wrapping gelu()): erf-form GELU as its own kernel.  The heads call their
+    Linear with act=EPI_GELU (fused epilogue) and skip this module; calling the Sequential the plain way
+    (`net(x)`) runs Linear -> this -> LayerNorm and gives the same result."""
 
     def forward(self, x):
-        return x
+        cd = compute_dtype_of(self)
+        if x.dtype != cd:
+            x = ops.cast(x, cd)
+        return ops.GeluFn.apply(x)
 
 
 class BertSelfAttention(nn.Module):
-    """parameters only (query/key/value Linear); the math runs inside BertLayerFn (fused QKV + attention)"""
+    """model/layer.py:53-101.  Inside a BertLayer the math runs in BertLayerFn (one autograd node); called on its
+    own, forward() composes the same kernels: one fused QKV GEMM over the adjacent q|k|v parameters, then the
+    fused attention kernel (scores never reach HBM), context written head-merged."""
 
     def __init__(self, config):
         super().__init__()
@@ -69,36 +79,71 @@ class BertSelfAttention(nn.Module):
         self.value = nn.Linear(config.hidden_size, self.all_head_size)
         self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
 
+    def forward(self, hidden_states, attention_mask):
+        """hidden_states [B,L,H], attention_mask [B,1,1,L] additive -> context [B,L,H] (model/layer.py:75-101)"""
+        cd = compute_dtype_of(self)
+        x = hidden_states if hidden_states.dtype == cd else ops.cast(hidden_states, cd)
+        B, L, H = x.shape
+        mask2d = ops._mask2d(attention_mask, B, L)
+        q, k, v = self.query, self.key, self.value
+        qkv = ops.FusedQKVFn.apply(x, self, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias)
+        p = self.dropout.p if self.training else 0.0
+        ctx = ops.AttentionFn.apply(qkv, mask2d, B, L, self.num_attention_heads, self.attention_head_size, p, 0x5341)
+        return ctx.view(B, L, H)
+
 
 class BertSelfOutput(nn.Module):
+    """model/layer.py:104-115: LayerNorm(dropout(dense(hidden_states)) + input_tensor)"""
+
     def __init__(self, config):
         super().__init__()
-        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.dense = Linear(config.hidden_size, config.hidden_size)
         self.LayerNorm = BertLayerNorm(config.hidden_size, eps=1e-12)
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
 
+    def forward(self, hidden_states, input_tensor):
+        p = self.dropout.p if self.training else 0.0
+        return self.LayerNorm(self.dense(hidden_states), input_tensor, p, 0x534F)
+
 
 class BertAttention(nn.Module):
+    """model/layer.py:118-127"""
+
     def __init__(self, config):
         super().__init__()
         self.self = BertSelfAttention(config)
         self.output = BertSelfOutput(config)
 
+    def forward(self, input_tensor, attention_mask):
+        self_output = self.self(input_tensor, attention_mask)
+        return self.output(self_output, input_tensor)
+
 
 class BertIntermediate(nn.Module):
+    """model/layer.py:130-142: gelu(dense(x)), GELU fused into the GEMM epilogue"""
+
     def __init__(self, config):
         super().__init__()
         if config.hidden_act != "gelu":
             raise ValueError("uc2_amd implements the erf-GELU feed-forward only (config/uc2-base.json)")
-        self.dense = nn.Linear(config.hidden_size, config.intermediate_size)
+        self.dense = Linear(config.hidden_size, config.intermediate_size)
+
+    def forward(self, hidden_states):
+        return self.dense(hidden_states, act=ops.EPI_GELU)
 
 
 class BertOutput(nn.Module):
+    """model/layer.py:145-156: LayerNorm(dropout(dense(hidden_states)) + input_tensor)"""
+
     def __init__(self, config):
         super().__init__()
-        self.dense = nn.Linear(config.intermediate_size, config.hidden_size)
+        self.dense = Linear(config.intermediate_size, config.hidden_size)
         self.LayerNorm = BertLayerNorm(config.hidden_size, eps=1e-12)
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def forward(self, hidden_states, input_tensor):
+        p = self.dropout.p if self.training else 0.0
+        return self.LayerNorm(self.dense(hidden_states), input_tensor, p, 0x424F)
 
 
 class BertLayer(nn.Module):
@@ -125,6 +170,13 @@ class BertLayer(nn.Module):
         new.__dict__.pop("_uc2_store_cache", None)
         _LAYER_COUNTER[0] += 1
         return new
+
+    def forward_unfused(self, hidden_states, attention_mask):
+        """the reference's composition (model/layer.py:166-170) through the sub-modules' own forward()s -- same
+        kernels, one autograd node per sub-module instead of one for the layer; used by the parity tests"""
+        attention_output = self.attention(hidden_states, attention_mask)
+        intermediate_output = self.intermediate(attention_output)
+        return self.output(intermediate_output, attention_output)
 
     def forward(self, hidden_states, attention_mask):
         cd = compute_dtype_of(self)

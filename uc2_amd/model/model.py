@@ -4,8 +4,8 @@ layout (reference model/model.py:1-776, 1143-1169), computing on the uc2 HIP ker
 Drop-in for:  VLXLMRConfig, VLXLMRPreTrainedModel (from_pretrained / init_weights),
 VLXLMRTextEmbeddings, VLXLMRImageEmbeddings, VLXLMREncoder, VLXLMRModel,
 VLXLMRForPretraining, RegionFeatureRegression, RegionClassification, pad_tensor_to_mul.
-Out of the hot path and not provided: the OT regulariser (ot_inputs) and the *-soft tasks
-(SURVEY.md §2.1, §8a a17).
+Every task of VLXLMRForPretraining.forward is provided, including the *-soft tasks and the OT
+regulariser of the ITM head.
 """
 import copy
 import json
@@ -212,9 +212,11 @@ class VLXLMRTextEmbeddings(nn.Module):
             position_ids = position_ids.expand_as(input_ids)
         e = ops.EmbedTextFn.apply(self, compute_dtype_of(self), input_ids, position_ids, token_type_ids,
                                   self.word_embeddings.weight, self.position_embeddings.weight,
-                                  self.new_token_type_embeddings.weight)
+                                  self.new_token_type_embeddings.weight,
+                                  -1 if self.word_embeddings.padding_idx is None else self.word_embeddings.padding_idx,
+                                  -1 if self.position_embeddings.padding_idx is None else self.position_embeddings.padding_idx)
         p = self.dropout.p if self.training else 0.0
-        return self.LayerNorm(e, None, p, 0x7E01)
+        return self.LayerNorm(e, None, p, 0x7E01, drop_after=True)       # dropout(LayerNorm(.)), model/model.py:331-333
 
 
 class VLXLMRImageEmbeddings(nn.Module):
@@ -245,7 +247,7 @@ class VLXLMRImageEmbeddings(nn.Module):
             s = ops.AddRowFn.apply(ti, tp, type_embeddings, 1)
         else:
             s = ti + tp + ops.cast(type_embeddings, cd)
-        return self.LayerNorm(s, None, p, 0x7E02)
+        return self.LayerNorm(s, None, p, 0x7E02, drop_after=True)       # dropout(LayerNorm(.)), model/model.py:361-363
 
 
 class VLXLMREncoder(nn.Module):
@@ -392,8 +394,9 @@ class VLXLMRForPretraining(VLXLMRPreTrainedModel):
             return self.forward_mmxlm(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                                       batch['img_masks'], batch['txt_labels'], compute_loss)
         elif task in ["mmxlm-soft", 'vmlm-soft']:
-            raise NotImplementedError("the *-soft tasks need the tokenizer-derived id list and are outside "
-                                      "the hot path (SURVEY.md §8a a17)")
+            return self.forward_mmxlm_soft(input_ids, position_ids, img_feat, img_pos_feat, attention_mask,
+                                           gather_index, batch['img_masks'], batch['tgt_masks'],
+                                           batch['label_targets'], compute_loss)
         elif task == 'mrfr':
             return self.forward_mrfr(input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                                      batch['img_masks'], batch['img_mask_tgt'], batch['feat_targets'], compute_loss)
@@ -442,6 +445,27 @@ class VLXLMRForPretraining(VLXLMRPreTrainedModel):
                                        gather_index, output_all_encoded_layers=False, img_masks=img_masks)
         masked_output = self._compute_masked_hidden(sequence_output, txt_labels != -1)
         return self._mlm_scores_or_loss(masked_output, txt_labels[txt_labels != -1], compute_loss)
+
+    def forward_mmxlm_soft(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
+                           img_masks, tgt_masks, label_targets, compute_loss=True):
+        """model/model.py:627-651: MLM head on the masked regions, restricted to the VALID_XLMR_TOKEN_IDS columns
+        (computed as a GEMM against those rows of the tied decoder only), KL against the soft labels"""
+        sequence_output = self.roberta(input_ids, position_ids, img_feat, img_pos_feat, attention_mask,
+                                       gather_index, output_all_encoded_layers=False, img_masks=img_masks)
+        masked_output = self._compute_masked_hidden(sequence_output, tgt_masks)
+        z = self.cls.transform(masked_output)
+        ids = self._valid_ids(z.device)
+        prediction_soft_label = ops.TiedSubsetDecoderFn.apply(z, self.cls, self.cls.decoder.weight, self.cls.bias, ids)
+        if compute_loss:
+            return ops.KLDivFn.apply(prediction_soft_label, label_targets, prediction_soft_label.shape[-1])
+        return prediction_soft_label
+
+    def _valid_ids(self, device):
+        ids = self.__dict__.get("_valid_ids_dev")
+        if ids is None or ids.device != device or ids.numel() != len(VALID_XLMR_TOKEN_IDS):
+            ids = torch.tensor(list(VALID_XLMR_TOKEN_IDS), dtype=torch.long, device=device)
+            self.__dict__["_valid_ids_dev"] = ids
+        return ids
 
     def forward_mrfr(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                      img_masks, img_mask_tgt, feat_targets, compute_loss=True):

@@ -52,7 +52,67 @@ class GemmTimer:
         return sorted(out, key=lambda r: -r[3])
 
 
-_CUR_VARIANT = -2
+HBM_TIMER = None       # bench.py installs an HbmTimer: HIP-event timing of the HBM-bound kernels with their algorithmic bytes
+
+
+class HbmTimer:
+    """HIP-event timing (on the launch stream) of the HBM-bound kernels of the step, each with its ALGORITHMIC
+    bytes (operands read once + results written once) -> GB/s against the HBM roofline"""
+
+    def __init__(self):
+        self.groups = {}
+
+    def tick(self, name, nbytes):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.groups.setdefault(name, []).append((nbytes, e0, e1))
+        return e1
+
+    def summary(self):
+        out = []
+        for name, recs in self.groups.items():
+            tot_b = sum(r[0] for r in recs)
+            tot_t = sum(r[1].elapsed_time(r[2]) for r in recs) * 1e-3
+            out.append((name, len(recs), tot_b, tot_t))
+        return sorted(out, key=lambda r: -r[3])
+
+
+class _Timed:
+    """with _Timed(name, bytes): launch  -- no-op unless bench.py installed ops.HBM_TIMER"""
+    __slots__ = ("e1",)
+
+    def __init__(self, name, nbytes):
+        t = HBM_TIMER
+        self.e1 = t.tick(name, nbytes) if t is not None else None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        if self.e1 is not None:
+            self.e1.record()
+        return False
+
+
+GEMM_AUTO, GEMM_GENERIC = -2, 99      # include/uc2_hip.h: UC2_GEMM_AUTO / UC2_GEMM_GENERIC
+GEMM_DEFER_REDUCE = 1
+_FORCED = [None]                       # tests/diagnostics only (force_variant); production passes the plan per call
+
+
+class force_variant:
+    """with ops.force_variant(8): ...  -- every gemm() inside that does not name a variant itself uses this one
+    (A/B tests and the bench_*.py diagnostics; the training path passes its tuned variant per call)"""
+
+    def __init__(self, variant, flags=0):
+        self.v = (variant, flags)
+
+    def __enter__(self):
+        self.prev, _FORCED[0] = _FORCED[0], self.v
+        return self
+
+    def __exit__(self, *exc):
+        _FORCED[0] = self.prev
+        return False
 
 
 def _require_cuda(t):
@@ -93,8 +153,10 @@ rng = _Rng()
 # raw kernel wrappers
 # --------------------------------------------------------------------------------------
 def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=None, epi=EPI_NONE,
-         aux_in=None, aux_out=None, accumulate=False, split_k=1, lda=None, ldb=None, ldc=None):
-    """C[M,N] (=|+=) epi(sum_k A(m,k) B(n,k) + bias[n]); see uc2_amd/csrc/gemm.hip."""
+         aux_in=None, aux_out=None, accumulate=False, split_k=1, lda=None, ldb=None, ldc=None, variant=None, flags=0):
+    """C[M,N] (=|+=) epi(sum_k A(m,k) B(n,k) + bias[n]); see uc2_amd/csrc/gemm.hip.
+    variant: kernel to use for THIS call (None = the library's default for the shape); the plan travels with the
+    call, the library holds no kernel-selection state."""
     _require_cuda(a)
     dtype = a.dtype
     assert b.dtype == dtype
@@ -108,32 +170,36 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
     for x in (aux_in, aux_out):
         if x is not None and x.dim() == 2:
             ldaux = x.stride(0)
-    two_stage = False
-    if _CUR_VARIANT == 8 and c_f32 and split_k > 1:
-        two_stage = _ensure_splitk_workspace(a.device, split_k * M * N * 4)
+    if variant is None:
+        if _FORCED[0] is not None:
+            variant, fflags = _FORCED[0]
+            flags |= fflags
+        else:
+            variant = GEMM_AUTO
+    ws = None
+    if variant == 8 and c_f32 and split_k > 1:
+        ws = _splitk_workspace(a.device, split_k * M * N * 4)
+    two_stage = ws is not None
     timer = GEMM_TIMER
-    if timer is not None and dtype == torch.bfloat16 and _CUR_VARIANT != -2:
+    if timer is not None and dtype == torch.bfloat16 and variant != GEMM_AUTO:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()                # on torch's current stream == the stream the kernel is launched on
     else:
         e0 = None
     defer = two_stage and e0 is not None         # time the GEMM kernel alone: run the reduction pass separately
     if defer:
-        call("uc2_gemm_defer_reduce", 1)
-    try:
-        call("uc2_gemm", dt(dtype), int(ta), int(tb), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc, int(c_f32),
-             ptr(bias), epi, ptr(aux_in), ptr(aux_out), ldaux, int(accumulate), split_k, stream())
-    finally:
-        if defer:
-            call("uc2_gemm_defer_reduce", 0)
+        flags |= GEMM_DEFER_REDUCE
+    call("uc2_gemm", dt(dtype), int(ta), int(tb), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc, int(c_f32),
+         ptr(bias), epi, ptr(aux_in), ptr(aux_out), ldaux, int(accumulate), split_k, variant,
+         ptr(ws), 0 if ws is None else ws.numel(), flags, stream())
     if e0 is not None:
         e1.record()
         if defer:
-            call("uc2_gemm_splitk_reduce", M, N, ptr(out), ldc, split_k, int(accumulate), stream())
-        if _CUR_VARIANT in (8, 9):  # ping-pong kernel: transposed accumulators unless fp32 atomics; the epilogue kind is a template argument
-            key = (bool(ta), bool(tb), _CUR_VARIANT, bool(c_f32 and not two_stage), int(epi))
+            call("uc2_gemm_splitk_reduce", M, N, ptr(out), ldc, split_k, int(accumulate), ptr(ws), ws.numel(), stream())
+        if variant in (8, 9):  # ping-pong kernel: transposed accumulators unless fp32 atomics; the epilogue kind is a template argument
+            key = (bool(ta), bool(tb), variant, bool(c_f32 and not two_stage), int(epi))
         else:
-            key = (bool(ta), bool(tb), _CUR_VARIANT, bool(c_f32 and split_k > 1), 0)
+            key = (bool(ta), bool(tb), variant, bool(c_f32 and split_k > 1), 0)
         timer.add(key, 2.0 * M * N * K, e0, e1)
     return out
 
@@ -141,17 +207,18 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
 _SPLITK_WS = {}
 
 
-def _ensure_splitk_workspace(device, nbytes):
-    """device scratch for the two-stage split-K reduction of the ping-pong kernel (uc2_gemm_set_workspace): grown
-    on demand, one per process (one process per GPU); every user runs on torch's current stream, in order"""
-    ws = _SPLITK_WS.get("ws")
-    if ws is None or ws.numel() < nbytes or ws.device != device:
+def _splitk_workspace(device, nbytes):
+    """caller-owned device scratch for the two-stage split-K reduction of the ping-pong kernel, handed to uc2_gemm with
+    each call: grown on demand, one per device; every user runs on torch's current stream, in order.  None when it
+    cannot be (re)allocated (stream capture): the kernel then reduces with fp32 atomics."""
+    key = (device.type, device.index)
+    ws = _SPLITK_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
-            return ws is not None and ws.device == device and ws.numel() >= nbytes
+            return None
         ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
-        _SPLITK_WS["ws"] = ws
-        _lib.call("uc2_gemm_set_workspace", ws.data_ptr(), ws.numel())
-    return True
+        _SPLITK_WS[key] = ws
+    return ws
 
 
 def _wgrad_split(dtype, n_out, n_in, rows):
@@ -167,6 +234,27 @@ def _wgrad_split(dtype, n_out, n_in, rows):
 # ---- per-shape kernel selection: measured once per (layout, shape) on the device, then cached ----------
 AUTOTUNE = True
 _TUNE = {}
+_MAX_TUNED = 256          # cap on tuned shapes (each tuning costs ~30 candidates x 7 launches + a host sync)
+
+
+def _bucket_key(key):
+    ta, tb, M, N, K, wgrad = key
+    r = lambda x: (x + 511) // 512 * 512
+    return (ta, tb, M, N, r(K), wgrad) if wgrad else (ta, tb, r(M), N, K, wgrad)
+
+
+def _plan_fits(plan, key):
+    """can the kernel of `plan` run the shape `key` (else the library would silently take its generic kernel)"""
+    v, sp = plan
+    ta, tb, M, N, K, wgrad = key
+    if v in (8, 9):
+        rows = 192 if v == 9 else 256
+        kt = K // 64
+        per = ((kt + sp - 1) // sp + 1) & ~1
+        return M % rows == 0 and N % 256 == 0 and K % 128 == 0 and kt - (sp - 1) * per >= 2
+    if wgrad and sp * 1024 > K:
+        return False
+    return K % 64 == 0
 _FWD_CANDIDATES = ((99, 1), (0, 1), (1, 1), (2, 1), (6, 1), (7, 1), (8, 1))     # (kernel variant, split_k); 99 = generic kernel, 8 = ping-pong
 _WGRAD_SPLITS = (2, 3, 4, 6, 8, 12, 16)
 
@@ -219,12 +307,24 @@ def gemm_plan(dtype, ta, tb, M, N, K, wgrad=False):
     and caches the winner; later calls are a dict lookup.  fp32 (parity mode) and small shapes use defaults."""
     if dtype != torch.bfloat16:
         return -2, (_wgrad_split(dtype, M, N, K) if wgrad else 1)
+    global GEMM_TIMER
     key = (bool(ta), bool(tb), M, N, K, wgrad)
     hit = _TUNE.get(key)
     if hit is not None:
         return hit
     default = (-2, _wgrad_split(dtype, M, N, K) if wgrad else 1)
     if (not AUTOTUNE) or float(M) * N * K < 2.0 ** 31 or torch.cuda.is_current_stream_capturing():
+        return default
+    # The token dimension (M forward / dgrad, K for weight gradients) changes almost every step under the reference's
+    # token-bucket batching (data/sampler.py:11-59): tune one representative per 512-token bucket and reuse its plan
+    # if the kernel accepts the real shape (tile divisibility is re-checked by the library, which falls back to the
+    # generic kernel), and stop tuning after _MAX_TUNED shapes.
+    bkey = _bucket_key(key)
+    hit = _TUNE.get(bkey)
+    if hit is not None and _plan_fits(hit, key):
+        _TUNE[key] = hit
+        return hit
+    if len(_TUNE) >= _MAX_TUNED:
         return default
     dev = torch.device("cuda", torch.cuda.current_device())
     a = torch.randn((K, M) if ta else (M, K), device=dev).to(torch.bfloat16)
@@ -242,29 +342,23 @@ def gemm_plan(dtype, ta, tb, M, N, K, wgrad=False):
             if s * 256 <= K:
                 cands.append((8, s))
     best, best_t = default, None
-    for v, sp in cands:
-        lib.uc2_gemm_set_variant(v)
-        t = _time_gemm(lambda: gemm(a, b, M, N, K, ta=ta, tb=tb, out=out, accumulate=wgrad, split_k=sp))
-        if best_t is None or t < best_t:
-            best, best_t = (v, sp), t
-    lib.uc2_gemm_set_variant(-2)
+    timer_was, GEMM_TIMER = GEMM_TIMER, None          # tuning launches are not part of anybody's timed region
+    try:
+        for v, sp in cands:
+            t = _time_gemm(lambda: gemm(a, b, M, N, K, ta=ta, tb=tb, out=out, accumulate=wgrad, split_k=sp, variant=v))
+            if best_t is None or t < best_t:
+                best, best_t = (v, sp), t
+    finally:
+        GEMM_TIMER = timer_was
     _TUNE[key] = best
+    _TUNE.setdefault(bkey, best)
     return best
 
 
 def _gemm_planned(a, b, M, N, K, ta, tb, wgrad=False, **kw):
-    global _CUR_VARIANT
+    """one GEMM with its tuned (variant, split_k) plan, passed to the library with the call"""
     v, sp = gemm_plan(a.dtype, ta, tb, M, N, K, wgrad)
-    lib = _lib.load()
-    if v != -2:
-        lib.uc2_gemm_set_variant(v)
-        _CUR_VARIANT = v
-    try:
-        return gemm(a, b, M, N, K, ta=ta, tb=tb, split_k=sp, **kw)
-    finally:
-        if v != -2:
-            lib.uc2_gemm_set_variant(-2)
-            _CUR_VARIANT = -2
+    return gemm(a, b, M, N, K, ta=ta, tb=tb, split_k=sp, variant=v, **kw)
 
 
 def linear_fwd(x2, w, bias, epi=EPI_NONE, aux_out=None):
@@ -346,27 +440,32 @@ def colsum_accum(x2, out, rowmask=None):
     call("uc2_colsum_accum", dt(x2.dtype), M, N, ptr(x2), x2.stride(0), ptr(rowmask), ptr(out), stream())
 
 
-def ln_fwd(x2, res2, gamma, beta, eps, drop_p=0.0, seed=None, seed_imm=0, want_stats=True):
+def ln_fwd(x2, res2, gamma, beta, eps, drop_p=0.0, seed=None, seed_imm=0, want_stats=True, drop_after=False):
+    """y = LN(dropout(x) + res) (drop_after False: the encoder's dense->dropout->LN tails) or
+    y = dropout(LN(x + res)) (drop_after True: the embedding tails, model/model.py:331-333,361-363)"""
     M, H = x2.shape
     y = torch.empty_like(x2)
     mean = torch.empty(M, dtype=torch.float32, device=x2.device) if want_stats else None
     rstd = torch.empty(M, dtype=torch.float32, device=x2.device) if want_stats else None
-    call("uc2_ln_fwd", dt(x2.dtype), M, H, ptr(x2), ptr(res2), ptr(gamma), ptr(beta), eps, drop_p, ptr(seed), seed_imm,
-         ptr(y), ptr(mean), ptr(rstd), stream())
+    with _Timed("ln_fwd", M * H * x2.element_size() * (3 if res2 is not None else 2)):
+        call("uc2_ln_fwd", dt(x2.dtype), M, H, ptr(x2), ptr(res2), ptr(gamma), ptr(beta), eps, drop_p, int(drop_after),
+             ptr(seed), seed_imm, ptr(y), ptr(mean), ptr(rstd), stream())
     return y, mean, rstd
 
 
 def ln_bwd(dy2, x2, res2, gamma, mean, rstd, dgamma, dbeta, drop_p=0.0, seed=None, seed_imm=0, need_dres=True,
-           dbias=None):
+           dbias=None, drop_after=False):
     """returns (dx, dres); with drop_p == 0 they are the same tensor.  dbias (optional, fp32 [H]) accumulates
     the column sum of dx: the bias gradient of the dense layer that produced x, for free in the same pass."""
     M, H = x2.shape
     lib = _lib.load()
     ws = torch.empty(lib.uc2_ln_bwd_workspace(M, H) // 4, dtype=torch.float32, device=x2.device)
     dx = torch.empty_like(x2)
-    dres = torch.empty_like(x2) if (drop_p > 0.0 and need_dres) else None
-    call("uc2_ln_bwd", dt(x2.dtype), M, H, ptr(dy2), ptr(x2), ptr(res2), ptr(gamma), ptr(mean), ptr(rstd), drop_p,
-         ptr(seed), seed_imm, ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(ws), stream())
+    dres = torch.empty_like(x2) if (drop_p > 0.0 and need_dres and not drop_after) else None
+    streams = 3 + (1 if res2 is not None else 0) + (1 if dres is not None else 0)     # dy, x, (res) in; dx, (dres) out
+    with _Timed("ln_bwd", M * H * x2.element_size() * streams):
+        call("uc2_ln_bwd", dt(x2.dtype), M, H, ptr(dy2), ptr(x2), ptr(res2), ptr(gamma), ptr(mean), ptr(rstd), drop_p,
+             int(drop_after), ptr(seed), seed_imm, ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(ws), stream())
     return dx, (dres if dres is not None else dx)
 
 
@@ -374,16 +473,18 @@ def attn_fwd(qkv, mask2d, B, L, nh, D, drop_p=0.0, seed=None, seed_imm=0, impl=N
     H = nh * D
     ctx = torch.empty((B * L, H), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, nh, L), dtype=torch.float32, device=qkv.device)
-    call("uc2_attn_fwd", dt(qkv.dtype), ATTN_IMPL if impl is None else impl, B, L, nh, D, ptr(qkv), ptr(mask2d),
-         1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(lse), stream())
+    with _Timed("attn_fwd", B * L * H * qkv.element_size() * 4 + B * nh * L * 4):       # q,k,v in; ctx, lse out
+        call("uc2_attn_fwd", dt(qkv.dtype), ATTN_IMPL if impl is None else impl, B, L, nh, D, ptr(qkv), ptr(mask2d),
+             1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(lse), stream())
     return ctx, lse
 
 
 def attn_bwd(qkv, mask2d, ctx, dctx, lse, B, L, nh, D, drop_p=0.0, seed=None, seed_imm=0, impl=None, dbias=None):
     """dqkv; with dbias (fp32 [3H]) also dbias += column sums of dqkv = the gradient of the fused q|k|v bias"""
     dqkv = torch.empty_like(qkv)
-    call("uc2_attn_bwd", dt(qkv.dtype), ATTN_IMPL if impl is None else impl, B, L, nh, D, ptr(qkv), ptr(mask2d),
-         1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(dbias), stream())
+    with _Timed("attn_bwd", B * L * nh * D * qkv.element_size() * 8 + B * nh * L * 4):   # qkv, ctx, dctx, lse in; dqkv out
+        call("uc2_attn_bwd", dt(qkv.dtype), ATTN_IMPL if impl is None else impl, B, L, nh, D, ptr(qkv), ptr(mask2d),
+             1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(dbias), stream())
     return dqkv
 
 
@@ -583,11 +684,107 @@ def _dgelu(dy2, pre):
     return out
 
 
-class LayerNormFn(torch.autograd.Function):
-    """y = LN(dropout(x) + residual) * gamma + beta   (residual optional)"""
+class GeluFn(torch.autograd.Function):
+    """x * 0.5 * (1 + erf(x / sqrt 2)) as a stand-alone activation (model/layer.py:31-37)"""
 
     @staticmethod
-    def forward(ctx, x, residual, owner, eps, drop_p, seed_imm, gamma, beta, beta_extra):
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        call("uc2_gelu", dt(x.dtype), x.numel(), ptr(x), ptr(y), stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return _dgelu(dy.contiguous(), x)
+
+
+class FusedQKVFn(torch.autograd.Function):
+    """q|k|v = x [Wq;Wk;Wv]^T + [bq;bk;bv] in ONE GEMM over the adjacent arena slices of the three nn.Linear
+    parameters (model/layer.py:76-78 runs three); gradients go straight into the matching gradient-arena span"""
+
+    @staticmethod
+    def forward(ctx, x, owner, qw, qb, kw, kb, vw, vb):
+        st = store_of(owner)
+        dtype = x.dtype
+        if dtype == torch.bfloat16:
+            st.sync_shadow()
+        H = qw.shape[1]
+        x2 = x.reshape(-1, H)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        wqkv = st.compute_span(qw, vw, (3 * qw.shape[0], H), dtype)
+        bqkv = st.span(st.data, qb, vb, (3 * qw.shape[0],))
+        qkv = linear_fwd(x2, wqkv, bqkv)
+        ctx.save_for_backward(x2)
+        ctx.owner, ctx.ps, ctx.shp = owner, (qw, qb, kw, kb, vw, vb), x.shape
+        return qkv
+
+    @staticmethod
+    def backward(ctx, dqkv):
+        (x2,) = ctx.saved_tensors
+        qw, qb, kw, kb, vw, vb = ctx.ps
+        st = store_of(ctx.owner)
+        H = qw.shape[1]
+        dqkv = dqkv.contiguous()
+        linear_wgrad(dqkv, x2, st.grad_span(qw, vw, (3 * qw.shape[0], H)), st.grad_span(qb, vb, (3 * qw.shape[0],)))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = linear_dgrad(dqkv, st.compute_span(qw, vw, (3 * qw.shape[0], H), x2.dtype)).view(ctx.shp)
+        return (dx,) + (None,) * 7
+
+
+class TiedSubsetDecoderFn(torch.autograd.Function):
+    """logits over a SUBSET of the tied decoder's columns: (z E^T + bias)[:, ids] == z E[ids]^T + bias[ids]
+    (forward_mmxlm_soft, model/model.py:639-642, keeps 2857 of 250 002 columns): the full-vocabulary logits are
+    never formed; dE rows / dbias entries of the subset are accumulated into the gradient arena (ids unique)."""
+
+    @staticmethod
+    def forward(ctx, z, owner, weight, bias, ids):
+        st = store_of(owner)
+        dtype = z.dtype
+        if dtype == torch.bfloat16:
+            st.sync_shadow()
+        n, H = z.shape
+        nv = ids.numel()
+        z = z.contiguous()
+        wsub = torch.empty((nv, H), dtype=dtype, device=z.device)
+        wc = st.compute(weight, dtype)
+        call("uc2_select_rows", dt(dtype), nv, H, ptr(wc), wc.stride(0), ptr(ids), ptr(wsub), H, 0, stream())
+        bsub = torch.empty(nv, dtype=torch.float32, device=z.device)
+        call("uc2_gather_f32", nv, ptr(bias.data), ptr(ids), ptr(bsub), 0, stream())
+        y = gemm(z, wsub, n, nv, H, bias=bsub)
+        ctx.save_for_backward(z, wsub, ids)
+        ctx.owner, ctx.wb = owner, (weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, wsub, ids = ctx.saved_tensors
+        weight, bias = ctx.wb
+        st = store_of(ctx.owner)
+        n, H = z.shape
+        nv = ids.numel()
+        dy = dy.contiguous()
+        dwsub = torch.zeros((nv, H), dtype=torch.float32, device=z.device)
+        gemm(dy, z, nv, H, n, ta=True, tb=True, out=dwsub, accumulate=True)
+        dE = st.grad_buf(weight)
+        call("uc2_select_rows", 0, nv, H, ptr(dwsub), H, ptr(ids), ptr(dE), dE.stride(0), 2, stream())
+        dbsub = torch.zeros(nv, dtype=torch.float32, device=z.device)
+        colsum_accum(dy, dbsub)
+        call("uc2_gather_f32", nv, ptr(dbsub), ptr(ids), ptr(st.grad_buf(bias)), 1, stream())
+        dz = gemm(dy, wsub, n, H, nv, tb=True)
+        return dz, None, None, None, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    """y = LN(dropout(x) + residual) * gamma + beta   (residual optional); with drop_after the dropout
+    sits on the output instead: y = dropout(LN(x + residual) * gamma + beta)"""
+
+    @staticmethod
+    def forward(ctx, x, residual, owner, eps, drop_p, seed_imm, gamma, beta, beta_extra, drop_after=False):
         st = store_of(owner)
         shp = x.shape
         H = shp[-1]
@@ -601,16 +798,16 @@ class LayerNormFn(torch.autograd.Function):
                 r2 = r2.contiguous()
         seed = rng.snapshot(x.device) if drop_p > 0 else None
         b = beta.data if beta_extra is None else (beta.data + beta_extra.data)
-        y, mean, rstd = ln_fwd(x2, r2, gamma.data, b, eps, drop_p, seed, seed_imm)
+        y, mean, rstd = ln_fwd(x2, r2, gamma.data, b, eps, drop_p, seed, seed_imm, drop_after=drop_after)
         ctx.save_for_backward(x2, r2, mean, rstd, seed)
-        ctx.owner, ctx.gb, ctx.cfg, ctx.shp = owner, (gamma, beta, beta_extra), (drop_p, seed_imm), shp
+        ctx.owner, ctx.gb, ctx.cfg, ctx.shp = owner, (gamma, beta, beta_extra), (drop_p, seed_imm, drop_after), shp
         return y.view(shp)
 
     @staticmethod
     def backward(ctx, dy):
         x2, r2, mean, rstd, seed = ctx.saved_tensors
         gamma, beta, beta_extra = ctx.gb
-        drop_p, seed_imm = ctx.cfg
+        drop_p, seed_imm, drop_after = ctx.cfg
         st = store_of(ctx.owner)
         H = x2.shape[1]
         dy2 = dy.reshape(-1, H)
@@ -618,22 +815,24 @@ class LayerNormFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         dbeta = st.grad_buf(beta)
         dx, dres = ln_bwd(dy2, x2, r2, gamma.data, mean, rstd, st.grad_buf(gamma), dbeta, drop_p, seed, seed_imm,
-                          need_dres=r2 is not None)
+                          need_dres=r2 is not None, drop_after=drop_after)
         dextra = None
         if beta_extra is not None and ctx.needs_input_grad[8]:
             # d(beta + extra) flows to both; beta got it through the arena, extra gets a fresh column sum
+            if drop_after and drop_p > 0:
+                raise _lib.Uc2Error("beta_extra with output dropout is not supported")
             dextra = torch.zeros(H, dtype=torch.float32, device=dy.device)
             colsum_accum(dy2, dextra)
         return (dx.view(ctx.shp) if ctx.needs_input_grad[0] else None,
                 dres.view(ctx.shp) if (r2 is not None and ctx.needs_input_grad[1]) else None,
-                None, None, None, None, None, None, dextra)
+                None, None, None, None, None, None, dextra, None)
 
 
 class EmbedTextFn(torch.autograd.Function):
     """word[ids] + pos[pos_ids] + type[type_ids or 0]  (model/model.py:322-330), output in compute dtype"""
 
     @staticmethod
-    def forward(ctx, owner, dtype, ids, pos_ids, type_ids, word, pos, typ):
+    def forward(ctx, owner, dtype, ids, pos_ids, type_ids, word, pos, typ, word_pad=-1, pos_pad=-1):
         B, T = ids.shape
         H = word.shape[1]
         out = torch.empty((B, T, H), dtype=dtype, device=ids.device)
@@ -642,7 +841,7 @@ class EmbedTextFn(torch.autograd.Function):
         call("uc2_embed_fwd", dt(dtype), B * T, H, ptr(ids_c), ptr(pos_c), ptr(ty_c), 0, ptr(word.data), ptr(pos.data),
              ptr(typ.data), ptr(out), stream())
         ctx.save_for_backward(ids_c, pos_c, ty_c)
-        ctx.owner, ctx.tabs, ctx.H = owner, (word, pos, typ), H
+        ctx.owner, ctx.tabs, ctx.H, ctx.pads = owner, (word, pos, typ), H, (int(word_pad), int(pos_pad))
         return out
 
     @staticmethod
@@ -657,10 +856,10 @@ class EmbedTextFn(torch.autograd.Function):
         rows = d2.shape[0]
         dtyp = st.grad_buf(typ)
         call("uc2_embed_bwd", dt(d2.dtype), rows, H, ptr(ids), ptr(pos_ids), ptr(type_ids), ptr(d2),
-             ptr(st.grad_buf(word)), ptr(st.grad_buf(pos)), ptr(dtyp), stream())
+             ptr(st.grad_buf(word)), ptr(st.grad_buf(pos)), ptr(dtyp), ctx.pads[0], ctx.pads[1], stream())
         if type_ids is None:         # constant type 0: its row gets the column sum (no atomic pile-up on one row)
             colsum_accum(d2, dtyp[0])
-        return (None,) * 8
+        return (None,) * 10
 
 
 class GatherRowsFn(torch.autograd.Function):

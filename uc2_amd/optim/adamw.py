@@ -75,10 +75,27 @@ class AdamW(Optimizer):
             recs.append((p, gi, pi, m, v, st if in_store else None))
         self._plan = dict(recs=recs, dev=dev, stores=list(stores.values()), n_params=len(plist),
                           steps_dev=torch.tensor(steps, dtype=torch.int32, device=dev),
-                          active_host=torch.zeros(len(plist), dtype=torch.int32).pin_memory(),
-                          active_dev=torch.zeros(len(plist), dtype=torch.int32, device=dev),
+                          active_list=None, active_dev=None,
                           table=None, table_key=None, n_chunks=0)
         return self._plan
+
+    # the plan caches the moments and step counts on the device: anything that replaces optimizer state or the
+    # parameter list has to drop it (the next step() rebuilds it from self.state)
+    def load_state_dict(self, state_dict):
+        super(AdamW, self).load_state_dict(state_dict)
+        self._plan = None
+
+    def add_param_group(self, param_group):
+        super(AdamW, self).add_param_group(param_group)
+        self._plan = None
+
+    def _plan_valid(self, plan):
+        for (p, gi, pi, m, v, st) in plan["recs"]:
+            if st is not None and not st.owns(p):
+                return False              # the module was re-homed (.to(), a new ParamStore): rebuild
+            if p.device != plan["dev"]:
+                return False
+        return True
 
     def _chunk_table(self, plan, want_p16):
         """device table of (p, g, m, v, p16, n, group, param) records; g = the gradient (arena view)"""
@@ -119,24 +136,35 @@ class AdamW(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        plan = self._plan or self._build_plan()
+        plan = self._plan
+        if plan is not None and not self._plan_valid(plan):
+            for (p, gi, pi, m, v, st) in plan["recs"]:          # keep the moments: they become the resumed state
+                self.state[p]['exp_avg'], self.state[p]['exp_avg_sq'] = m.clone(), v.clone()
+            plan = None
+        plan = plan or self._build_plan()
         if plan is None:
             return loss
         from .. import ops
         ops.join_side_streams()
-        ah = plan["active_host"]
+        active = [0] * plan["n_params"]
         any_active = False
         for (p, gi, pi, m, v, st) in plan["recs"]:
-            a = 1 if p.grad is not None else 0            # parameters without a gradient are skipped (adamw.py:52-53)
-            ah[pi] = a
-            if a:
-                any_active = True
-                self.state[p]['step'] += 1
-                if st is None and (p.grad.dtype != torch.float32 or not p.grad.is_contiguous()):
-                    raise _lib.Uc2Error("AdamW expects contiguous fp32 gradients")
+            if p.grad is None:                            # parameters without a gradient are skipped (adamw.py:52-53)
+                continue
+            active[pi] = 1
+            any_active = True
+            self.state[p]['step'] += 1
+            if st is not None:
+                st.grad_buf(p)                            # a gradient produced outside the arena is folded into it
+            elif p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
+                raise _lib.Uc2Error("AdamW expects contiguous fp32 gradients")
         if not any_active:
             return loss
-        plan["active_dev"].copy_(ah, non_blocking=True)
+        if active != plan["active_list"]:
+            # a NEW device tensor per distinct mask, filled by a synchronous pageable copy: the host never rewrites a
+            # buffer an earlier step's (still queued) kernel or copy reads -- tasks change the mask every few steps
+            plan["active_dev"] = torch.tensor(active, dtype=torch.int32, device=plan["dev"])
+            plan["active_list"] = active
         want_p16 = any(st.shadow is not None for st in plan["stores"])
         table, n_chunks = self._chunk_table(plan, want_p16)
         ng = len(self.param_groups)
@@ -148,8 +176,11 @@ class AdamW(Optimizer):
         eps = F(*[float(g['eps']) for g in self.param_groups])
         wd = F(*[float(g['weight_decay']) for g in self.param_groups])
         cb = Iarr(*[1 if g['correct_bias'] else 0 for g in self.param_groups])
-        call("uc2_adamw_step", ptr(table), n_chunks, plan["n_params"], ng, lr, b1, b2, eps, wd, cb,
-             ptr(plan["active_dev"]), ptr(plan["steps_dev"]), ptr(grad_scale), int(zero_grad), stream())
+        n_act = sum(p.numel() for (p, gi, pi, m, v, st) in plan["recs"] if active[pi])
+        # algorithmic bytes per active parameter: g 4 (+4 cleared), p/m/v 8 each, bf16 copy 2
+        with ops._Timed("adamw", n_act * (28 + (4 if zero_grad else 0) + (2 if want_p16 else 0))):
+            call("uc2_adamw_step", ptr(table), n_chunks, plan["n_params"], ng, lr, b1, b2, eps, wd, cb,
+                 ptr(plan["active_dev"]), ptr(plan["steps_dev"]), ptr(grad_scale), int(zero_grad), stream())
         for st in plan["stores"]:
             st.version += 1
             if want_p16 and st.shadow is not None:

@@ -38,7 +38,7 @@ def _pack_groups(named):
     for n, p in named:
         if n in used:
             continue
-        if n.endswith("attention.self.query.weight") or n.endswith("self.query.weight"):
+        if n == "query.weight" or n.endswith(".query.weight"):
             base = n[:-len("query.weight")]
             grp_w = [base + k + ".weight" for k in ("query", "key", "value")]
             grp_b = [base + k + ".bias" for k in ("query", "key", "value")]

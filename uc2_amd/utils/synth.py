@@ -106,8 +106,32 @@ def _gather_index(txt_lens, num_bbs, bs, max_len, out_size):
     return gi
 
 
+def tlm_position_ids(row_ids):
+    """data/mlm.py:420-429: positions count up from 3 and restart at 2 on every <s> (id 0), so the second
+    caption of a TLM pair gets its own position range"""
+    out, pos = [], 2
+    for t in row_ids:
+        pos = 2 if t == 0 else pos + 1
+        out.append(pos)
+    return out
+
+
+def ot_inputs_for(txt_lens, num_bbs, max_tl, max_bb, joint_len):
+    """data/itm.py:264-278,303-309: scatter index back to the padded [txt | img] layout and the pad masks
+    (bool here; the reference builds uint8 masks, which torch >= 1.2 treats as bool)"""
+    sc = torch.arange(0, joint_len, dtype=torch.long).unsqueeze(0).repeat(len(txt_lens), 1)
+    for i, tl in enumerate(txt_lens):
+        sc[i, tl:] = torch.arange(max_tl, max_tl + (joint_len - tl), dtype=torch.long)
+    tp = torch.zeros(len(txt_lens), max_tl, dtype=torch.bool)
+    ip = torch.zeros(len(num_bbs), max_bb, dtype=torch.bool)
+    for i, (tl, nb) in enumerate(zip(txt_lens, num_bbs)):
+        tp[i, tl:] = True
+        ip[i, nb:] = True
+    return {"ot_scatter": sc, "scatter_max": int(sc.max().item()), "txt_pad": tp, "img_pad": ip}
+
+
 def make_batch(vocab_size, B, T, R, task="itm", seed=1, img_dim=2048, img_label_dim=1601,
-               variable_len=False, sample_size=None):
+               variable_len=False, sample_size=None, n_soft=45, ot=False):
     """One synthetic batch with the reference's dict keys.
 
     Fixed length (default): every pair has T tokens and R regions, attn mask all
@@ -145,7 +169,22 @@ def make_batch(vocab_size, B, T, R, task="itm", seed=1, img_dim=2048, img_label_
                         gather_index=_gather_index(tls, nbs, B, max_tl, out_size))
     batch["_txt_lens"], batch["_num_bbs"] = tls, nbs
 
+    if task in ("tlm", "tlm-ni"):
+        # two captions per sample: a second <s> in the middle (data/mlm.py TLM datasets), batch position_ids
+        for i, tl in enumerate(tls):
+            input_ids[i, max(2, tl // 2)] = 0
+        pid = torch.ones(B, max_tl, dtype=torch.long)                # pad_sequence(..., padding_value=1), data/mlm.py:822
+        for i, tl in enumerate(tls):
+            pid[i, :tl] = torch.tensor(tlm_position_ids(input_ids[i, :tl].tolist()))
+        batch["position_ids"] = pid
+    if task == "tlm-ni":                                             # data/mlm.py:803-843: text only, no gather
+        a = torch.zeros(B, max_tl, dtype=torch.long)
+        for i, tl in enumerate(tls):
+            a[i, :tl] = 1
+        batch["attn_masks"] = a
+        batch["gather_index"] = None
     if task in ("mlm", "tlm", "tlm-ni", "vmlm", "mmxlm"):
+        input_ids = batch["input_ids"]
         lab = torch.full((B, max_tl), -1, dtype=torch.long)
         pick = det_bernoulli((B, max_tl), s + 6, 0.15)
         for i, tl in enumerate(tls):
@@ -174,6 +213,21 @@ def make_batch(vocab_size, B, T, R, task="itm", seed=1, img_dim=2048, img_label_
             batch["txt_labels"] = lab
     if task == "itm":
         batch["targets"] = det_bernoulli((B,), s + 9, 0.5).long()
+        if ot:
+            batch["targets"][0], batch["targets"][-1] = 1, 0        # both OT branches non-empty
+            batch["ot_inputs"] = ot_inputs_for(tls, nbs, max_tl, max_bb, out_size)
+    if task in ("vmlm-soft", "mmxlm-soft"):
+        # model/model.py:627-651: masked regions predict a soft distribution over the VALID token subset
+        im = _img_masks(B, max_bb, nbs, s + 7)
+        batch["img_masks"] = im
+        tgt = torch.zeros(B, out_size, dtype=torch.bool)
+        for i, (tl, nb) in enumerate(zip(tls, nbs)):
+            tgt[i, tl:tl + nb] = im[i, :nb]
+        batch["tgt_masks"] = tgt
+        soft = det_uniform((B, max_bb, n_soft), s + 11, 0.0, 1.0) ** 4
+        soft = soft / soft.sum(-1, keepdim=True)
+        batch["label_targets"] = soft[im].contiguous()
+        batch["img_feat"] = feat.masked_fill(im.unsqueeze(-1), 0)
     if task in ("mrfr",) or task.startswith("mrc"):
         im = _img_masks(B, max_bb, nbs, s + 7)
         batch["img_masks"] = im
