@@ -181,6 +181,9 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a))
+    if os.environ.get("UC2_HANG_TRACE"):               # debugging aid: dump every thread's stack after N seconds and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["UC2_HANG_TRACE"]), exit=True)
     import torch
     import torch.distributed as dist
     from uc2_amd import ops

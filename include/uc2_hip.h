@@ -58,12 +58,15 @@ int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, const voi
  *              gradients: partial tiles are stored plainly and reduced in a second pass instead of fp32 atomics
  *              (bit-reproducible); NULL = atomics.
  *   flags      UC2_GEMM_DEFER_REDUCE: stop after the partial tiles, the caller runs uc2_gemm_splitk_reduce itself
- *              (lets a profiler time the two passes separately); UC2_GEMM_SKEW(n): ping-pong start skew between phase
+ *              (lets a profiler time the two passes separately); UC2_GEMM_AUX_DERIV: the GELU epilogue saves
+ *              gelu'(pre) instead of pre in aux_out and the DGELU epilogue multiplies by aux_in as it is (the
+ *              derivative comes almost free beside the forward's Phi(x); the backward GEMM loses its transcendental
+ *              epilogue); a forward/backward pair must agree on it; UC2_GEMM_SKEW(n): ping-pong start skew between phase
  *              groups, n * ~8k cycles; UC2_GEMM_DIAG(m): diagnostic launch modes (tests/bench_pp.py), 0 in production. */
 enum { UC2_GEMM_AUTO = -2, UC2_GEMM_GENERIC = 99 };
-enum { UC2_GEMM_DEFER_REDUCE = 1 };
+enum { UC2_GEMM_DEFER_REDUCE = 1, UC2_GEMM_AUX_DERIV = 2 };
 #define UC2_GEMM_SKEW(n) (((n) & 15) << 4)
-#define UC2_GEMM_DIAG(m) (((m) & 0xFFF) << 8)
+#define UC2_GEMM_DIAG(m) (((m) & 0xFFFF) << 8)
 int uc2_gemm_splitk_reduce(int M, int N, void* C, int ldc, int split_k, int accumulate, const void* workspace,
                            size_t workspace_bytes, void* stream);
 

@@ -18,7 +18,9 @@ def pytest_collection_modifyitems(config, items):
     # works on both kinds of machine; `-m gpu` / `-m "not gpu"` select explicitly.
     try:
         import torch
-        have = torch.cuda.is_available()
+        # device_count() does not initialise the GPU in this process (is_available() does): tests/test_gpu_dist.py
+        # has to start its rank processes from a process that has not touched the GPU yet
+        have = torch.cuda.device_count() > 0
     except Exception:
         have = False
     if have:

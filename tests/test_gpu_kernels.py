@@ -399,6 +399,31 @@ def test_gemm_pingpong_persistent():
 
 
 @pytest.mark.parametrize("variant", [8, 7, 99])
+def test_gemm_gelu_saves_derivative_for_the_backward(variant):
+    """UC2_GEMM_AUX_DERIV: the GELU epilogue stores gelu'(pre) (not pre) and the DGELU epilogue multiplies by it as
+    is -- same results as the (pre, gelu'(pre)-in-the-backward) pair, in every kernel family"""
+    M, N, K = 1024, 768, 768
+    x = rnd((M, K), 1, dtype=torch.bfloat16)
+    w = rnd((N, K), 2, 0.05, dtype=torch.bfloat16)
+    bias = rnd((N,), 3)
+    d = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    u = ops.gemm(x, w, M, N, K, bias=bias, epi=ops.EPI_GELU, aux_out=d, variant=variant, flags=ops.GEMM_AUX_DERIV)
+    pre = (x.float() @ w.float().t() + bias).requires_grad_(True)
+    ref = torch.nn.functional.gelu(pre)
+    ref.sum().backward()
+    assert rel_err(u.float(), ref) < 4e-3
+    assert rel_err(d.float(), pre.grad) < 4e-3
+    dy = rnd((M, K), 4, dtype=torch.bfloat16)
+    w2 = rnd((K, N), 5, 0.05, dtype=torch.bfloat16)
+    acc = rnd((N,), 6)
+    got = acc.clone()
+    dpre = ops.gemm(dy, w2, M, N, K, tb=True, epi=ops.EPI_DGELU, aux_in=d, aux_out=got, variant=variant, flags=ops.GEMM_AUX_DERIV)
+    want = (dy.float() @ w2.float()) * d.float()
+    assert rel_err(dpre.float(), want) < 4e-3
+    assert rel_err(got, acc + dpre.float().sum(0)) < 2e-3
+
+
+@pytest.mark.parametrize("variant", [8, 7, 99])
 def test_gemm_dgelu_fused_colsum(variant):
     """EPI_DGELU with aux_out: the column sums of the result (bias gradient) come with the GEMM -- fused in the
     ping-pong kernel's epilogue, a second pass for the others; both must match an explicit column sum"""

@@ -105,6 +105,21 @@ __device__ __forceinline__ float dgelu_bf(float x) {                    // Phi(x
   const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(x * x * (-0.5f * UC2_LOG2E));
   return fmaf(x, pdf, phi_bf(x));
 }
+// GELU and its derivative from ONE evaluation of the fit: with Phi(x) ~= sigma(s(x)), s(x) = x (c0 + c1 x^2 + c2 x^4),
+//     gelu(x) = x Phi ,   gelu'(x) = Phi + x Phi' = Phi + x Phi (1 - Phi) s'(x) ,   s'(x) = c0 + 3 c1 x^2 + 5 c2 x^4
+// -- no transcendental beyond the forward's own exp2 + rcp (the Gaussian density would cost a second exp2).  Max
+// |gelu' error| 1.1e-4 over all x (1/20 of half a bf16 ulp at |gelu'| ~ 1).  The forward epilogue that saves gelu'(pre)
+// for the backward (UC2_GEMM_AUX_DERIV) uses this; the backward GEMM then only multiplies.
+__device__ __forceinline__ void gelu_and_dgelu_bf(float x, float& g, float& d) {
+  const float xc = __builtin_amdgcn_fmed3f(x, -9.0f, 9.0f), x2 = xc * xc;
+  float q = fmaf(-UC2_PHI_C2 * UC2_LOG2E, x2, -UC2_PHI_C1 * UC2_LOG2E);
+  q = fmaf(q, x2, -UC2_PHI_C0 * UC2_LOG2E);
+  const float ph = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(q * xc));
+  const float sp = fmaf(fmaf(5.0f * UC2_PHI_C2, x2, 3.0f * UC2_PHI_C1), x2, UC2_PHI_C0);
+  const float t = fmaf(-ph, ph, ph);                  // Phi (1 - Phi)
+  g = x * ph;
+  d = fmaf(xc * sp, t, ph);
+}
 __device__ __forceinline__ float tanh_bf(float x) {                     // 1 - 2/(1 + exp(2x)); saturates correctly at +-inf
   return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * (2.0f * UC2_LOG2E))), 1.0f);
 }

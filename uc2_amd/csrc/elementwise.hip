@@ -372,7 +372,41 @@ extern "C" int uc2_add_rowvec(int a_dtype, int dtype, int rows, int H, const voi
 // side output (first index of the maximum).  Backward rewrites logits in place:
 //   dlogits = (softmax - onehot) * gout[row]     (zero for ignored rows)
 // ---------------------------------------------------------------------------------------
-template <typename T>
+// online-softmax merge of (max, sum, first argmax) pairs
+__device__ __forceinline__ void ce_merge(float& m, float& s, int& am, float m2, float s2, int a2) {
+  const float mn = fmaxf(m, m2);
+  const float sa = (m == -INFINITY) ? 0.f : s * __expf(m - mn);
+  const float sb = (m2 == -INFINITY) ? 0.f : s2 * __expf(m2 - mn);
+  am = (m2 > m || (m2 == m && a2 < am)) ? a2 : am;
+  s = sa + sb; m = mn;
+}
+// 16 bytes per lane and load: VEC = 8 bf16 / 4 fp32 consecutive columns (the 250 002-column MLM rows are HBM-bound:
+// scalar 2-byte loads ran at 1.8 TB/s); rows must start 16-byte aligned (ld a multiple of VEC), else VEC = 1
+template <typename T> struct CeVec;
+template <> struct CeVec<float> { static constexpr int N = 4; };
+template <> struct CeVec<bf16> { static constexpr int N = 8; };
+template <typename T, int VEC>
+__device__ __forceinline__ void ce_load(const T* p, float (&v)[VEC]) {
+  if constexpr (VEC == 1) { v[0] = to_f<T>(p[0]); }
+  else if constexpr (sizeof(T) == 4) { Vec4<float>::load(reinterpret_cast<const float*>(p), reinterpret_cast<float (&)[4]>(v)); }
+  else {
+    const bf16x8 x = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)x[e];
+  }
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void ce_store(T* p, const float (&v)[VEC]) {
+  if constexpr (VEC == 1) { p[0] = from_f<T>(v[0]); }
+  else if constexpr (sizeof(T) == 4) { Vec4<float>::store(reinterpret_cast<float*>(p), reinterpret_cast<const float (&)[4]>(v)); }
+  else {
+    bf16x8 x;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (bf16)v[e];
+    *reinterpret_cast<bf16x8*>(p) = x;
+  }
+}
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void ce_fwd_kernel(int V, const T* __restrict__ logits, int ld,
                                                      const int64_t* __restrict__ labels, int64_t ignore_index,
                                                      float* __restrict__ loss, float* __restrict__ lse_o,
@@ -383,35 +417,30 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(int V, const T* __restrict_
   const T* x = logits + (size_t)row * ld;
   float m = -INFINITY, s = 0.f;
   int am = 0x7fffffff;
-  for (int c = t; c < V; c += 256) {
-    const float v = to_f<T>(x[c]);
-    if (v > m) { s = s * __expf(m - v) + 1.f; m = v; am = c; }
-    else s += __expf(v - m);
-  }
-  // wave reduce (max, sum, first argmax)
+  for (int c0 = t * VEC; c0 < V; c0 += 256 * VEC) {
+    float v[VEC];
+    ce_load<T, VEC>(x + c0, v);                      // (the row is padded to a multiple of VEC columns by its leading dimension)
+    float cm = -INFINITY;
+    int ci = 0x7fffffff;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float m2 = __shfl_xor(m, o), s2 = __shfl_xor(s, o);
-    const int a2 = __shfl_xor(am, o);
-    const float mn = fmaxf(m, m2);
-    const float sa = (m == -INFINITY) ? 0.f : s * __expf(m - mn);
-    const float sb = (m2 == -INFINITY) ? 0.f : s2 * __expf(m2 - mn);
-    am = (m2 > m || (m2 == m && a2 < am)) ? a2 : am;
-    s = sa + sb; m = mn;
+    for (int e = 0; e < VEC; ++e) {
+      if (c0 + e >= V) v[e] = -INFINITY;
+      if (v[e] > cm) { cm = v[e]; ci = c0 + e; }       // strict >: the first maximum wins (torch.argmax tie rule)
+    }
+    if (cm > m) { s *= __expf(m - cm); m = cm; am = ci; }     // exp(-inf) = 0 the first time
+    if (m > -INFINITY) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s += __expf(v[e] - m);
+    }
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ce_merge(m, s, am, __shfl_xor(m, o), __shfl_xor(s, o), __shfl_xor(am, o));
   if (lane == 0) { sm_m[wv] = m; sm_s[wv] = s; sm_i[wv] = am; }
   __syncthreads();
   if (t == 0) {
     float M = sm_m[0], S = sm_s[0];
     int A = sm_i[0];
-    for (int i = 1; i < 4; ++i) {
-      const float m2 = sm_m[i], s2 = sm_s[i];
-      const float mn = fmaxf(M, m2);
-      const float sa = (M == -INFINITY) ? 0.f : S * __expf(M - mn);
-      const float sb = (m2 == -INFINITY) ? 0.f : s2 * __expf(m2 - mn);
-      A = (m2 > M || (m2 == M && sm_i[i] < A)) ? sm_i[i] : A;
-      S = sa + sb; M = mn;
-    }
+    for (int i = 1; i < 4; ++i) ce_merge(M, S, A, sm_m[i], sm_s[i], sm_i[i]);
     const float lse = M + __logf(S);
     if (lse_o) lse_o[row] = lse;
     if (argmax_o) argmax_o[row] = A;
@@ -421,7 +450,9 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(int V, const T* __restrict_
     }
   }
 }
-template <typename T>
+// in place: logits -> dlogits = (softmax - onehot) * g; the padding columns [V, ld) of a row are set to zero (they feed
+// the decoder's weight-gradient and input-gradient GEMMs, which run over whole padded rows)
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(int V, T* __restrict__ logits, int ld,
                                                      const int64_t* __restrict__ labels, int64_t ignore_index,
                                                      const float* __restrict__ lse, const float* __restrict__ gout) {
@@ -430,18 +461,37 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(int V, T* __restrict__ logi
   const float g = (lab == ignore_index) ? 0.f : gout[row];
   const float l = lse[row];
   T* x = logits + (size_t)row * ld;
-  for (int c = blockIdx.x * 256 + threadIdx.x; c < V; c += gridDim.x * 256) {
-    const float p = __expf(to_f<T>(x[c]) - l);
-    x[c] = from_f<T>((p - (c == lab ? 1.f : 0.f)) * g);
+  const int cend = VEC == 1 ? V : ld;
+  for (int c0 = (blockIdx.x * 256 + threadIdx.x) * VEC; c0 < cend; c0 += gridDim.x * 256 * VEC) {
+    float v[VEC];
+    ce_load<T, VEC>(x + c0, v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int c = c0 + e;
+      v[e] = (c < V && g != 0.f) ? (__expf(v[e] - l) - (c == lab ? 1.f : 0.f)) * g : 0.f;
+    }
+    ce_store<T, VEC>(x + c0, v);
+  }
+  if (VEC == 1) {                                    // unaligned rows: scalar tail zeroing
+    for (int c = V + blockIdx.x * 256 + threadIdx.x; c < ld; c += gridDim.x * 256) x[c] = from_f<T>(0.f);
   }
 }
-extern "C" int uc2_ce_fwd(int dtype, int n, int V, const void* logits, int ld, const int64_t* labels,
-                          int64_t ignore_index, float* loss, float* lse, int64_t* argmax, void* stream) {
+template <typename T> static bool ce_vec_ok(const void* p, int ld) {
+  return (ld % CeVec<T>::N) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+}
+extern "C" int uc2_ce_fwd(int dtype, int n, int V, const void* logits, int ld, const int64_t* labels, int64_t ignore_index,
+                          float* loss, float* lse, int64_t* argmax, void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
   if (n <= 0) return 0;
-  UC2_CHECK_ARG(V > 0 && logits && (labels || !loss));
-  if (dtype == 0) hipLaunchKernelGGL(ce_fwd_kernel<float>, dim3(n), dim3(256), 0, (hipStream_t)stream, V, (const float*)logits, ld, labels, ignore_index, loss, lse, argmax);
-  else hipLaunchKernelGGL(ce_fwd_kernel<bf16>, dim3(n), dim3(256), 0, (hipStream_t)stream, V, (const bf16*)logits, ld, labels, ignore_index, loss, lse, argmax);
+  UC2_CHECK_ARG(V > 0 && ld >= V && logits && (labels || !loss));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0) {
+    if (ce_vec_ok<float>(logits, ld)) hipLaunchKernelGGL((ce_fwd_kernel<float, 4>), dim3(n), dim3(256), 0, st, V, (const float*)logits, ld, labels, ignore_index, loss, lse, argmax);
+    else hipLaunchKernelGGL((ce_fwd_kernel<float, 1>), dim3(n), dim3(256), 0, st, V, (const float*)logits, ld, labels, ignore_index, loss, lse, argmax);
+  } else {
+    if (ce_vec_ok<bf16>(logits, ld)) hipLaunchKernelGGL((ce_fwd_kernel<bf16, 8>), dim3(n), dim3(256), 0, st, V, (const bf16*)logits, ld, labels, ignore_index, loss, lse, argmax);
+    else hipLaunchKernelGGL((ce_fwd_kernel<bf16, 1>), dim3(n), dim3(256), 0, st, V, (const bf16*)logits, ld, labels, ignore_index, loss, lse, argmax);
+  }
   UC2_LAUNCH_CHECK();
   return 0;
 }
@@ -449,12 +499,20 @@ extern "C" int uc2_ce_bwd(int dtype, int n, int V, void* logits, int ld, const i
                           const float* lse, const float* gout, void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
   if (n <= 0) return 0;
-  UC2_CHECK_ARG(V > 0 && logits && labels && lse && gout);
-  int gx = (V + 255) / 256;
+  UC2_CHECK_ARG(V > 0 && ld >= V && logits && labels && lse && gout);
+  hipStream_t st = (hipStream_t)stream;
+  const int vec = dtype == 0 ? (ce_vec_ok<float>(logits, ld) ? 4 : 1) : (ce_vec_ok<bf16>(logits, ld) ? 8 : 1);
+  int gx = (ld / vec + 255) / 256;
   if (gx > 64) gx = 64;
+  if (gx < 1) gx = 1;
   dim3 grid(gx, n);
-  if (dtype == 0) hipLaunchKernelGGL(ce_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, V, (float*)logits, ld, labels, ignore_index, lse, gout);
-  else hipLaunchKernelGGL(ce_bwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, V, (bf16*)logits, ld, labels, ignore_index, lse, gout);
+  if (dtype == 0) {
+    if (vec == 4) hipLaunchKernelGGL((ce_bwd_kernel<float, 4>), grid, dim3(256), 0, st, V, (float*)logits, ld, labels, ignore_index, lse, gout);
+    else hipLaunchKernelGGL((ce_bwd_kernel<float, 1>), grid, dim3(256), 0, st, V, (float*)logits, ld, labels, ignore_index, lse, gout);
+  } else {
+    if (vec == 8) hipLaunchKernelGGL((ce_bwd_kernel<bf16, 8>), grid, dim3(256), 0, st, V, (bf16*)logits, ld, labels, ignore_index, lse, gout);
+    else hipLaunchKernelGGL((ce_bwd_kernel<bf16, 1>), grid, dim3(256), 0, st, V, (bf16*)logits, ld, labels, ignore_index, lse, gout);
+  }
   UC2_LAUNCH_CHECK();
   return 0;
 }

@@ -324,7 +324,7 @@ extern "C" int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K
   p.epi = epilogue; p.c_f32 = (dtype == 0) ? 1 : c_is_f32; p.accumulate = accumulate;
   p.split_k = split_k; p.atomic = (split_k > 1) ? 1 : 0; p.partial = nullptr;
   p.variant = variant; p.ws = reinterpret_cast<float*>(workspace); p.ws_bytes = workspace ? workspace_bytes : 0;
-  p.defer = flags & 1; p.skew = (flags >> 4) & 15; p.diag = (flags >> 8) & 0xFFF;
+  p.defer = flags & 1; p.aux_deriv = (flags >> 1) & 1; p.skew = (flags >> 4) & 15; p.diag = (flags >> 8) & 0xFFFF;
   p.a_vec = (((uintptr_t)A & 15) == 0) && ((lda & 7) == 0);
   p.b_vec = (((uintptr_t)B & 15) == 0) && ((ldb & 7) == 0);
   hipStream_t st = (hipStream_t)stream;

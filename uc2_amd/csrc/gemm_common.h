@@ -2,7 +2,8 @@
 #pragma once
 #include "common.h"
 
-enum { EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_ADD = 3, EPI_TANH = 4 };
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_ADD = 3, EPI_TANH = 4,
+       EPI_GELU_D = 5, EPI_MUL = 6 };     // internal to the ping-pong kernel: EPI_GELU / EPI_DGELU under GemmArgs::aux_deriv
 
 struct GemmArgs {
   const void* A; const void* B; void* C;
@@ -18,6 +19,7 @@ struct GemmArgs {
   float* ws; size_t ws_bytes;   // caller-owned split-K workspace for THIS call (or null)
   int defer;             // leave the split-K partials in ws (the caller runs uc2_gemm_splitk_reduce)
   int diag;              // diagnostic launch mode (main loop only / epilogue only / stamps), 0 in production
+  int aux_deriv;         // UC2_GEMM_AUX_DERIV: EPI_GELU stores gelu'(pre) (not pre) to aux_out, EPI_DGELU multiplies by aux_in as is
 };
 
 // ------------------------------------------------------------------------------------------
@@ -29,10 +31,11 @@ __device__ __forceinline__ void epi_store(const GemmArgs& p, int m, int n, float
   if (p.bias) v += p.bias[n];
   const size_t ia = (size_t)m * p.ldaux + n;
   if (p.epi == EPI_GELU) {
-    if (p.aux_out) reinterpret_cast<T*>(p.aux_out)[ia] = from_f<T>(v);
+    if (p.aux_out) reinterpret_cast<T*>(p.aux_out)[ia] = from_f<T>(p.aux_deriv ? dgelu_t<T>(v) : v);
     v = gelu_t<T>(v);
   } else if (p.epi == EPI_DGELU) {
-    v *= dgelu_t<T>(to_f<T>(reinterpret_cast<const T*>(p.aux_in)[ia]));
+    const float x = to_f<T>(reinterpret_cast<const T*>(p.aux_in)[ia]);
+    v *= p.aux_deriv ? x : dgelu_t<T>(x);
   } else if (p.epi == EPI_ADD) {
     v += to_f<T>(reinterpret_cast<const T*>(p.aux_in)[ia]);
   } else if (p.epi == EPI_TANH) {
@@ -110,7 +113,7 @@ __device__ __forceinline__ void bf16_tile_epilogue(const GemmArgs& p, const f32x
             if (p.aux_out) {
               bf16x8 o;
 #pragma unroll
-              for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+              for (int e = 0; e < 8; ++e) o[e] = (bf16)(p.aux_deriv ? dgelu_bf(v[e]) : v[e]);
               *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.aux_out) + ia) = o;
             }
 #pragma unroll
@@ -118,7 +121,7 @@ __device__ __forceinline__ void bf16_tile_epilogue(const GemmArgs& p, const f32x
           } else if (p.epi == EPI_DGELU) {
             const bf16x8 x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.aux_in) + ia);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= dgelu_bf((float)x[e]);
+            for (int e = 0; e < 8; ++e) v[e] *= p.aux_deriv ? (float)x[e] : dgelu_bf((float)x[e]);
           } else if (p.epi == EPI_ADD) {
             const bf16x8 x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.aux_in) + ia);
 #pragma unroll
@@ -195,7 +198,7 @@ __device__ __forceinline__ void bf16_tile_epilogue_direct(const GemmArgs& p, con
           if (p.aux_out) {
             bf16x8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)(p.aux_deriv ? dgelu_bf(v[e]) : v[e]);
             *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.aux_out) + ia) = o;
           }
 #pragma unroll
@@ -203,7 +206,7 @@ __device__ __forceinline__ void bf16_tile_epilogue_direct(const GemmArgs& p, con
         } else if (p.epi == EPI_DGELU) {
           const bf16x8 x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.aux_in) + ia);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= dgelu_bf((float)x[e]);
+          for (int e = 0; e < 8; ++e) v[e] *= p.aux_deriv ? (float)x[e] : dgelu_bf((float)x[e]);
         } else if (p.epi == EPI_ADD) {
           const bf16x8 x = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.aux_in) + ia);
 #pragma unroll

@@ -28,7 +28,7 @@
 // rounds.  Unit A1 is then 8 KiB (one LDS-DMA per wave, 7 per k-tile instead of 8) and phases 2, 3 run 4 MFMAs.
 //
 // The kernel is persistent: one workgroup per CU walks over (output tile, k-split) work items.  The epilogue
-// stores straight from the accumulator registers (gemm_common.h, bf16_tile_epilogue_direct), so the LDS ring is
+// never touches the ring (it transposes through 4 KiB of wave-private LDS beside it, see tp_* below), so the LDS ring is
 // free as soon as the main loop ends: the next item's first six units are issued BEFORE the epilogue's stores
 // and land while they drain (`vmcnt(8 + stores)` then retires only the two units the first phase reads).
 // At K = 768 the per-tile launch + first-fetch latency and the store tail were 40 % of a non-persistent tile.
@@ -113,45 +113,90 @@ __device__ __forceinline__ float colsum_butterfly32(float (&v)[32], int lane) {
   return v[0];
 }
 
+// ---- full-line epilogue I/O through a wave-private 4 KiB LDS transposition buffer ---------------------------------
+// After the lane-half exchange a lane owns (row r = lane & 31, half h) of a 32-row block: four 16-byte pieces of one
+// row, 32 bytes apart.  Stored (or loaded) like that, one wave-instruction touches 64 different 16-byte fragments of
+// 32 rows -- 64 separate L2 requests -- and the epilogue's store tail was request-bound (measured: the same bytes in a
+// full-line pattern ran the GELU GEMM 19 % faster, the plain ones 7 %).  So every global access of the epilogue is made
+// in the LINE layout: lane l owns the 16-byte chunk (l & 7) of row 8*it + (l >> 3), eight lanes cover one 128-byte line,
+// one wave-instruction = 8 whole lines.  The two layouts are exchanged through 32 rows x 128 B of LDS per wave (the
+// 32 KiB the 128 KiB ring leaves free), chunk c of row r at r*128 + ((c ^ (r & 7)) << 4): conflict-free for the
+// ds_write_b128 / ds_read_b128 of both layouts.  LDS executes a wave's operations in issue order, so the buffer is
+// reused back to back without waits; only the consumer of a read waits (lgkmcnt).  All of it is inline asm: hipcc
+// would otherwise order plain LDS accesses behind the LDS-DMA in flight (vmcnt(0)).
+__device__ __forceinline__ void tp_write(unsigned addr, const bf16x8& v) {
+  asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(v) : "memory");
+}
+template <int OFF> __device__ __forceinline__ void tp_write_o(unsigned addr, const bf16x8& v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void tp_read(bf16x8& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr) : "memory");
+}
+template <int OFF> __device__ __forceinline__ void tp_read_o(bf16x8& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+#define TP_WAIT4(A, B, C, D) do { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A), "+v"(B), "+v"(C), "+v"(D) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+struct TpAddr {
+  unsigned line;         // LINE layout: + it * 1024
+  unsigned rh[4];        // (row, half) layout: piece k = 2j + g  (chunk 2k + h)
+};
+__device__ __forceinline__ TpAddr tp_addr(unsigned tb, int lane) {
+  TpAddr t;
+  const int lr = lane >> 3, lc = lane & 7, r = lane & 31, h = lane >> 5;
+  t.line = tb + lr * 128 + ((lc ^ lr) << 4);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) t.rh[k] = tb + r * 128 + (((2 * k + h) ^ (r & 7)) << 4);
+  return t;
+}
+
 struct PpOut {
-  bf16x8 o[2][2][2][2];       // [A half][i][j][g]
+  bf16x8 o[2][2][4];          // [A half][i][it], LINE layout: row 8*it + (lane >> 3) of the 32-row block, columns 8*(lane & 7) .. +7
 };
 
 template <int EPI, int HI>
 __device__ __forceinline__ void pp_epi_compute(const GemmArgs& p, const f32x16 (&acc)[2][2][2], PpOut& out, int mb0, int nb,
-                                               int lane) {
-  const int h = lane >> 5, c31 = lane & 31;
-  constexpr bool has_aux = (EPI == EPI_DGELU || EPI == EPI_ADD);
+                                               int lane, const TpAddr& ta) {
+  const int h = lane >> 5, c31 = lane & 31, lr = lane >> 3, lc = lane & 7;
+  constexpr bool has_aux = (EPI == EPI_DGELU || EPI == EPI_ADD || EPI == EPI_MUL);
   // EPI_DGELU: aux_out (fp32 [N]) += column sums of the result = bias gradient of the layer whose pre-activation
   // gradient this GEMM produces (saves a separate pass over the M x N result)
-  const bool want_cs = (EPI == EPI_DGELU) && p.aux_out != nullptr;
+  const bool want_cs = (EPI == EPI_DGELU || EPI == EPI_MUL) && p.aux_out != nullptr;
   float cs[32];
 #pragma unroll
   for (int v = 0; v < 32; ++v) cs[v] = 0.f;
-  bf16x8 ax[2][2][2][2];
-  if (has_aux) {
+  bf16x8 ax[2][2][4];
+  if (has_aux) {                                       // whole 128-byte lines, all 16 loads in flight at once
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int g = 0; g < 2; ++g) {
-            if (hh == 1 && i >= HI) continue;
-            const int m = mb0 + hh * 64 + i * 32 + c31, n = nb + 32 * j + 16 * g + 8 * h;
-            ax[hh][i][j][g] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.aux_in) + (size_t)m * p.ldaux + n);
-          }
+        for (int it = 0; it < 4; ++it) {
+          if (hh == 1 && i >= HI) continue;
+          const int m = mb0 + hh * 64 + i * 32 + 8 * it + lr;
+          ax[hh][i][it] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.aux_in) + (size_t)m * p.ldaux + nb + 8 * lc);
+        }
   }
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+      if (hh == 1 && i >= HI) continue;
+      bf16x8 axr[4];                                   // aux tile of this block in the (row, half) layout
+      if (has_aux) {
+        tp_write_o<0>(ta.line, ax[hh][i][0]); tp_write_o<1024>(ta.line, ax[hh][i][1]);
+        tp_write_o<2048>(ta.line, ax[hh][i][2]); tp_write_o<3072>(ta.line, ax[hh][i][3]);
+        tp_read(axr[0], ta.rh[0]); tp_read(axr[1], ta.rh[1]); tp_read(axr[2], ta.rh[2]); tp_read(axr[3], ta.rh[3]);
+        TP_WAIT4(axr[0], axr[1], axr[2], axr[3]);
+      }
+      bf16x8 pre[4], o[4];
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-          if (hh == 1 && i >= HI) continue;
+          const int k = 2 * j + g;
           float v[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -161,34 +206,52 @@ __device__ __forceinline__ void pp_epi_compute(const GemmArgs& p, const f32x16 (
             v[4 + e] = __uint_as_float(sw[1]);
           }
           if (EPI == EPI_GELU) {
-            bf16x8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-            // the pre-activation copy leaves right here, while the GELU arithmetic of the remaining values runs (the
-            // stores are older than the next item's LDS-DMA and have mostly drained by the time it is waited for)
-            if (p.aux_out) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.aux_out) + (size_t)(mb0 + hh * 64 + i * 32 + c31) * p.ldaux + nb + 32 * j + 16 * g + 8 * h) = o;
+            for (int e = 0; e < 8; ++e) pre[k][e] = (bf16)v[e];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = gelu_bf(v[e]);
-          } else if (EPI == EPI_DGELU) {
+          } else if (EPI == EPI_GELU_D) {               // aux_out <- gelu'(pre): the backward multiplies by it (EPI_MUL)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= dgelu_bf((float)ax[hh][i][j][g][e]);
+            for (int e = 0; e < 8; ++e) {
+              float gg, dd;
+              gelu_and_dgelu_bf(v[e], gg, dd);
+              pre[k][e] = (bf16)dd;
+              v[e] = gg;
+            }
+          } else if (EPI == EPI_DGELU || EPI == EPI_MUL) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= (EPI == EPI_MUL) ? (float)axr[k][e] : dgelu_bf((float)axr[k][e]);
             if (want_cs) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) cs[16 * j + 8 * g + e] += v[e];
             }
           } else if (EPI == EPI_ADD) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)ax[hh][i][j][g][e];
+            for (int e = 0; e < 8; ++e) v[e] += (float)axr[k][e];
           } else if (EPI == EPI_TANH) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = tanh_bf(v[e]);
           }
-          bf16x8 o;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-          out.o[hh][i][j][g] = o;
+          for (int e = 0; e < 8; ++e) o[k][e] = (bf16)v[e];
         }
-  if (EPI == EPI_DGELU) {
+      if ((EPI == EPI_GELU || EPI == EPI_GELU_D) && p.aux_out) {
+        // the pre-activation copy leaves from here (older than the next item's LDS-DMA: it has mostly drained by the
+        // time that is waited for)
+        bf16x8 t[4];
+        tp_write(ta.rh[0], pre[0]); tp_write(ta.rh[1], pre[1]); tp_write(ta.rh[2], pre[2]); tp_write(ta.rh[3], pre[3]);
+        tp_read_o<0>(t[0], ta.line); tp_read_o<1024>(t[1], ta.line); tp_read_o<2048>(t[2], ta.line); tp_read_o<3072>(t[3], ta.line);
+        TP_WAIT4(t[0], t[1], t[2], t[3]);
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.aux_out) + (size_t)(mb0 + hh * 64 + i * 32 + 8 * it + lr) * p.ldaux + nb + 8 * lc) = t[it];
+      }
+      tp_write(ta.rh[0], o[0]); tp_write(ta.rh[1], o[1]); tp_write(ta.rh[2], o[2]); tp_write(ta.rh[3], o[3]);
+      tp_read_o<0>(out.o[hh][i][0], ta.line); tp_read_o<1024>(out.o[hh][i][1], ta.line);
+      tp_read_o<2048>(out.o[hh][i][2], ta.line); tp_read_o<3072>(out.o[hh][i][3], ta.line);
+      TP_WAIT4(out.o[hh][i][0], out.o[hh][i][1], out.o[hh][i][2], out.o[hh][i][3]);
+    }
+  if (EPI == EPI_DGELU || EPI == EPI_MUL) {
     if (want_cs) {                                     // (wave-uniform) one 64-lane atomic per wave and tile
       const float tot = colsum_butterfly32(cs, lane);
       const int vv = c31;                              // value index v = 16 j + 8 g + e  ->  column 32 j + 16 g + 8 h + e
@@ -199,41 +262,43 @@ __device__ __forceinline__ void pp_epi_compute(const GemmArgs& p, const f32x16 (
 
 template <int EPI, int HI>
 __device__ __forceinline__ void pp_epi_store(const GemmArgs& p, const PpOut& out, int mb0, int nb, int lane) {
-  const int h = lane >> 5, c31 = lane & 31;
+  const int lr = lane >> 3, lc = lane & 7;
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (hh == 1 && i >= HI) continue;
-      const int m = mb0 + hh * 64 + i * 32 + c31;
-      bf16* crow = reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + nb + 8 * h;
+      bf16* c0 = reinterpret_cast<bf16*>(p.C) + (size_t)(mb0 + hh * 64 + i * 32 + lr) * p.ldc + nb + 8 * lc;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          *reinterpret_cast<bf16x8*>(crow + 32 * j + 16 * g) = out.o[hh][i][j][g];
-        }
+      for (int it = 0; it < 4; ++it) *reinterpret_cast<bf16x8*>(c0 + (size_t)(8 * it) * p.ldc) = out.o[hh][i][it];
     }
 }
 
 // fp32 partial tile of one split-K item (two-stage reduction): transposed accumulators, lane = row m with 4
-// consecutive columns per register group -> 16-byte plain stores, 32 per wave (compile-time count, full tiles)
+// consecutive columns per register group; through the same LDS transposition -> whole 128-byte lines,
+// 32 stores per wave (compile-time count, full tiles)
 template <int HI>
 __device__ __forceinline__ void pp_partial_store(float* __restrict__ dst, int ldn, const f32x16 (&acc)[2][2][2], int mb0, int nb,
-                                                 int lane) {
-  const int h = lane >> 5, c31 = lane & 31;
+                                                 int lane, const TpAddr& ta) {
+  const int lr = lane >> 3, lc = lane & 7;
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (hh == 1 && i >= HI) continue;
-      float* row = dst + (size_t)(mb0 + hh * 64 + i * 32 + c31) * ldn + nb + 4 * h;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j) {
+        bf16x8 w[4], t[4];                              // 16 bytes = 4 floats (columns 32j + 8c + 4h .. +3  ->  chunk 2c + h)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          *reinterpret_cast<float4*>(row + 32 * j + 8 * c) =
-              make_float4(acc[hh][i][j][4 * c], acc[hh][i][j][4 * c + 1], acc[hh][i][j][4 * c + 2], acc[hh][i][j][4 * c + 3]);
+          w[c] = __builtin_bit_cast(bf16x8, make_float4(acc[hh][i][j][4 * c], acc[hh][i][j][4 * c + 1], acc[hh][i][j][4 * c + 2], acc[hh][i][j][4 * c + 3]));
+        tp_write(ta.rh[0], w[0]); tp_write(ta.rh[1], w[1]); tp_write(ta.rh[2], w[2]); tp_write(ta.rh[3], w[3]);
+        tp_read_o<0>(t[0], ta.line); tp_read_o<1024>(t[1], ta.line); tp_read_o<2048>(t[2], ta.line); tp_read_o<3072>(t[3], ta.line);
+        TP_WAIT4(t[0], t[1], t[2], t[3]);
+        float* row = dst + (size_t)(mb0 + hh * 64 + i * 32 + lr) * ldn + nb + 32 * j + 4 * lc;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) *reinterpret_cast<float4*>(row + (size_t)(8 * it) * ldn) = __builtin_bit_cast(float4, t[it]);
+      }
     }
 }
 
@@ -499,13 +564,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
       younger = GKT;
     } else if (TACC && p.partial) {                     // split-K item of a two-stage reduction (fp32 partial, plain stores)
       if (more) { setup(item); PP_PROLOGUE(); }
-      pp_partial_store<HI>(p.partial + (size_t)ez * p.M * p.N, p.N, acc, em0, en0, lane);
+      {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const TpAddr tpa = tp_addr(lds0 + 131072u + (unsigned)w * 4096u, ln);
+        pp_partial_store<HI>(p.partial + (size_t)ez * p.M * p.N, p.N, acc, em0, en0, ln, tpa);
+      }
       younger = GKT + 2 * NST;
     } else if (TACC) {
       PpOut out;
       int ln = lane;
       asm volatile("" : "+v"(ln));
-      pp_epi_compute<EPI, HI>(p, acc, out, em0, en0, ln);
+      {
+        const TpAddr tpa = tp_addr(lds0 + 131072u + (unsigned)w * 4096u, ln);
+        pp_epi_compute<EPI, HI>(p, acc, out, em0, en0, ln, tpa);
+      }
       // pin the finished outputs here: otherwise hipcc sinks the aux-dependent arithmetic below the DMA issue that
       // follows, and its wait for the aux loads (vmcnt is in order) becomes a wait for the whole next-item prologue
 #pragma unroll
@@ -513,10 +586,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-              if (!(hh == 1 && i >= HI)) asm volatile("" : "+v"(out.o[hh][i][j][g]));
+          for (int it = 0; it < 4; ++it)
+            if (!(hh == 1 && i >= HI)) asm volatile("" : "+v"(out.o[hh][i][it]));
       PP_STAMP(2);
       if (more) { setup(item); PP_PROLOGUE(); }
       PP_STAMP(3);
@@ -565,7 +636,7 @@ static int pp_num_cus() {
 template <bool TA, bool TB, bool TACC, int EPI, int HI = 2>
 static void pp_launch0(const GemmArgs& p, hipStream_t st) {
   static_assert(HI == 2 || TACC, "the 192-row variant exists for the bf16-output epilogue only");
-  constexpr int smem = 131072;
+  constexpr int smem = 131072 + 8 * 4096;            // the ring + one 4 KiB transposition buffer per wave = all 160 KiB
   auto kern = gemm_bf16_pp_kernel<TA, TB, TACC, EPI, HI>;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
@@ -606,12 +677,14 @@ void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t
     else if (trans_a && !trans_b) pp_launch0<true, false, false, EPI_NONE>(p, st);
     else pp_launch0<true, true, false, EPI_NONE>(p, st);
   } else if (!trans_a && !trans_b) {
-    if (p.epi == EPI_GELU) pp_launch0<false, false, true, EPI_GELU>(p, st);
+    if (p.epi == EPI_GELU && p.aux_deriv) pp_launch0<false, false, true, EPI_GELU_D>(p, st);
+    else if (p.epi == EPI_GELU) pp_launch0<false, false, true, EPI_GELU>(p, st);
     else if (p.epi == EPI_ADD) pp_launch0<false, false, true, EPI_ADD>(p, st);
     else if (p.epi == EPI_TANH) pp_launch0<false, false, true, EPI_TANH>(p, st);
     else pp_launch0<false, false, true, EPI_NONE>(p, st);
   } else if (!trans_a && trans_b) {
-    if (p.epi == EPI_DGELU) pp_launch0<false, true, true, EPI_DGELU>(p, st);
+    if (p.epi == EPI_DGELU && p.aux_deriv) pp_launch0<false, true, true, EPI_MUL>(p, st);
+    else if (p.epi == EPI_DGELU) pp_launch0<false, true, true, EPI_DGELU>(p, st);
     else if (p.epi == EPI_ADD) pp_launch0<false, true, true, EPI_ADD>(p, st);
     else pp_launch0<false, true, true, EPI_NONE>(p, st);
   } else if (trans_a && !trans_b) {

@@ -96,6 +96,7 @@ class _Timed:
 
 GEMM_AUTO, GEMM_GENERIC = -2, 99      # include/uc2_hip.h: UC2_GEMM_AUTO / UC2_GEMM_GENERIC
 GEMM_DEFER_REDUCE = 1
+GEMM_AUX_DERIV = 2                    # EPI_GELU saves gelu'(pre), EPI_DGELU multiplies by it as is
 _FORCED = [None]                       # tests/diagnostics only (force_variant); production passes the plan per call
 
 
@@ -197,7 +198,8 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
         if defer:
             call("uc2_gemm_splitk_reduce", M, N, ptr(out), ldc, split_k, int(accumulate), ptr(ws), ws.numel(), stream())
         if variant in (8, 9):  # ping-pong kernel: transposed accumulators unless fp32 atomics; the epilogue kind is a template argument
-            key = (bool(ta), bool(tb), variant, bool(c_f32 and not two_stage), int(epi))
+            epi_t = int(epi) + 4 if (flags & GEMM_AUX_DERIV and epi in (EPI_GELU, EPI_DGELU)) else int(epi)   # EPI_GELU_D = 5, EPI_MUL = 6
+            key = (bool(ta), bool(tb), variant, bool(c_f32 and not two_stage), epi_t)
         else:
             key = (bool(ta), bool(tb), variant, bool(c_f32 and split_k > 1), 0)
         timer.add(key, 2.0 * M * N * K, e0, e1)
@@ -355,26 +357,32 @@ def gemm_plan(dtype, ta, tb, M, N, K, wgrad=False):
     return best
 
 
+PP_SKEW = {}          # epilogue kind -> ping-pong start skew (UC2_GEMM_SKEW(n) flag); experiment knob, empty = off
+
+
 def _gemm_planned(a, b, M, N, K, ta, tb, wgrad=False, **kw):
     """one GEMM with its tuned (variant, split_k) plan, passed to the library with the call"""
     v, sp = gemm_plan(a.dtype, ta, tb, M, N, K, wgrad)
-    return gemm(a, b, M, N, K, ta=ta, tb=tb, split_k=sp, variant=v, **kw)
+    flags = kw.pop("flags", 0)
+    if PP_SKEW and v in (8, 9):
+        flags |= (PP_SKEW.get(kw.get("epi", EPI_NONE), 0) & 15) << 4
+    return gemm(a, b, M, N, K, ta=ta, tb=tb, split_k=sp, variant=v, flags=flags, **kw)
 
 
-def linear_fwd(x2, w, bias, epi=EPI_NONE, aux_out=None):
+def linear_fwd(x2, w, bias, epi=EPI_NONE, aux_out=None, flags=0):
     M, K = x2.shape
     N = w.shape[0]
-    return _gemm_planned(x2, w, M, N, K, False, False, bias=bias, epi=epi, aux_out=aux_out)
+    return _gemm_planned(x2, w, M, N, K, False, False, bias=bias, epi=epi, aux_out=aux_out, flags=flags)
 
 
-def linear_dgrad(dy2, w, epi=EPI_NONE, aux_in=None, colsum_out=None):
+def linear_dgrad(dy2, w, epi=EPI_NONE, aux_in=None, colsum_out=None, flags=0):
     """dX[M,K] = epi(dY[M,N] @ W[N,K])  (W in nn.Linear layout).  With EPI_DGELU, colsum_out (fp32 [K]) += column sums
     of dX = the bias gradient of the layer below (fused into the GEMM epilogue where the kernel supports it)."""
     M, N = dy2.shape
     K = w.shape[1]
     if colsum_out is not None and epi != EPI_DGELU:
         raise _lib.Uc2Error("colsum_out needs EPI_DGELU")
-    return _gemm_planned(dy2, w, M, K, N, False, True, epi=epi, aux_in=aux_in, aux_out=colsum_out)
+    return _gemm_planned(dy2, w, M, K, N, False, True, epi=epi, aux_in=aux_in, aux_out=colsum_out, flags=flags)
 
 
 def _linear_wgrad_now(dy2, x2, dw, db):
@@ -556,8 +564,10 @@ class BertLayerFn(torch.autograd.Function):
         ctxv, lse = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, sid + 1)
         o1 = linear_fwd(ctxv, st.compute(P["ow"], dtype), P["ob"].data)
         a, mean1, rstd1 = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, sid + 2)
+        # `pre` holds gelu'(a W1^T + b1), not the pre-activation itself (UC2_GEMM_AUX_DERIV): one more exp2 beside
+        # the forward's Phi(x) there, and the backward's dGELU epilogue becomes a plain multiply
         pre = torch.empty((M, P["iw"].shape[0]), dtype=dtype, device=x.device)
-        u = linear_fwd(a, st.compute(P["iw"], dtype), P["ib"].data, EPI_GELU, pre)
+        u = linear_fwd(a, st.compute(P["iw"], dtype), P["ib"].data, EPI_GELU, pre, flags=GEMM_AUX_DERIV)
         o2 = linear_fwd(u, st.compute(P["fw"], dtype), P["fb"].data)
         y, mean2, rstd2 = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, sid + 3)
 
@@ -584,7 +594,8 @@ class BertLayerFn(torch.autograd.Function):
         d_o2, dz2 = ln_bwd(dy2, o2, a, P["g2"].data, mean2, rstd2, G(P["g2"]), G(P["b2"]), p_h, seed, sid + 3,
                            dbias=G(P["fb"]))
         linear_wgrad(d_o2, u, G(P["fw"]), None)
-        d_pre = linear_dgrad(d_o2, st.compute(P["fw"], dtype), EPI_DGELU, pre, colsum_out=G(P["ib"]))   # + d(intermediate bias)
+        d_pre = linear_dgrad(d_o2, st.compute(P["fw"], dtype), EPI_DGELU, pre, colsum_out=G(P["ib"]),
+                             flags=GEMM_AUX_DERIV)                                             # + d(intermediate bias)
         linear_wgrad(d_pre, a, G(P["iw"]), None)
         da = linear_dgrad(d_pre, st.compute(P["iw"], dtype), EPI_ADD, dz2)
         # LN1, output projection, attention, fused QKV
@@ -1077,10 +1088,17 @@ class AddRowFn(torch.autograd.Function):
         return dout, dout, dtab, None
 
 
+_DEC_ROWS = 8192          # rows per decoder chunk: 2 * rows * 250 112 bytes of logits must stay below 2^32 (the ping-pong
+                          # kernel addresses its operands with 32-bit byte offsets), and a chunk's logits are 4.1 GB
+
+
 class DecoderCEFn(torch.autograd.Function):
-    """tied-decoder logits + cross entropy in one node (model/layer.py:257-265, model/model.py:590-596):
-    logits = z E^T + bias live in ONE [n, V_pad] buffer that the backward overwrites with dlogits;
-    dE += dlogits^T z goes straight into the word-embedding gradient arena."""
+    """tied-decoder logits + cross entropy in one node (model/layer.py:257-265, model/model.py:590-596).
+    The vocabulary tables are padded to whole 256-row GEMM tiles inside the arena (store.padded) and the masked rows
+    to a multiple of 256 (zero rows, ignored labels), so the three decoder GEMMs -- logits = z E^T + bias,
+    dE += dlogits^T z, dz = dlogits E -- all run on the persistent 256x256 MFMA kernel; logits live in ONE
+    [rows, 250112] bf16 buffer per chunk of 8192 rows that the backward overwrites with dlogits, and dE goes straight
+    into the word-embedding gradient arena."""
 
     @staticmethod
     def forward(ctx, z, owner, weight, bias, labels, ignore_index):
@@ -1090,38 +1108,80 @@ class DecoderCEFn(torch.autograd.Function):
             st.sync_shadow()
         n, H = z.shape
         V = weight.shape[0]
-        Vp = (V + 7) // 8 * 8
+        in_arena = st.owns(weight) and st.owns(bias)
+        Wp = st.padded(st.data if dtype == torch.float32 else st.shadow, weight) if in_arena else st.compute(weight, dtype)
+        bp = st.padded(st.data, bias) if in_arena else bias.data
+        Vp = Wp.shape[0] if Wp.shape[0] % 8 == 0 else (V + 7) // 8 * 8
+        tile = 256 if (dtype == torch.bfloat16 and n >= 256) else 1
+        npad = (n + tile - 1) // tile * tile
         z = z.contiguous()
         labels = labels.contiguous()
-        logits = torch.empty((n, Vp), dtype=dtype, device=z.device)
-        gemm(z, st.compute(weight, dtype), n, V, H, out=logits, bias=bias.data)
-        loss = torch.empty(n, dtype=torch.float32, device=z.device)
-        lse = torch.empty(n, dtype=torch.float32, device=z.device)
-        am = torch.empty(n, dtype=torch.int64, device=z.device)
-        call("uc2_ce_fwd", dt(dtype), n, V, ptr(logits), Vp, ptr(labels), ignore_index, ptr(loss), ptr(lse), ptr(am),
-             stream())
-        ctx.save_for_backward(z, logits, labels, lse)
-        ctx.owner, ctx.wb, ctx.cfg = owner, (weight, bias), (ignore_index, V, Vp)
+        if npad != n:                                 # zero rows / ignored labels up to whole tiles
+            zp = torch.zeros((npad, H), dtype=dtype, device=z.device)
+            zp[:n].copy_(z)
+            lp = torch.full((npad,), ignore_index, dtype=labels.dtype, device=z.device)
+            lp[:n].copy_(labels)
+            z, labels = zp, lp
+        loss = torch.empty(npad, dtype=torch.float32, device=z.device)
+        lse = torch.empty(npad, dtype=torch.float32, device=z.device)
+        am = torch.empty(npad, dtype=torch.int64, device=z.device)
+        chunks = []
+        for r0 in range(0, npad, _DEC_ROWS):
+            r1 = min(npad, r0 + _DEC_ROWS)
+            m = r1 - r0
+            logits = torch.empty((m, Vp), dtype=dtype, device=z.device)
+            if Wp.shape[0] == Vp and Vp != V:         # whole padded tiles: N = Vp (padding columns = padding bias = 0)
+                _gemm_planned(z[r0:r1], Wp, m, Vp, H, False, False, out=logits, bias=bp)
+            else:
+                gemm(z[r0:r1], Wp, m, V, H, out=logits, bias=bp)
+            call("uc2_ce_fwd", dt(dtype), m, V, ptr(logits), Vp, ptr(labels[r0:r1]), ignore_index, ptr(loss[r0:r1]),
+                 ptr(lse[r0:r1]), ptr(am[r0:r1]), stream())
+            chunks.append(logits)
+        ctx.save_for_backward(z, labels, lse, *chunks)
+        ctx.owner, ctx.wb, ctx.cfg = owner, (weight, bias), (ignore_index, V, Vp, n, npad)
+        loss, am = loss[:n], am[:n]
         ctx.mark_non_differentiable(am)
         return loss, am
 
     @staticmethod
     def backward(ctx, gloss, _g):
-        z, logits, labels, lse = ctx.saved_tensors
+        z, labels, lse = ctx.saved_tensors[:3]
+        chunks = ctx.saved_tensors[3:]
         weight, bias = ctx.wb
-        ignore_index, V, Vp = ctx.cfg
+        ignore_index, V, Vp, n, npad = ctx.cfg
         st = store_of(ctx.owner)
         dtype = z.dtype
-        n, H = z.shape
+        H = z.shape[1]
         g = gloss.contiguous().float()
-        call("uc2_ce_bwd", dt(dtype), n, V, ptr(logits), Vp, ptr(labels), ignore_index, ptr(lse), ptr(g), stream())
-        dlog = logits
-        # dE[V,H] += dlogits^T z ; dbias[V] += colsum(dlogits) ; dz = dlogits E
-        gemm(dlog, z, V, H, n, ta=True, tb=True, out=st.grad_buf(weight), accumulate=True, lda=Vp,
-             split_k=_wgrad_split(dtype, V, H, n))
-        call("uc2_colsum_accum", dt(dtype), n, V, ptr(dlog), Vp, None, ptr(st.grad_buf(bias)), stream())
-        dz = gemm(dlog, st.compute(weight, dtype), n, H, V, tb=True, lda=Vp)
-        return dz, None, None, None, None, None
+        if npad != n:
+            gp = torch.zeros(npad, dtype=torch.float32, device=g.device)
+            gp[:n].copy_(g)
+            g = gp
+        in_arena = st.owns(weight) and st.owns(bias)
+        Wp = st.padded(st.data if dtype == torch.float32 else st.shadow, weight) if in_arena else st.compute(weight, dtype)
+        st.grad_buf(weight)
+        st.grad_buf(bias)
+        dE = st.padded(st.grad, weight) if in_arena else st.grad_buf(weight)
+        db = st.padded(st.grad, bias) if in_arena else st.grad_buf(bias)
+        full = Wp.shape[0] == Vp and Vp != V
+        dz = torch.empty((npad, H), dtype=dtype, device=z.device)
+        for ci, r0 in enumerate(range(0, npad, _DEC_ROWS)):
+            r1 = min(npad, r0 + _DEC_ROWS)
+            m = r1 - r0
+            dlog = chunks[ci]                          # in place: the logits buffer becomes dlogits (padding columns zeroed)
+            call("uc2_ce_bwd", dt(dtype), m, V, ptr(dlog), Vp, ptr(labels[r0:r1]), ignore_index, ptr(lse[r0:r1]),
+                 ptr(g[r0:r1]), stream())
+            # dE[V,H] += dlogits^T z ; dbias[V] += colsum(dlogits) ; dz = dlogits E
+            if full:
+                _gemm_planned(dlog, z[r0:r1], Vp, H, m, True, True, wgrad=True, out=dE, accumulate=True, lda=Vp)
+                call("uc2_colsum_accum", dt(dtype), m, Vp, ptr(dlog), Vp, None, ptr(db), stream())
+                _gemm_planned(dlog, Wp, m, H, Vp, False, True, out=dz[r0:r1], lda=Vp)
+            else:
+                gemm(dlog, z[r0:r1], V, H, m, ta=True, tb=True, out=dE, accumulate=True, lda=Vp,
+                     split_k=_wgrad_split(dtype, V, H, m))
+                call("uc2_colsum_accum", dt(dtype), m, V, ptr(dlog), Vp, None, ptr(db), stream())
+                gemm(dlog, Wp, m, H, V, tb=True, out=dz[r0:r1], lda=Vp)
+        return dz[:n], None, None, None, None, None
 
 
 class AttentionFn(torch.autograd.Function):
@@ -1151,6 +1211,10 @@ def attn_probs_mean(qkv2, mask2d, B, L, nh, D):
 
 
 import os as _os
+if _os.environ.get("UC2_AUTOTUNE", "1") == "0":     # variable-shape runs that must never stall on a tuning pass
+    AUTOTUNE = False
+if _os.environ.get("UC2_PP_SKEW"):          # e.g. "1:2,2:2" = skew 2 for the GELU and dGELU epilogue GEMMs
+    PP_SKEW = {int(k): int(v) for k, v in (kv.split(":") for kv in _os.environ["UC2_PP_SKEW"].split(","))}
 if _os.environ.get("UC2_GEMM_PLANS", "1") != "0":
     load_plans(_os.environ.get("UC2_GEMM_PLANS_FILE", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)),
                                                                     "gemm_plans.json")))

@@ -19,7 +19,19 @@ import torch
 from . import _lib
 
 _ALIGN = 64                      # elements; keeps every view 16-byte aligned in fp32 and bf16
+_ROW_TILE = 256                  # large tables are followed by zero rows up to a multiple of the GEMM tile (see padded())
+_PAD_MIN = 65536                 # ... when they have at least this many rows / elements (the 250 002-row vocabulary tables)
 _STORES = weakref.WeakSet()
+
+
+def _slot_numel(p):
+    """elements reserved for p in the arenas: the vocabulary-sized tables (word embeddings = tied MLM decoder weight
+    [250002, H], decoder bias [250002]) get zero rows up to a multiple of 256, so that the decoder GEMMs run on whole
+    256-row tiles of the arena itself (the reference disabled its own pad_vocab, model/model.py:1051-1054)"""
+    if p.dim() >= 1 and p.shape[0] >= _PAD_MIN and p.shape[0] % _ROW_TILE:
+        rows = (p.shape[0] + _ROW_TILE - 1) // _ROW_TILE * _ROW_TILE
+        return rows * (p.numel() // p.shape[0])
+    return p.numel()
 
 
 def _unique_named_params(module):
@@ -73,7 +85,7 @@ class ParamStore:
                 self.offsets[id(p)] = off
                 self.names.append(n)
                 self.params.append(p)
-                off += p.numel()
+                off += _slot_numel(p)
         self.total = (off + _ALIGN - 1) // _ALIGN * _ALIGN
         self.pos = {id(p): i for i, p in enumerate(self.params)}
         self.device = dev
@@ -99,6 +111,13 @@ class ParamStore:
     def view(self, flat, p):
         o = self.offsets[id(p)]
         return flat[o:o + p.numel()].view(p.shape)
+
+    def padded(self, flat, p):
+        """p's slot INCLUDING its zero padding rows, as [rows_padded, ...] (== view() for unpadded parameters)"""
+        o = self.offsets[id(p)]
+        n = _slot_numel(p)
+        rows = n // (p.numel() // p.shape[0])
+        return flat[o:o + n].view((rows,) + tuple(p.shape[1:]))
 
     def owns(self, p):
         return getattr(p, "_uc2_store", None) is self and id(p) in self.offsets and \
