@@ -191,7 +191,7 @@ def main():
     from uc2_amd.optim.adamw import AdamW, clip_grad_norm_
     from uc2_amd.optim.misc import param_groups
     from uc2_amd.store import set_compute_dtype, store_of
-    from uc2_amd.utils.distributed import GradSync, all_reduce_and_rescale_tensors, broadcast_tensors
+    from uc2_amd.utils.distributed import GradSync, NativeComm, all_reduce_and_rescale_tensors, broadcast_tensors
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -211,6 +211,21 @@ def main():
         else:
             dist.init_process_group(backend)
     assert world == a.gpus, "--gpus %d but WORLD_SIZE %d" % (a.gpus, world)
+    comm_path = "none" if world == 1 else "torch.distributed/%s" % backend
+    if world > 1 and backend == "nccl" and os.environ.get("UC2_COMM", "native") == "native":
+        # data plane: the library's own RCCL communicator (include/uc2_hip.h uc2_comm_*); torch.distributed stays the
+        # control plane (rendezvous, barriers, the unique-id exchange).  Every rank must agree on the outcome.
+        ok = torch.ones(1, device=dev)
+        try:
+            NativeComm.init(dev)
+        except Exception as e:                               # noqa: BLE001
+            sys.stderr.write("rank %d: native RCCL communicator unavailable (%s); using torch.distributed\n" % (rank, e))
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() == 0:
+            NativeComm.destroy()
+        else:
+            comm_path = "libuc2_hip.so uc2_comm_* (RCCL, library-owned side stream)"
 
     ops.rng.manual_seed(20260101 + rank, dev)              # dropout streams differ per rank
     torch.manual_seed(0)                                   # weights seed 0 (random init, N(0, 0.02))
@@ -347,6 +362,7 @@ def main():
                                    % (a.layers, a.task.upper()),
                        "pairs_per_gpu_per_step": a.batch, "global_batch": a.batch * world,
                        "seq_len": T_TXT + N_REG, "parallelism": "dp%d" % world, "final_loss": round(lossv, 4), "replicas_in_sync": in_sync,
+                       "gradient_allreduce": comm_path,
                        "gemm_plans": {"%s%s %dx%dx%d" % ("T" if k[0] else "N", "T" if k[1] else "N", k[2], k[3], k[4]):
                                       "%s split %d" % ("generic" if v[0] == 99 else "ping-pong" if v[0] == 8 else "ring v%d" % v[0], v[1])
                                       for k, v in sorted(ops._TUNE.items())}},
@@ -367,6 +383,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.layers)
         print(json.dumps(out), flush=True)
+    NativeComm.destroy()
     if world > 1:
         dist.destroy_process_group()
 

@@ -159,6 +159,25 @@ int uc2_sumsq_partials(size_t n, const float* x, float* partials, void* stream);
 int uc2_clip_coef(const float* partials, int count, float max_norm, float* coef, float* norm_out, void* stream);
 int uc2_scale(size_t n, float* x, const float* scale_dev, float scale_imm, void* stream);
 
+/* ---- data-parallel communication on RCCL over xGMI (utils/distributed.py:15-42 all_reduce_and_rescale_tensors,
+ *      :99-147 broadcast_tensors; hvd.init / rank / size at pretrain.py:384-388) -------------------------------
+ *   One communicator per process (one process per GPU).  The library owns a side HIP stream and two events and
+ *   nothing else; librccl is opened lazily by uc2_comm_unique_id / uc2_comm_init.  A bucket's collective is ordered
+ *   after `compute_stream` (its gradients are final), runs on the side stream while backward continues, and
+ *   uc2_comm_wait(stream) orders `stream` behind everything issued so far (device-side wait; no call blocks the host
+ *   except init / destroy).  dtype: UC2_F32 or UC2_BF16.  Return codes >= 10000 are ncclResult_t + 10000.
+ *   Typical step (uc2_amd/utils/distributed.py): one uc2_comm_allreduce_bucket per encoder layer from that layer's
+ *   backward hook, one for the embedding / head tail after backward, uc2_comm_wait, then clip + AdamW. */
+int uc2_comm_unique_id_bytes(void);
+int uc2_comm_unique_id(void* out, int bytes);                       /* rank 0; carry the bytes to the other ranks out of band */
+int uc2_comm_init(int rank, int world, const void* unique_id, int bytes);
+int uc2_comm_rank(void);
+int uc2_comm_world(void);
+int uc2_comm_allreduce_bucket(void* buf, size_t count, int dtype, int average, void* compute_stream);
+int uc2_comm_broadcast(void* buf, size_t count, int dtype, int root, void* compute_stream);
+int uc2_comm_wait(void* stream);
+int uc2_comm_destroy(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,3 +31,43 @@ def test_bench_self_launches_two_ranks_and_replicas_stay_in_sync():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["replicas_in_sync"] is True
     assert d["config"]["global_batch"] == 128 and d["value"] > 0
+
+
+def test_native_rccl_communicator_single_rank():
+    """include/uc2_hip.h uc2_comm_*: the library's RCCL communicator (dlopen of librccl, side stream, event ordering)
+    with world = 1 -- the only size a 1-GPU box admits (RCCL rejects two ranks on one device); the 8-GPU run is the
+    driver's.  Mean over one rank leaves fp32 data untouched, the bf16 tail path rounds once."""
+    import torch
+    from uc2_amd.utils.distributed import NativeComm, all_reduce_and_rescale_tensors, broadcast_tensors
+    from uc2_amd.store import ParamStore
+    dev = torch.device("cuda", 0)
+    assert NativeComm.init(dev)
+    try:
+        x = torch.randn(1 << 16, device=dev)
+        y = x.clone()
+        NativeComm.allreduce_avg(y)
+        NativeComm.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(x, y)
+        h = x.to(torch.bfloat16)
+        h2 = h.clone()
+        NativeComm.allreduce_avg(h2)
+        NativeComm.broadcast(y, 0)
+        NativeComm.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(h, h2) and torch.equal(x, y)
+        # through the reference-shaped entry point, on a gradient arena: small spans stay fp32 (exact),
+        # the >= 1M-element span takes the bf16 staging path (one rounding), then / rescale_denom
+        m = torch.nn.Sequential(torch.nn.Linear(1500, 1024), torch.nn.Linear(64, 8)).to(dev)
+        st = ParamStore(m)
+        for p in m.parameters():
+            st.grad_buf(p).copy_(torch.randn_like(p))
+        ref = [p.grad.clone() for p in m.parameters()]
+        all_reduce_and_rescale_tensors([p.grad.data for p in m.parameters()], 2.0)
+        torch.cuda.synchronize()
+        for p, r in zip(m.parameters(), ref):           # adjacent parameters travel as one span: all of it rounds to bf16 once
+            assert torch.allclose(p.grad, r.to(torch.bfloat16).float() / 2.0, rtol=1e-6, atol=0)
+        broadcast_tensors([p.data for p in m.parameters()], 0)
+        torch.cuda.synchronize()
+    finally:
+        NativeComm.destroy()

@@ -56,6 +56,15 @@ SIGNATURES = {
     "uc2_sumsq_blocks": (I, []),
     "uc2_clip_coef": (I, [P, I, F, P, P, P]),
     "uc2_scale": (I, [SZ, P, P, F, P]),
+    "uc2_comm_unique_id_bytes": (I, []),
+    "uc2_comm_unique_id": (I, [P, I]),
+    "uc2_comm_init": (I, [I, I, P, I]),
+    "uc2_comm_rank": (I, []),
+    "uc2_comm_world": (I, []),
+    "uc2_comm_allreduce_bucket": (I, [P, SZ, I, I, P]),
+    "uc2_comm_broadcast": (I, [P, SZ, I, I, P]),
+    "uc2_comm_wait": (I, [P]),
+    "uc2_comm_destroy": (I, []),
 }
 
 

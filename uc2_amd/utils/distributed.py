@@ -10,10 +10,70 @@ What changes relative to the reference (utils/distributed.py:15-42):
     exposed; RCCL picks the multi-link algorithm (7 xGMI links per GPU), nothing forces a ring;
   * the mean over ranks (Horovod's default) and `/ rescale_denom` are one scaling pass.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 from .. import _lib
+
+# The gradient tail (embeddings + heads: 0.77 GB of fp32, final only when backward ends, so its all-reduce is exposed)
+# is reduced as bf16 on the GPU data paths -- the reference reduces fp16 gradients too (apex O2 + Horovod,
+# pretrain.py:557-566).  Encoder-layer buckets overlap with backward and stay fp32.  UC2_ALLREDUCE_TAIL=fp32 turns it off.
+TAIL_BF16 = os.environ.get("UC2_ALLREDUCE_TAIL", "bf16") == "bf16"
+_TAIL_MIN = 1 << 20              # elements; smaller spans are not worth two cast passes
+
+
+class NativeComm:
+    """The library's own RCCL communicator (include/uc2_hip.h uc2_comm_*): collectives on a library-owned side stream,
+    ordered against the compute stream with events.  The 128-byte unique id travels over the torch.distributed control
+    group that the launcher (torch.distributed.run) set up -- any backend -- exactly once."""
+    active = False
+
+    @classmethod
+    def init(cls, device):
+        if cls.active:
+            return True
+        lib = _lib.load()
+        world, rank = _world(), _rank()
+        nb = lib.uc2_comm_unique_id_bytes()
+        buf = (torch.zeros(nb, dtype=torch.uint8))
+        if rank == 0:
+            import ctypes
+            raw = (ctypes.c_char * nb)()
+            _lib.check(lib.uc2_comm_unique_id(raw, nb))
+            buf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+        obj = [buf.tolist()]
+        if world > 1:
+            dist.broadcast_object_list(obj, src=0)
+        idb = bytes(obj[0])
+        torch.cuda.set_device(device)
+        _lib.check(lib.uc2_comm_init(rank, world, idb, nb))
+        cls.active = True
+        return True
+
+    @classmethod
+    def destroy(cls):
+        if cls.active:
+            _lib.load().uc2_comm_destroy()
+            cls.active = False
+
+    @staticmethod
+    def allreduce_avg(t):
+        """in-place mean over ranks of a contiguous fp32 / bf16 CUDA tensor, asynchronous (side stream)"""
+        _lib.call("uc2_comm_allreduce_bucket", t.data_ptr(), t.numel(), _lib.dt(t.dtype), 1, _lib.stream())
+
+    @staticmethod
+    def broadcast(t, root):
+        _lib.call("uc2_comm_broadcast", t.data_ptr(), t.numel(), _lib.dt(t.dtype), int(root), _lib.stream())
+
+    @staticmethod
+    def wait():
+        _lib.call("uc2_comm_wait", _lib.stream())
+
+
+def _native_ok(t):
+    return NativeComm.active and t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)
 
 
 def _world():
@@ -22,6 +82,46 @@ def _world():
 
 def _rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+class _Reducer:
+    """one in-place mean-over-ranks of a flat tensor, on whichever data path is up: the library's RCCL communicator
+    (mean computed by the collective) or torch.distributed (sum, scaled afterwards)"""
+
+    def __init__(self):
+        self.works, self.sum_views, self.native_used = [], [], False
+
+    def start(self, v):
+        if _world() == 1 and not NativeComm.active:
+            return
+        if _native_ok(v):
+            NativeComm.allreduce_avg(v)
+            self.native_used = True
+        else:
+            self.works.append(dist.all_reduce(v, async_op=True))
+            self.sum_views.append(v)
+
+    def finish(self, extra_scale):
+        """wait for everything started; apply 1/world to the summed views and `extra_scale` to all of `views`"""
+        for w in self.works:
+            w.wait()
+        if self.native_used:
+            NativeComm.wait()
+        W = _world()
+        for v in self.sum_views:
+            _scale_(v, 1.0 / W)
+        self.works, self.sum_views, self.native_used = [], [], False
+
+
+_TAIL_STAGE = {}
+
+
+def _tail_stage(device, n):
+    buf = _TAIL_STAGE.get(device)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(n, dtype=torch.bfloat16, device=device)
+        _TAIL_STAGE[device] = buf
+    return buf[:n]
 
 
 def _scale_(t, s):
@@ -58,7 +158,6 @@ def all_reduce_and_rescale_tensors(tensors, rescale_denom):
         from .. import ops
         ops.join_side_streams()
     W = _world()
-    scale = 1.0 / (W * rescale_denom)
     # find arena-backed spans by address
     from ..store import _STORES
     spans, loose = [], []
@@ -75,11 +174,11 @@ def all_reduce_and_rescale_tensors(tensors, rescale_denom):
             loose.append(t)
         else:
             spans.append(hit)
-    works = []
+    red = _Reducer()
     by_store = {}
     for st, o, n in spans:
         by_store.setdefault(id(st), (st, []))[1].append((o, n))
-    views = []
+    views, staged, todo = [], [], []
     for st, ranges in by_store.values():
         sync = getattr(st, "_grad_sync", None)
         done = sync.take_done() if sync is not None else []
@@ -87,11 +186,27 @@ def all_reduce_and_rescale_tensors(tensors, rescale_denom):
             for (a, b) in _subtract((o, o + n), done):
                 v = st.grad[a:b]
                 views.append(v)
-                if W > 1:
-                    works.append(dist.all_reduce(v, async_op=True))
+                todo.append(v)
         if sync is not None:
-            works.extend(sync.take_works())
+            sync.merge_into(red)
             views.extend(sync.take_views())
+    if W > 1 or NativeComm.active:
+        def half(v):
+            return TAIL_BF16 and v.is_cuda and v.numel() >= _TAIL_MIN and \
+                (NativeComm.active or dist.get_backend() == "nccl")
+        n_half = sum((v.numel() + 63) // 64 * 64 for v in todo if half(v))
+        stage = _tail_stage(todo[0].device, n_half) if n_half else None
+        off = 0
+        for v in todo:
+            if half(v):
+                # exposed tail: fp32 -> bf16 staging (one slice per span), reduce half the bytes, back to fp32 below
+                h = stage[off:off + v.numel()]
+                off += (v.numel() + 63) // 64 * 64
+                _lib.call("uc2_cast", 0, 1, v.numel(), _lib.ptr(v), _lib.ptr(h), _lib.stream())
+                red.start(h)
+                staged.append((v, h))
+            else:
+                red.start(v)
     buf = None
     if loose:
         sz = sum(t.numel() for t in loose)
@@ -100,10 +215,11 @@ def all_reduce_and_rescale_tensors(tensors, rescale_denom):
         for t in loose:
             buf[off:off + t.numel()].copy_(t.reshape(-1))
             off += t.numel()
-        if W > 1:
-            works.append(dist.all_reduce(buf, async_op=True))
-    for w in works:
-        w.wait()
+        red.start(buf)
+    red.finish(1.0)
+    for v, h in staged:
+        _lib.call("uc2_cast", 1, 0, v.numel(), _lib.ptr(h), _lib.ptr(v), _lib.stream())
+    scale = 1.0 / rescale_denom
     for v in views:
         _scale_(v, scale)
     if buf is not None:
@@ -147,23 +263,23 @@ class GradSync:
         self.st._grad_sync = self
         self.layers = [m for m in model.modules() if isinstance(m, BertLayer)]
         self.armed = False
-        self._works, self._views, self._done = [], [], []
+        self._red, self._views, self._done = _Reducer(), [], []
         for l in self.layers:
             l.grad_ready_hook = self._on_layer_done
 
     def arm(self):
         self.armed = True
-        self._works, self._views, self._done = [], [], []
+        self._red, self._views, self._done = _Reducer(), [], []
 
     def _on_layer_done(self, layer):
-        if not self.armed or _world() == 1:
+        if not self.armed or (_world() == 1 and not NativeComm.active):
             return
         st = self.st
         ps = list(layer.parameters())
         lo = min(st.offsets[id(p)] for p in ps)
         hi = max(st.offsets[id(p)] + p.numel() for p in ps)
         v = st.grad[lo:hi]
-        self._works.append(dist.all_reduce(v, async_op=True))
+        self._red.start(v)                 # 28 MB of fp32 per layer, in flight while the layers below run their backward
         self._views.append(v)
         self._done.append((lo, hi))
 
@@ -171,10 +287,13 @@ class GradSync:
         d, self._done = self._done, []
         return d
 
-    def take_works(self):
-        w, self._works = self._works, []
+    def merge_into(self, red):
+        """hand the in-flight per-layer reductions to the caller's reducer (it waits for them and finishes the mean)"""
+        red.works.extend(self._red.works)
+        red.sum_views.extend(self._red.sum_views)
+        red.native_used = red.native_used or self._red.native_used
+        self._red = _Reducer()
         self.armed = False
-        return w
 
     def take_views(self):
         v, self._views = self._views, []
@@ -186,7 +305,11 @@ def broadcast_tensors(tensors, root_rank, buffer_size=10485760):
     broadcast in place in buffer_size-byte chunks of the arena; others one by one."""
     from ..store import mark_all_dirty
     tensors = list(tensors)
-    if _world() > 1:
+    if NativeComm.active and tensors and all(_native_ok(t) for t in tensors):
+        for t in tensors:
+            NativeComm.broadcast(t, root_rank)
+        NativeComm.wait()
+    elif _world() > 1:
         for t in tensors:
             if t.is_contiguous():
                 flat = t.reshape(-1)
