@@ -118,6 +118,10 @@ int uc2_gather_rows_bwd(int dtype, int B, int S, int L, int H, const void* dout,
 /* scatter 0: dst[i] = src[rows[i]] (gather); 1: dst[rows[i]] = src[i]; 2: dst[rows[i]] += src[i] (rows unique) */
 int uc2_select_rows(int dtype, int n, int H, const void* src, int ld_src, const int64_t* rows, void* dst, int ld_dst,
                     int scatter, void* stream);
+/* retrieval recall without a top-k (eval/itm.py:6-53, itm.py:461-470): rank[q] = position of candidate target[q] in a
+ * stable descending sort of s(q, c) = scores[off[q] + c*stride], c < nc.  dtype: UC2_F32, UC2_BF16 or 2 = fp16. */
+int uc2_rank_of_target(int dtype, int nq, int nc, const void* scores, const int64_t* off, int64_t stride,
+                       const int64_t* target, int32_t* rank, void* stream);
 /* fp32 vector gather (mode 0: dst[i] = src[idx[i]]) / scatter-add (mode 1: dst[idx[i]] += src[i], idx unique):
  * the bias entries of the column subset kept by forward_mmxlm_soft (model/model.py:639-642) */
 int uc2_gather_f32(int n, const float* src, const int64_t* idx, float* dst, int mode, void* stream);
@@ -139,6 +143,17 @@ int uc2_dtanh(int dtype, size_t n, const void* y, const void* dy, void* dx, void
 int uc2_gelu(int dtype, size_t n, const void* x, void* y, void* stream);       /* model/layer.py:31-37, stand-alone */
 int uc2_dgelu(int dtype, size_t n, const void* pre, const void* dy, void* dx, void* stream);
 int uc2_cast(int from_dtype, int to_dtype, size_t n, const void* in, void* out, void* stream);
+
+/* ---- optimal-transport regulariser of the ITM head (model/ot.py:8-82; hooked at model/model.py:701-729) -----------
+ *   seq [B, L, H] compact encoder output; scatter [B, L] = position of each row in the padded [txt(T) | img(R)] layout;
+ *   txt_pad [B, T], img_pad [B, R] (1 = padding).  dist[b] = trace(cost Tm), cost = 1 - cosine, Tm = IPOT(beta, iters, k = 1)
+ *   on the detached cost.  Tm [B, R, T] and the workspace (unit rows, norms, inverse scatter) are kept for the backward,
+ *   which writes dseq rows (dseq zero-initialised by the caller).  T, R <= 128. */
+size_t uc2_ot_workspace(int B, int T, int R, int H);
+int uc2_ot_fwd(int dtype, int B, int L, int T, int R, int H, const void* seq, const int64_t* scatter, const uint8_t* txt_pad,
+               const uint8_t* img_pad, float beta, int iters, float* dist, float* Tm, void* ws, void* stream);
+int uc2_ot_bwd(int dtype, int B, int L, int T, int R, int H, const float* Tm, const void* ws, const float* gdist, void* dseq,
+               void* stream);
 
 /* ---- optimizer step and gradient clipping (optim/adamw.py:40-103; clip_grad_norm_ at pretrain.py:610) ------
  *   chunks: DEVICE array of uc2_adam_chunk records built once by the host; active / steps: DEVICE int32 per

@@ -398,8 +398,44 @@ def case_more(mm, out):
         put(out, "mha_cross/grad/" + n, p.grad, full=p.numel() <= 70000)
 
 
+def case_retrieval(mi, out):
+    """retrieval inference (itm.py:516-538 + eval/itm.py:6-53): a 12-text x 11-image score matrix from the reference's
+    VLXLMRForImageTextRetrieval in eval mode, mini-batches of 4 images, and the reference's own itm_eval on it"""
+    ev = load_file("ref_eval_itm", REF + "/eval/itm.py")
+    cfg = ref_config(importlib.import_module("model.model"), TINY)
+    model = mi.VLXLMRForImageTextRetrieval(cfg, img_dim=2048, margin=0.2)
+    synth.det_init_(model)
+    model.eval()
+    n_txt, n_img = 12, 11
+    pool = synth.retrieval_pool(1000, n_txt, n_img, 32, 36)
+    sm = torch.zeros(n_txt, n_img)
+    with torch.no_grad():
+        for i in range(n_txt):
+            for j0 in range(0, n_img, 4):
+                j1 = min(n_img, j0 + 4)
+                b = synth.retrieval_batch(pool, i, j0, j1)
+                sm[i, j0:j1] = model(b, compute_loss=False).squeeze(1)
+    out["retrieval/scores"] = sm.numpy()
+    txt_ids = ["t%d" % i for i in range(n_txt)]
+    img_ids = ["i%d" % j for j in range(n_img)]
+    txt2img = {t: img_ids[(3 * k) % n_img] for k, t in enumerate(txt_ids)}
+    img2txts = {j: [t for t in txt_ids if txt2img[t] == j] for j in img_ids}
+    # the recall numbers are pinned on a tie-free fp16 matrix: torch.topk leaves the order of equal scores
+    # unspecified, and the tiny model's raw scores collide in fp16
+    ev_in = ((sm - sm.mean()) / sm.std() + synth.det_uniform((n_txt, n_img), 99, -0.05, 0.05)).half()
+    for r in range(n_txt):
+        assert len(set(ev_in[r].tolist())) == n_img
+    for c in range(n_img):
+        assert len(set(ev_in[:, c].tolist())) == n_txt
+    out["retrieval/eval_input"] = ev_in.float().numpy()
+    log = ev.itm_eval(ev_in.float(), txt_ids, img_ids, txt2img, img2txts)
+    for k, v in log.items():
+        out["retrieval/eval/" + k] = np.array([v])
+    print("  retrieval:", {k: round(v, 4) for k, v in log.items()})
+
+
 def main():
-    which = sys.argv[1:] or ["tiny", "gather", "adamw", "mha", "base", "more", "large"]
+    which = sys.argv[1:] or ["tiny", "gather", "adamw", "mha", "base", "more", "large", "retrieval"]
     install_shims()
     sys.path.insert(0, REF)
     mm = importlib.import_module("model.model")
@@ -423,6 +459,8 @@ def main():
             case_large(mm, out)
         elif w == "more":
             case_more(mm, out)
+        elif w == "retrieval":
+            case_retrieval(mi, out)
         else:
             raise SystemExit("unknown case " + w)
         path = os.path.join(HERE, "golden_%s.npz" % w)

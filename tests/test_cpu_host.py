@@ -3,6 +3,8 @@ the reference-shaped modules expose the reference's parameter names / state_dict
 flat arenas behave, the product path refuses to run without a GPU (no CPU fallback), and the
 data-parallel helpers are correct under a 2-process gloo group."""
 import ctypes
+import json
+from collections import OrderedDict
 import os
 import re
 import subprocess
@@ -21,6 +23,7 @@ from uc2_amd.model.model import VLXLMRConfig, VLXLMRForPretraining
 from uc2_amd.optim import sched
 from uc2_amd.optim.misc import param_groups
 from uc2_amd.store import ParamStore, store_of
+from uc2_amd.utils import synth
 from util import golden
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -244,3 +247,85 @@ def test_data_parallel_gloo_world2(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
         assert "worker %d ok" % r in o
+
+
+# ------------------------------------------------------------------------------------------ round 2: config, optimizer groups, checkpoints
+def test_config_constructors_match_reference_semantics():
+    c = VLXLMRConfig(1000, 128, 2, 4, 512)                       # positional, the reference's argument order
+    assert (c.vocab_size, c.hidden_size, c.num_hidden_layers, c.num_attention_heads, c.intermediate_size) == (1000, 128, 2, 4, 512)
+    assert c.layer_norm_eps == 1e-5 and c.pad_token_id == 1 and c.max_position_embeddings == 514
+    d = VLXLMRConfig.from_dict({"vocab_size": 7, "extra_key": "kept"})
+    assert d.vocab_size == 7 and d.extra_key == "kept"
+    assert json.loads(d.to_json_string())["extra_key"] == "kept"
+    with pytest.raises(ValueError):
+        VLXLMRConfig(1.5)
+
+
+def test_xlmr_optimizer_groups():
+    """optim/misc.py:48-100: four groups, the pretrained XLM-R part at its own (smaller) learning rate"""
+    from uc2_amd.optim.misc import xlmr_param_groups, xlmr_pretrained_encoder_layer
+    m = VLXLMRForPretraining(tiny_cfg(), img_dim=2048, img_label_dim=1601)
+    names = {id(p): n for n, p in m.named_parameters()}
+    g = xlmr_param_groups(m, 0.01, 4e-5, 1e-5)
+    assert [x["lr"] for x in g] == [1e-5, 1e-5, 4e-5, 4e-5] and [x["weight_decay"] for x in g] == [0.01, 0.0, 0.01, 0.0]
+    assert sum(len(x["params"]) for x in g) == len(list(m.parameters()))
+    assert all("roberta.embeddings" in names[id(p)] for p in g[0]["params"] + g[1]["params"])
+    assert "roberta.embeddings.LayerNorm.weight" in [names[id(p)] for p in g[1]["params"]]
+    g = xlmr_param_groups(m, 0.01, 4e-5, 1e-5, load_layer=0 + 1)
+    pre = [names[id(p)] for p in g[0]["params"] + g[1]["params"]]
+    assert any(n.startswith("roberta.encoder.layer.1.") for n in pre) and any(n.startswith("roberta.encoder.layer.0.") for n in pre)
+    assert xlmr_pretrained_encoder_layer("roberta.encoder.layer.3.output.dense.weight", 2) is False
+
+
+def test_from_pretrained_key_surgery(tmp_path):
+    """legacy gamma/beta LayerNorm names, a `roberta.bert.`-less checkpoint, partial loads (model/model.py:205-264)"""
+    cfgf = tmp_path / "cfg.json"
+    cfgf.write_text(tiny_cfg().to_json_string())
+    src = VLXLMRForPretraining(tiny_cfg(), img_dim=2048, img_label_dim=1601)
+    synth.det_init_(src)
+    sd = OrderedDict((k.replace("LayerNorm.weight", "LayerNorm.gamma").replace("LayerNorm.bias", "LayerNorm.beta"), v.clone())
+                     for k, v in src.state_dict().items())
+    assert any("gamma" in k for k in sd)
+    m = VLXLMRForPretraining.from_pretrained(str(cfgf), sd, img_dim=2048, img_label_dim=1601)
+    for (n, p), (_, q) in zip(m.named_parameters(), src.named_parameters()):
+        assert torch.equal(p, q), n
+    sd = OrderedDict((k, v.clone()) for k, v in src.state_dict().items())
+    m2 = VLXLMRForPretraining.from_pretrained(str(cfgf), sd, load_embedding_only=True, img_dim=2048, img_label_dim=1601)
+    assert torch.equal(m2.roberta.embeddings.word_embeddings.weight, src.roberta.embeddings.word_embeddings.weight)
+    assert not torch.equal(m2.roberta.encoder.layer[0].output.dense.weight, src.roberta.encoder.layer[0].output.dense.weight)
+    sd = OrderedDict((k, v.clone()) for k, v in src.state_dict().items())
+    m3 = VLXLMRForPretraining.from_pretrained(str(cfgf), sd, load_layer=1 - 1 + 1, img_dim=2048, img_label_dim=1601)
+    assert torch.equal(m3.roberta.encoder.layer[1].output.dense.weight, src.roberta.encoder.layer[1].output.dense.weight)
+
+
+def test_model_saver_and_training_restorer_formats(tmp_path):
+    """utils/save.py:58-80,164-213: file names, dict keys, fp16 narrowing + widening, backup rotation"""
+    from types import SimpleNamespace
+    from uc2_amd.utils.save import ModelSaver, TrainingRestorer, save_training_meta
+    out = tmp_path / "run"
+    cfgf = tmp_path / "cfg.json"
+    cfgf.write_text(tiny_cfg().to_json_string())
+    opts = SimpleNamespace(output_dir=str(out), model_config=str(cfgf), save_steps=2, fp16=True, rank=0)
+    save_training_meta(opts)
+    assert (out / "log" / "hps.json").exists() and (out / "log" / "model.json").exists() and (out / "ckpt").is_dir()
+    m = VLXLMRForPretraining(tiny_cfg(), img_dim=2048, img_label_dim=1601)
+    synth.det_init_(m)
+    opt = torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9)
+    ModelSaver(str(out / "ckpt")).save(m, 7, opt)
+    sd = torch.load(out / "ckpt" / "model_step_7.pt")
+    assert list(sd.keys()) == list(m.state_dict().keys()) and sd["cls.bias"].shape == (1000,)
+    ts = torch.load(out / "ckpt" / "train_state_7.pt")
+    assert ts["step"] == 7 and "state" in ts["optimizer"]
+    r = TrainingRestorer(opts, m, opt)
+    assert r.global_step == 0
+    r.step(); r.step()                                            # save_steps = 2 -> restore.pt
+    r.step(); r.step()                                            # rotated to restore_backup.pt
+    assert (out / "restore.pt").exists() and (out / "restore_backup.pt").exists()
+    ck = torch.load(out / "restore.pt")
+    assert set(ck) == {"global_step", "model_state_dict", "optim_state_dict", "amp_state_dict"} and ck["global_step"] == 4
+    assert ck["model_state_dict"]["cls.dense.weight"].dtype == torch.float16          # narrowed on disk
+    m2 = VLXLMRForPretraining(tiny_cfg(), img_dim=2048, img_label_dim=1601)
+    r2 = TrainingRestorer(opts, m2, torch.optim.SGD(m2.parameters(), lr=0.1, momentum=0.9))
+    assert r2.global_step == 4
+    w, w2 = m.cls.dense.weight, m2.cls.dense.weight
+    assert w2.dtype == torch.float32 and torch.equal(w2, w.half().float())            # widened again on load

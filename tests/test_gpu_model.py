@@ -273,6 +273,31 @@ def test_more_tasks_fp32_vs_golden():
     _grad_checks(g, key, model, 3e-3, what="vmlm-soft")
 
 
+def test_itm_with_ot_regulariser_fp32_vs_golden():
+    """f4: ITM + optimal-transport regulariser (model/model.py:701-729, model/ot.py:32-82), variable length, both
+    ot_pos_only settings: ITM losses, OT distances and every gradient of itm.mean() + 0.1 * ot against the reference"""
+    g = golden("more")
+    model = build_pretrain(O.TINY, torch.float32)
+    b = to_dev(synth.make_batch(1000, 8, 32, 36, task="itm", seed=1, variable_len=True, ot=True))
+    b["ot_inputs"] = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b["ot_inputs"].items()}
+    for pos_only in (False, True):
+        key = "tiny8var/itm-ot%s" % ("-pos" if pos_only else "")
+        model.ot_pos_only = pos_only
+        model.zero_grad()
+        itm_loss, ot = model(b, "itm", compute_loss=True)
+        check_against_golden(g, key + "/loss", itm_loss, TOL32)
+        if pos_only:
+            check_against_golden(g, key + "/ot", ot, TOL32)
+            otl = ot.mean()
+        else:
+            check_against_golden(g, key + "/ot_pos", ot[0], TOL32)
+            check_against_golden(g, key + "/ot_neg", ot[1], TOL32)
+            otl = (ot[0].sum() - ot[1].sum()) / (ot[0].size(0) + ot[1].size(0))
+        (itm_loss.mean() + 0.1 * otl).backward()
+        _grad_checks(g, key, model, 3e-3, what=key)
+    model.ot_pos_only = False
+
+
 def test_text_only_image_only_all_layers_fp32_vs_golden():
     """VLXLMRModel.forward's text-only / image-only branches (model/model.py:439-446) with gradients (padding rows
     of the embedding tables get none: nn.Embedding padding_idx), and output_all_encoded_layers=True"""
@@ -426,6 +451,120 @@ def test_gelu_module_and_sequential_heads():
     xr = x.clone().requires_grad_(True)
     torch.nn.functional.gelu(xr).sum().backward()
     assert max_rel(xg.grad, xr.grad) < 1e-4
+
+
+def test_checkpoint_load_reproduces_golden_and_resume_matches(tmp_path):
+    """f3: a reference-layout checkpoint dict (legacy gamma/beta names) through from_pretrained reproduces the
+    reference's own outputs; ModelSaver + train_state files resume a run onto the same trajectory"""
+    from uc2_amd.utils.save import ModelSaver
+    g = golden("tiny")
+    cfgf = tmp_path / "cfg.json"
+    cfgf.write_text(make_cfg(O.TINY).to_json_string())
+    src = VLXLMRForPretraining(make_cfg(O.TINY), img_dim=2048, img_label_dim=1601)
+    synth.det_init_(src)
+    from collections import OrderedDict as OD
+    sd = OD((k.replace("LayerNorm.weight", "LayerNorm.gamma").replace("LayerNorm.bias", "LayerNorm.beta"), v.clone())
+            for k, v in src.state_dict().items())
+    model = VLXLMRForPretraining.from_pretrained(str(cfgf), sd, img_dim=2048, img_label_dim=1601)
+    model.to(DEV).train()
+    b = to_dev(synth.make_batch(1000, 8, 32, 36, task="mlm", seed=1))
+    loss = model(b, "mlm", compute_loss=True)
+    check_against_golden(g, "tiny8/mlm/loss", loss, TOL32)
+    # ---- resume: 2 steps, save, 1 more step  ==  load + 1 step
+    def make_opt(m):
+        return AdamW(param_groups(m, 0.01), lr=1e-3, betas=(0.9, 0.98))
+
+    def one_step(m, opt, seed):
+        bb = to_dev(synth.make_batch(1000, 4, 32, 36, task="itm", seed=seed))
+        opt.zero_grad()
+        l, _ = m(bb, "itm")
+        l.mean().backward()
+        opt.step()
+    opt = make_opt(model)
+    one_step(model, opt, 31)
+    one_step(model, opt, 32)
+    ModelSaver(str(tmp_path)).save(model, 2, opt)
+    one_step(model, opt, 33)
+    m2 = VLXLMRForPretraining.from_pretrained(str(cfgf), torch.load(tmp_path / "model_step_2.pt"), img_dim=2048, img_label_dim=1601)
+    m2.to(DEV).train()
+    opt2 = make_opt(m2)
+    opt2.load_state_dict(torch.load(tmp_path / "train_state_2.pt")["optimizer"])
+    one_step(m2, opt2, 33)
+    for (n, p), (_, q) in zip(model.named_parameters(), m2.named_parameters()):
+        assert torch.allclose(p, q, rtol=0, atol=2e-6), n          # (fp32 atomics in the embedding backward: not bit-exact)
+    w = "roberta.encoder.layer.0.output.dense.weight"
+    assert not torch.equal(dict(model.named_parameters())[w], src.state_dict()[w].to(DEV))
+
+
+def test_retrieval_inference_vs_golden():
+    """f2: forward-only scoring into the fp16 score matrix (itm.py:516-538) and device-side recall (eval/itm.py:6-53)
+    against the reference's score matrix and its own itm_eval numbers; the forward-only layer equals the training
+    forward"""
+    from uc2_amd.eval.itm import inference, itm_eval, validate
+    g = golden("retrieval")
+    model = VLXLMRForImageTextRetrieval(make_cfg(O.TINY), img_dim=2048, margin=0.2)
+    synth.det_init_(model)
+    model.to(DEV)
+    n_txt, n_img = 12, 11
+    pool = synth.retrieval_pool(1000, n_txt, n_img, 32, 36)
+    loader = [[to_dev(synth.retrieval_batch(pool, i, j0, min(n_img, j0 + 4))) for j0 in range(0, n_img, 4)] for i in range(n_txt)]
+    sm = inference(model, loader, n_txt, n_img)
+    assert sm.dtype == torch.float16 and tuple(sm.shape) == (n_txt, n_img)
+    ref = torch.from_numpy(g["retrieval/scores"])
+    assert max_rel(sm.float().cpu(), ref.half().float()) < 2e-3          # fp16 storage of the scores
+    txt_ids = ["t%d" % i for i in range(n_txt)]
+    img_ids = ["i%d" % j for j in range(n_img)]
+    txt2img = {t: img_ids[(3 * k) % n_img] for k, t in enumerate(txt_ids)}
+    img2txts = {j: [t for t in txt_ids if txt2img[t] == j] for j in img_ids}
+    ev_in = torch.from_numpy(g["retrieval/eval_input"]).half().to(DEV)     # tie-free (topk's order of equal scores is unspecified)
+    log = itm_eval(ev_in, txt_ids, img_ids, txt2img, img2txts)
+    for k, v in log.items():
+        assert abs(v - float(g["retrieval/eval/" + k][0])) < 1e-6, (k, v, float(g["retrieval/eval/" + k][0]))
+    plain = itm_eval(ev_in, txt_ids, img_ids, txt2img, img2txts, reference_row_term=False)
+    assert plain["img_r10"] <= 1.0
+    # forward-only path == training-graph path in eval mode (same kernels minus the saved streams)
+    b = loader[3][1]
+    model.eval()
+    with torch.no_grad():
+        s_inf = model(b, compute_loss=False)
+    s_trn = model(b, compute_loss=False)
+    assert torch.equal(s_inf, s_trn.detach())
+    v = validate(model, [loader[0][0], loader[1][0]])
+    assert set(v) == {"valid/recall_1", "valid/recall_5", "valid/recall_10"}
+
+
+def test_hard_negative_forward_matches_manual_selection():
+    """configs[3] pattern (model/itm.py:105-186 restated for the VL-XLM-R model): no-grad eval scoring -> top-k ->
+    training forward on the selected sub-batch, against doing the same three steps by hand"""
+    from uc2_amd.model.itm import VLXLMRForImageTextRetrievalHardNeg
+    torch.manual_seed(0)
+    model = VLXLMRForImageTextRetrievalHardNeg(make_cfg(O.TINY), img_dim=2048, margin=0.2, hard_size=3)
+    synth.det_init_(model)
+    model.to(DEV).train()
+    pool = synth.retrieval_pool(1000, 2, 9, 32, 36)
+    b = to_dev(synth.retrieval_batch(pool, 0, 0, 9))
+    b["input_ids"] = b["input_ids"][:1]                      # one text, expanded by the model
+    loss = model(dict(b), sample_from='t', compute_loss=True)
+    assert tuple(loss.shape) == (1, 3)
+    loss.mean().backward()
+    assert model.rank_output.weight.grad is not None
+    plain = VLXLMRForImageTextRetrieval(make_cfg(O.TINY), img_dim=2048, margin=0.2)
+    synth.det_init_(plain)
+    plain.to(DEV).eval()
+    full = dict(b, input_ids=b["input_ids"].expand(9, -1))
+    with torch.no_grad():
+        sc = plain(full, compute_loss=False).reshape(-1)
+    hard = sc[1:].topk(3, sorted=False)[1] + 1
+    idx = torch.cat([torch.zeros(1, dtype=torch.long, device=DEV), hard])
+    attn = b["attn_masks"].index_select(0, idx)
+    ml = int(attn.sum(1).max().item())
+    mi = ml - b["input_ids"].size(1)
+    hb = dict(sample_size=4, input_ids=full["input_ids"][:4], img_feat=b["img_feat"].index_select(0, idx)[:, :mi],
+              img_pos_feat=b["img_pos_feat"].index_select(0, idx)[:, :mi], attn_masks=attn[:, :ml],
+              gather_index=b["gather_index"].index_select(0, idx)[:, :ml])
+    plain.train()
+    want = plain(hb, compute_loss=True)
+    assert torch.allclose(loss, want, rtol=1e-5, atol=1e-7)
 
 
 # ------------------------------------------------------------------------------------------ optimizer

@@ -37,6 +37,7 @@ SIGNATURES = {
     "uc2_gather_rows_fwd": (I, [I, I, I, I, I, P, P, P, P]),
     "uc2_gather_rows_bwd": (I, [I, I, I, I, I, P, P, P, P]),
     "uc2_select_rows": (I, [I, I, I, P, I, P, P, I, I, P]),
+    "uc2_rank_of_target": (I, [I, I, I, P, P, I64, P, P, P]),
     "uc2_gather_f32": (I, [I, P, P, P, I, P]),
     "uc2_colsum_accum": (I, [I, I, I, P, I, P, P, P]),
     "uc2_add_rowvec": (I, [I, I, I, I, P, P, P, P, P, P]),
@@ -50,6 +51,9 @@ SIGNATURES = {
     "uc2_gelu": (I, [I, SZ, P, P, P]),
     "uc2_dgelu": (I, [I, SZ, P, P, P, P]),
     "uc2_cast": (I, [I, I, SZ, P, P, P]),
+    "uc2_ot_workspace": (SZ, [I, I, I, I]),
+    "uc2_ot_fwd": (I, [I, I, I, I, I, I, P, P, P, P, F, I, P, P, P, P]),
+    "uc2_ot_bwd": (I, [I, I, I, I, I, I, P, P, P, P, P]),
     "uc2_adamw_chunk_bytes": (SZ, []),
     "uc2_adamw_step": (I, [P, I, I, I, P, P, P, P, P, P, P, P, P, I, P]),
     "uc2_sumsq_partials": (I, [SZ, P, P, P]),

@@ -234,6 +234,46 @@ extern "C" int uc2_select_rows(int dtype, int n, int H, const void* src, int ld_
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// rank of a target among candidates (retrieval recall, reference eval/itm.py:6-53 and itm.py:461-470): for query q
+//   rank[q] = #{c : s(q,c) > s(q,t_q)} + #{c < t_q : s(q,c) == s(q,t_q)},   s(q,c) = scores[off[q] + c * stride]
+// i.e. the position of the target in a stable descending sort -- recall@k = mean(rank < k) -- without materialising
+// a top-k.  One wave per query; scores fp16 (the reference's score matrix dtype), bf16 or fp32.
+// ---------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float rk_f(T v) { return (float)v; }
+template <typename T>
+__global__ __launch_bounds__(256) void rank_of_target_kernel(int nq, int nc, const T* __restrict__ scores,
+                                                             const int64_t* __restrict__ off, int64_t stride,
+                                                             const int64_t* __restrict__ target, int32_t* __restrict__ rank) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= nq) return;
+  const T* s = scores + off[q];
+  const int64_t t = target[q];
+  const float st = rk_f<T>(s[t * stride]);
+  int cnt = 0;
+  for (int c = lane; c < nc; c += 64) {
+    const float v = rk_f<T>(s[(int64_t)c * stride]);
+    cnt += (v > st) || (v == st && c < t);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if (lane == 0) rank[q] = cnt;
+}
+extern "C" int uc2_rank_of_target(int dtype, int nq, int nc, const void* scores, const int64_t* off, int64_t stride,
+                                  const int64_t* target, int32_t* rank, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1 || dtype == 2);
+  if (nq <= 0) return 0;
+  UC2_CHECK_ARG(nc > 0 && scores && off && target && rank);
+  dim3 grid((nq + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0) hipLaunchKernelGGL(rank_of_target_kernel<float>, grid, dim3(256), 0, st, nq, nc, (const float*)scores, off, stride, target, rank);
+  else if (dtype == 1) hipLaunchKernelGGL(rank_of_target_kernel<bf16>, grid, dim3(256), 0, st, nq, nc, (const bf16*)scores, off, stride, target, rank);
+  else hipLaunchKernelGGL(rank_of_target_kernel<_Float16>, grid, dim3(256), 0, st, nq, nc, (const _Float16*)scores, off, stride, target, rank);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
 // element gather / scatter-add on an fp32 vector: mode 0: dst[i] = src[idx[i]]; mode 1: dst[idx[i]] += src[i]
 // (idx unique) -- bias entries of a column subset of the tied decoder (model/model.py:639-642)
 __global__ void gather_f32_kernel(int n, const float* __restrict__ src, const int64_t* __restrict__ idx,

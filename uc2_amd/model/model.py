@@ -29,75 +29,82 @@ VALID_XLMR_TOKEN_IDS = list(range(5, 50))
 
 
 def xlmr_sublayer_loading(state_dict, load_embedding_only=False, load_layer=0):
-    """model/model.py:24-41"""
-    old_keys, new_keys = [], []
-    if load_embedding_only:
-        for key in state_dict.keys():
-            if "roberta.embeddings" not in key:
-                old_keys.append(key)
-                new_keys.append("not_load." + key)
-    elif load_layer:
+    """Partial XLM-R loads (model/model.py:24-41): keys that must NOT be loaded are renamed to `not_load.<key>` in
+    place, so that the loader reports them as unexpected instead of copying them.  load_embedding_only keeps only
+    `roberta.embeddings.*`; load_layer = n keeps encoder layers 0..n."""
+    def skipped(key):
+        if load_embedding_only:
+            return "roberta.embeddings" not in key
+        if load_layer:
+            return "roberta.encoder" in key and int(key.split(".")[3]) > load_layer
+        return False
+    if load_layer and not load_embedding_only:
         assert isinstance(load_layer, int) and load_layer > 0
-        for key in state_dict.keys():
-            if "roberta.encoder" in key and int(key.split('.')[3]) > load_layer:
-                old_keys.append(key)
-                new_keys.append("not_load." + key)
-    for new_key, old_key in zip(new_keys, old_keys):
-        state_dict[new_key] = state_dict.pop(old_key)
+    for key in [k for k in state_dict.keys() if skipped(k)]:
+        state_dict["not_load." + key] = state_dict.pop(key)
+
+
+_CONFIG_FIELDS = (("hidden_size", 768), ("num_hidden_layers", 12), ("num_attention_heads", 12),
+                  ("intermediate_size", 3072), ("hidden_act", "gelu"), ("hidden_dropout_prob", 0.1),
+                  ("attention_probs_dropout_prob", 0.1), ("max_position_embeddings", 514), ("type_vocab_size", 2),
+                  ("initializer_range", 0.02), ("layer_norm_eps", 1e-5), ("pad_token_id", 1))
 
 
 class VLXLMRConfig(object):
-    """model/model.py:45-141 (same fields, same constructors)."""
+    """Model geometry with the reference's field names and constructors (model/model.py:45-141): an int first
+    argument is the vocabulary size and the keywords fill the rest; a str is the path of a JSON file whose keys
+    become attributes (config/uc2-base.json)."""
 
-    def __init__(self, vocab_size_or_config_json_file, hidden_size=768, num_hidden_layers=12,
-                 num_attention_heads=12, intermediate_size=3072, hidden_act="gelu",
-                 hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, max_position_embeddings=514,
-                 type_vocab_size=2, initializer_range=0.02, output_past=True, layer_norm_eps=1e-5,
-                 pad_token_id=1):
-        if isinstance(vocab_size_or_config_json_file, str):
-            with open(vocab_size_or_config_json_file, "r", encoding='utf-8') as reader:
-                json_config = json.loads(reader.read())
-            for key, value in json_config.items():
-                self.__dict__[key] = value
-        elif isinstance(vocab_size_or_config_json_file, int):
-            self.vocab_size = vocab_size_or_config_json_file
-            self.hidden_size = hidden_size
-            self.num_hidden_layers = num_hidden_layers
-            self.num_attention_heads = num_attention_heads
-            self.hidden_act = hidden_act
-            self.intermediate_size = intermediate_size
-            self.hidden_dropout_prob = hidden_dropout_prob
-            self.attention_probs_dropout_prob = attention_probs_dropout_prob
-            self.max_position_embeddings = max_position_embeddings
-            self.type_vocab_size = type_vocab_size
-            self.initializer_range = initializer_range
-            self.layer_norm_eps = layer_norm_eps
-            self.pad_token_id = pad_token_id
+    _POSITIONAL = ("hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size", "hidden_act",
+                   "hidden_dropout_prob", "attention_probs_dropout_prob", "max_position_embeddings", "type_vocab_size",
+                   "initializer_range", "output_past", "layer_norm_eps", "pad_token_id")     # the reference's argument order
+
+    def __init__(self, vocab_size_or_config_json_file, *args, **fields):
+        src = vocab_size_or_config_json_file
+        fields.update(zip(self._POSITIONAL, args))
+        fields.pop("output_past", None)                   # accepted and ignored, like the reference
+        if isinstance(src, str):
+            with open(src, "r", encoding="utf-8") as f:
+                self.__dict__.update(json.load(f))
+        elif isinstance(src, int):
+            unknown = set(fields) - {k for k, _ in _CONFIG_FIELDS}
+            if unknown:
+                raise TypeError("unexpected config field(s): %s" % sorted(unknown))
+            self.vocab_size = src
+            for key, default in _CONFIG_FIELDS:
+                setattr(self, key, fields.get(key, default))
         else:
             raise ValueError("First argument must be either a vocabulary size (int) or the path to a "
                              "pretrained model config file (str)")
 
     @classmethod
     def from_dict(cls, json_object):
-        config = VLXLMRConfig(vocab_size_or_config_json_file=-1)
-        for key, value in json_object.items():
-            config.__dict__[key] = value
+        config = cls(-1)
+        config.__dict__.update(json_object)
         return config
 
     @classmethod
     def from_json_file(cls, json_file):
-        with open(json_file, "r", encoding='utf-8') as reader:
-            text = reader.read()
-        return cls.from_dict(json.loads(text))
-
-    def __repr__(self):
-        return str(self.to_json_string())
+        with open(json_file, "r", encoding="utf-8") as f:
+            return cls.from_dict(json.load(f))
 
     def to_dict(self):
         return copy.deepcopy(self.__dict__)
 
     def to_json_string(self):
         return json.dumps(self.to_dict(), indent=2, sort_keys=True) + "\n"
+
+    def __repr__(self):
+        return self.to_json_string()
+
+
+def _legacy_key(key):
+    """TF-era LayerNorm names in old checkpoints: gamma -> weight, beta -> bias (model/model.py:213-226)"""
+    if "gamma" in key:
+        return key.replace("gamma", "weight")
+    if "beta" in key:
+        return key.replace("beta", "bias")
+    return None
 
 
 class VLXLMRPreTrainedModel(nn.Module):
@@ -111,6 +118,8 @@ class VLXLMRPreTrainedModel(nn.Module):
         self.config = config
 
     def init_weights(self, module):
+        """N(0, initializer_range) for Linear / Embedding weights (padding rows included), LayerNorm = (1, 0),
+        Linear biases 0 (model/model.py:159-172)"""
         if isinstance(module, (nn.Linear, nn.Embedding)):
             module.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
         elif isinstance(module, BertLayerNorm):
@@ -128,57 +137,42 @@ class VLXLMRPreTrainedModel(nn.Module):
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
-        mark_all_dirty()
+        mark_all_dirty()                   # the bf16 compute copies are stale now
         return r
 
     @classmethod
     def from_pretrained(cls, config_file, state_dict, load_embedding_only=False, load_layer=None, *inputs, **kwargs):
+        """Build the model from a JSON config and copy a checkpoint dict into it (model/model.py:174-278):
+        legacy LayerNorm key names are translated, partial XLM-R loads rename the skipped keys, a `roberta.bert.`
+        prefix in the checkpoint is honoured, missing / unexpected keys are logged, shape errors raise."""
         config = VLXLMRConfig.from_json_file(config_file)
         logger.info("Model config {}".format(config))
         model = cls(config, *inputs, **kwargs)
-        old_keys, new_keys = [], []
         if load_embedding_only:
             xlmr_sublayer_loading(state_dict, load_embedding_only=True)
         elif load_layer is not None:
             xlmr_sublayer_loading(state_dict, load_layer=load_layer)
         else:
-            for key in state_dict.keys():
-                new_key = None
-                if 'gamma' in key:
-                    new_key = key.replace('gamma', 'weight')
-                if 'beta' in key:
-                    new_key = key.replace('beta', 'bias')
-                if new_key:
-                    old_keys.append(key)
-                    new_keys.append(new_key)
-            for old_key, new_key in zip(old_keys, new_keys):
-                state_dict[new_key] = state_dict.pop(old_key)
-        missing_keys, unexpected_keys, error_msgs = [], [], []
-        metadata = getattr(state_dict, '_metadata', None)
-        state_dict = state_dict.copy()
+            for old in [k for k in state_dict.keys() if _legacy_key(k)]:
+                state_dict[_legacy_key(old)] = state_dict.pop(old)
+        metadata = getattr(state_dict, "_metadata", None)
+        sd = state_dict.copy()
         if metadata is not None:
-            state_dict._metadata = metadata
-
-        def load(module, prefix=''):
-            local_metadata = ({} if metadata is None else metadata.get(prefix[:-1], {}))
-            module._load_from_state_dict(state_dict, prefix, local_metadata, True, missing_keys,
-                                         unexpected_keys, error_msgs)
-            for name, child in module._modules.items():
-                if child is not None:
-                    load(child, prefix + name + '.')
-        start_prefix = ''
-        if not hasattr(model, 'roberta.bert.') and any(s.startswith('roberta.bert.') for s in state_dict.keys()):
-            start_prefix = 'roberta.bert.'
-        load(model, prefix=start_prefix)
-        if len(missing_keys) > 0:
-            logger.info("Weights of {} not initialized from pretrained model: {}".format(
-                model.__class__.__name__, missing_keys))
-        if len(unexpected_keys) > 0:
-            logger.info("Weights from pretrained model not used in {}: {}".format(
-                model.__class__.__name__, unexpected_keys))
-        if len(error_msgs) > 0:
-            raise RuntimeError('Error(s) in loading state_dict for {}:\n\t{}'.format(
-                model.__class__.__name__, "\n\t".join(error_msgs)))
+            sd._metadata = metadata
+        missing, unexpected, errors = [], [], []
+        prefix0 = "roberta.bert." if any(k.startswith("roberta.bert.") for k in sd.keys()) else ""
+        stack = [(model, prefix0)]
+        while stack:                       # every module copies its own direct parameters / buffers
+            module, prefix = stack.pop()
+            local = {} if metadata is None else metadata.get(prefix[:-1], {})
+            module._load_from_state_dict(sd, prefix, local, True, missing, unexpected, errors)
+            stack.extend((child, prefix + name + ".") for name, child in module._modules.items() if child is not None)
+        if missing:
+            logger.info("Weights of {} not initialized from pretrained model: {}".format(cls.__name__, missing))
+        if unexpected:
+            logger.info("Weights from pretrained model not used in {}: {}".format(cls.__name__, unexpected))
+        if errors:
+            raise RuntimeError("Error(s) in loading state_dict for {}:\n\t{}".format(cls.__name__, "\n\t".join(errors)))
         mark_all_dirty()
         return model
 
@@ -479,17 +473,25 @@ class VLXLMRForPretraining(VLXLMRPreTrainedModel):
 
     def forward_itm(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                     targets, ot_inputs, compute_loss=True):
-        if ot_inputs is not None:
-            raise NotImplementedError("the OT regulariser (itm_ot_lambda > 0) is outside the hot path "
-                                      "(SURVEY.md §8f rank 4); the shipped configs use ot_inputs=None")
         sequence_output = self.roberta(input_ids, position_ids, img_feat, img_pos_feat, attention_mask,
                                        gather_index, output_all_encoded_layers=False)
         pooled_output = self.roberta.pooler(sequence_output)
         rank_scores = self.itm_output(pooled_output)
+        ot_loss = None
+        if ot_inputs is not None:
+            # OT regulariser (model/model.py:701-729, model/ot.py): the scatter back to the padded [txt | img] layout,
+            # the cosine cost, 50 IPOT iterations and the trace run in one pass of uc2_ot_fwd per batch element
+            tl, il = input_ids.size(1), img_feat.size(1)
+            ot_dist = ops.OTDistFn.apply(sequence_output, ot_inputs['ot_scatter'], ot_inputs['txt_pad'],
+                                         ot_inputs['img_pad'], tl, il, 0.5, 50)
+            if self.ot_pos_only:
+                ot_loss = ot_dist.masked_select(targets == 1)
+            else:
+                ot_loss = (ot_dist.masked_select(targets == 1), ot_dist.masked_select(targets == 0))
         if compute_loss:
             itm_loss, _ = ops.CrossEntropyFn.apply(rank_scores, targets, -100, rank_scores.shape[-1])
-            return itm_loss, None
-        return rank_scores, None
+            return itm_loss, ot_loss
+        return rank_scores, ot_loss
 
     def forward_mrc(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index,
                     img_masks, img_mask_tgt, label_targets, task, compute_loss=True):

@@ -477,10 +477,10 @@ def ln_bwd(dy2, x2, res2, gamma, mean, rstd, dgamma, dbeta, drop_p=0.0, seed=Non
     return dx, (dres if dres is not None else dx)
 
 
-def attn_fwd(qkv, mask2d, B, L, nh, D, drop_p=0.0, seed=None, seed_imm=0, impl=None):
+def attn_fwd(qkv, mask2d, B, L, nh, D, drop_p=0.0, seed=None, seed_imm=0, impl=None, want_lse=True):
     H = nh * D
     ctx = torch.empty((B * L, H), dtype=qkv.dtype, device=qkv.device)
-    lse = torch.empty((B, nh, L), dtype=torch.float32, device=qkv.device)
+    lse = torch.empty((B, nh, L), dtype=torch.float32, device=qkv.device) if want_lse else None
     with _Timed("attn_fwd", B * L * H * qkv.element_size() * 4 + B * nh * L * 4):       # q,k,v in; ctx, lse out
         call("uc2_attn_fwd", dt(qkv.dtype), ATTN_IMPL if impl is None else impl, B, L, nh, D, ptr(qkv), ptr(mask2d),
              1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(lse), stream())
@@ -560,6 +560,20 @@ class BertLayerFn(torch.autograd.Function):
 
         wqkv = st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype)
         bqkv = st.span(st.data, P["qb"], P["vb"], (3 * H,))
+        if not any(ctx.needs_input_grad):
+            # forward-only (retrieval scoring, validation, the hard-negative scoring pass): nothing is kept for a
+            # backward -- no gelu' stream out of the FFN1 GEMM, no LayerNorm statistics, no log-sum-exp
+            qkv = linear_fwd(x2, wqkv, bqkv)
+            ctxv, _ = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, sid + 1, want_lse=False)
+            del qkv
+            o1 = linear_fwd(ctxv, st.compute(P["ow"], dtype), P["ob"].data)
+            a, _, _ = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, sid + 2, want_stats=False)
+            del o1, ctxv
+            u = linear_fwd(a, st.compute(P["iw"], dtype), P["ib"].data, EPI_GELU, None)
+            o2 = linear_fwd(u, st.compute(P["fw"], dtype), P["fb"].data)
+            del u
+            y, _, _ = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, sid + 3, want_stats=False)
+            return y.view(B, L, H)
         qkv = linear_fwd(x2, wqkv, bqkv)
         ctxv, lse = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, sid + 1)
         o1 = linear_fwd(ctxv, st.compute(P["ow"], dtype), P["ob"].data)
@@ -1182,6 +1196,37 @@ class DecoderCEFn(torch.autograd.Function):
                 call("uc2_colsum_accum", dt(dtype), m, V, ptr(dlog), Vp, None, ptr(db), stream())
                 gemm(dlog, Wp, m, H, V, tb=True, out=dz[r0:r1], lda=Vp)
         return dz[:n], None, None, None, None, None
+
+
+class OTDistFn(torch.autograd.Function):
+    """optimal_transport_dist of the scattered-back text / image embeddings (model/ot.py:66-82, model/model.py:701-720):
+    dist [B] fp32; the transport plan is a constant of the backward (the reference detaches it)"""
+
+    @staticmethod
+    def forward(ctx, seq, scatter, txt_pad, img_pad, T, R, beta, iters):
+        B, L, H = seq.shape
+        seq = seq.contiguous()
+        scatter = scatter.contiguous()
+        tp = txt_pad.to(torch.uint8).contiguous()
+        ip = img_pad.to(torch.uint8).contiguous()
+        lib = _lib.load()
+        ws = torch.empty(lib.uc2_ot_workspace(B, T, R, H), dtype=torch.uint8, device=seq.device)
+        dist = torch.empty(B, dtype=torch.float32, device=seq.device)
+        Tm = torch.empty((B, R, T), dtype=torch.float32, device=seq.device)
+        call("uc2_ot_fwd", dt(seq.dtype), B, L, T, R, H, ptr(seq), ptr(scatter), ptr(tp), ptr(ip), float(beta), int(iters),
+             ptr(dist), ptr(Tm), ptr(ws), stream())
+        ctx.save_for_backward(Tm, ws)
+        ctx.cfg = (B, L, T, R, H, seq.dtype)
+        return dist
+
+    @staticmethod
+    def backward(ctx, gdist):
+        Tm, ws = ctx.saved_tensors
+        B, L, T, R, H, dtype = ctx.cfg
+        g = gdist.contiguous().float()
+        dseq = torch.zeros((B, L, H), dtype=dtype, device=Tm.device)
+        call("uc2_ot_bwd", dt(dtype), B, L, T, R, H, ptr(Tm), ptr(ws), ptr(g), ptr(dseq), stream())
+        return dseq, None, None, None, None, None, None, None
 
 
 class AttentionFn(torch.autograd.Function):

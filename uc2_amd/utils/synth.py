@@ -265,3 +265,30 @@ def batch_to(batch, device, float_dtype=None):
                 v = v.to(float_dtype)
         out[k] = v
     return out
+
+
+def retrieval_pool(vocab_size, n_txt, n_img, T, R, seed=7, img_dim=2048):
+    """texts and images of a synthetic retrieval set (variable lengths): ids [n_txt, T] (pad 1), txt_lens,
+    img_feat [n_img, R, img_dim], img_pos_feat [n_img, R, 7], num_bbs"""
+    tb = make_batch(vocab_size, n_txt, T, R, task="itm", seed=seed, variable_len=True, img_dim=img_dim)
+    ib = make_batch(vocab_size, n_img, T, R, task="itm", seed=seed + 1, variable_len=True, img_dim=img_dim)
+    return dict(input_ids=tb["input_ids"], txt_lens=tb["_txt_lens"], img_feat=ib["img_feat"], img_pos_feat=ib["img_pos_feat"],
+                num_bbs=ib["_num_bbs"])
+
+
+def retrieval_batch(pool, i, j0, j1):
+    """text i against images j0..j1-1, built like itm_eval_collate (data/itm.py:905-930): the text repeated, images
+    padded to the longest of the mini-batch, attention mask and gather index from the true lengths"""
+    n = j1 - j0
+    tl = pool["txt_lens"][i]
+    nbs = pool["num_bbs"][j0:j1]
+    max_bb = max(nbs)
+    ids = pool["input_ids"][i:i + 1, :tl].repeat(n, 1)
+    feat = pool["img_feat"][j0:j1, :max_bb].clone()
+    pos = pool["img_pos_feat"][j0:j1, :max_bb].clone()
+    out_size = tl + max_bb
+    attn = torch.zeros(n, out_size, dtype=torch.long)
+    for r, nb in enumerate(nbs):
+        attn[r, :tl + nb] = 1
+    return OrderedDict(input_ids=ids, position_ids=torch.arange(0, tl, dtype=torch.long).unsqueeze(0), img_feat=feat,
+                       img_pos_feat=pos, attn_masks=attn, gather_index=_gather_index([tl] * n, nbs, n, tl, out_size))
