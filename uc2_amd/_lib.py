@@ -31,6 +31,9 @@ SIGNATURES = {
     "uc2_attn_bwd": (I, [I, I, I, I, I, I, P, P, F, F, P, U64, P, P, P, P, P, P]),
     "uc2_attn_mfma_supported": (I, [I, I]),
     "uc2_attn_probs_mean": (I, [I, I, I, I, I, P, P, F, P, P]),
+    "uc2_attn_general_fwd": (I, [I, I, I, I, I, I, P, I, P, I, P, I, P, P, F, P, I, P, P]),
+    "uc2_attn_general_bwd": (I, [I, I, I, I, I, I, P, I, P, I, P, I, P, P, F, P, P, I, P, P, P, I, P, I, P, I, P]),
+    "uc2_attn_general_probs_mean": (I, [I, I, I, I, I, I, P, I, P, I, P, P, F, P, P, P]),
     "uc2_position_ids": (I, [I, I, P, I64, P, P]),
     "uc2_embed_fwd": (I, [I, I, I, P, P, P, I, P, P, P, P, P]),
     "uc2_embed_bwd": (I, [I, I, I, P, P, P, P, P, P, P, I64, I64, P]),

@@ -3,9 +3,10 @@ packed `in_proj_weight [3E, E]`, `(L, N, E)` layout, boolean `key_padding_mask`)
 
 The reference uses this module only in the NLVR2 head (model/nlvr2.py), always as self-attention with the
 packed projection.  That case maps one-to-one onto the fused path of the encoder: one QKV GEMM, the fused
-attention kernel with an additive key mask, one output GEMM.  The cross-attention / separate-projection /
-bias_kv / zero_attn / attn_mask variants of the generic PyTorch function are not on any path of this
-repository and raise NotImplementedError.
+attention kernel with an additive key mask, one output GEMM.  Separate query / key / value inputs
+(cross-attention) and an additive float attn_mask [L, S] run on the general kernels (attention_general.hip): three
+projections over row slices of the packed in_proj_weight, then uc2_attn_general_*.  What stays unimplemented
+(and raises): kdim / vdim != embed_dim, bias_kv, zero_attn, boolean or 3-D attn_mask, dropout on the general path.
 """
 import torch
 from torch import nn
@@ -51,10 +52,8 @@ class MultiheadAttention(nn.Module):
     def forward(self, query, key, value, key_padding_mask=None, need_weights=True, attn_mask=None):
         """query = key = value: (L, N, E); key_padding_mask: (N, L) bool, True = ignore that key.
         Returns (attn_output (L, N, E), head-averaged weights (N, L, L) or None)."""
-        if not (query is key and key is value):
-            raise NotImplementedError("only self-attention (query is key is value) is implemented")
-        if attn_mask is not None:
-            raise NotImplementedError("attn_mask is not used by the reference's callers and is not implemented")
+        if not (query is key and key is value) or attn_mask is not None:
+            return self._forward_general(query, key, value, key_padding_mask, need_weights, attn_mask)
         L, N, E = query.shape
         cd = compute_dtype_of(self)
         x = query.transpose(0, 1).contiguous()                                   # (N, L, E): token-major rows
@@ -72,4 +71,39 @@ class MultiheadAttention(nn.Module):
         if need_weights:
             with torch.no_grad():
                 weights = ops.attn_probs_mean(qkv2.detach(), mask2d, N, L, self.num_heads, self.head_dim)
+        return out, weights
+
+    def _forward_general(self, query, key, value, key_padding_mask, need_weights, attn_mask):
+        """cross-attention / additive attn_mask (model/attention.py:130-264 with the packed in_proj split in thirds)"""
+        if self.training and self.dropout > 0:
+            raise NotImplementedError("attention dropout is implemented on the packed self-attention path only")
+        L, N, E = query.shape
+        S = key.shape[0]
+        if key.shape != value.shape or key.shape[1] != N or key.shape[2] != E:
+            raise NotImplementedError("key / value must be (S, N, embed_dim)")
+        if attn_mask is not None:
+            if attn_mask.dim() != 2 or tuple(attn_mask.shape) != (L, S) or not attn_mask.is_floating_point():
+                raise NotImplementedError("attn_mask must be an additive float mask of shape (L, S)")
+            attn_mask = attn_mask.to(torch.float32).contiguous()
+        cd = compute_dtype_of(self)
+
+        def rows(x):                                          # (L, N, E) -> token-major (N*L, E)
+            x = x.transpose(0, 1).contiguous()
+            return ops.cast(x, cd) if x.dtype != cd else x
+        W, bvec = self.in_proj_weight, self.in_proj_bias
+        q = ops.LinearFn.apply(rows(query), self, ops.EPI_NONE, False, W, bvec, (0, E))
+        k = ops.LinearFn.apply(rows(key), self, ops.EPI_NONE, False, W, bvec, (E, 2 * E))
+        v = ops.LinearFn.apply(rows(value), self, ops.EPI_NONE, False, W, bvec, (2 * E, 3 * E))
+        kmask = None
+        if key_padding_mask is not None:
+            kmask = torch.zeros((N, S), dtype=torch.float32, device=query.device)
+            kmask.masked_fill_(key_padding_mask.to(torch.bool), -1e30)
+        ctx, lse = ops.AttentionGeneralFn.apply(q.reshape(N * L, E), k.reshape(N * S, E), v.reshape(N * S, E), kmask, attn_mask,
+                                                N, L, S, self.num_heads, self.head_dim)
+        out = self.out_proj(ctx.view(N, L, E)).transpose(0, 1)
+        weights = None
+        if need_weights:
+            with torch.no_grad():
+                weights = ops.attn_general_probs_mean(q.detach().reshape(N * L, E), k.detach().reshape(N * S, E), kmask,
+                                                      attn_mask, lse, N, L, S, self.num_heads, self.head_dim)
         return out, weights

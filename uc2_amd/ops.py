@@ -642,7 +642,8 @@ class LinearFn(torch.autograd.Function):
     transposed (RegionFeatureRegression: F.linear(h, W_img^T), model/model.py:1155)."""
 
     @staticmethod
-    def forward(ctx, x, owner, act, weight_t, weight, bias):
+    def forward(ctx, x, owner, act, weight_t, weight, bias, rows=None):
+        """rows = (r0, r1): use only output rows r0..r1-1 of weight / bias (the q, k or v third of a packed in_proj)"""
         st = store_of(owner)
         dtype = x.dtype
         if dtype == torch.bfloat16:
@@ -652,16 +653,20 @@ class LinearFn(torch.autograd.Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         w = st.compute(weight, dtype)
-        M, K = x2.shape
-        N = weight.shape[1] if weight_t else weight.shape[0]
-        pre = torch.empty((M, N), dtype=dtype, device=x.device) if act == EPI_GELU else None
         b = bias.data if bias is not None else None
+        if rows is not None:
+            assert not weight_t
+            w = w[rows[0]:rows[1]]
+            b = b[rows[0]:rows[1]] if b is not None else None
+        M, K = x2.shape
+        N = w.shape[1] if weight_t else w.shape[0]
+        pre = torch.empty((M, N), dtype=dtype, device=x.device) if act == EPI_GELU else None
         if weight_t:
             y = gemm(x2, w, M, N, K, tb=True, bias=b, epi=act, aux_out=pre)
         else:
             y = gemm(x2, w, M, N, K, bias=b, epi=act, aux_out=pre)
         ctx.save_for_backward(x2, pre if act == EPI_GELU else (y if act == EPI_TANH else None))
-        ctx.owner, ctx.act, ctx.weight_t, ctx.wb, ctx.shp = owner, act, weight_t, (weight, bias), shp
+        ctx.owner, ctx.act, ctx.weight_t, ctx.wb, ctx.shp, ctx.rows = owner, act, weight_t, (weight, bias), shp, rows
         return y.view(*shp[:-1], N)
 
     @staticmethod
@@ -685,6 +690,10 @@ class LinearFn(torch.autograd.Function):
         w = st.compute(weight, dtype)
         dw = st.grad_buf(weight)
         db = st.grad_buf(bias) if bias is not None else None
+        if ctx.rows is not None:
+            r0, r1 = ctx.rows
+            w, dw = w[r0:r1], dw[r0:r1]
+            db = db[r0:r1] if db is not None else None
         if ctx.weight_t:                        # weight [K_in, N_out]: dW[K,N] += X^T dPre
             gemm(x2, dpre, K, N, M, ta=True, tb=True, out=dw, accumulate=True,
                  split_k=_wgrad_split(dtype, K, N, M))
@@ -699,7 +708,8 @@ class LinearFn(torch.autograd.Function):
             else:
                 dx = linear_dgrad(dpre, w)
             dx = dx.view(ctx.shp)
-        return dx, None, None, None, None, None
+        # one gradient slot per input actually passed (`rows` is only ever passed as a tuple, never as an explicit None)
+        return (dx, None, None, None, None, None) + ((None,) if ctx.rows is not None else ())
 
 
 def _dgelu(dy2, pre):
@@ -1246,6 +1256,45 @@ class AttentionFn(torch.autograd.Function):
         B, L, nh, D, drop_p, seed_imm = ctx.cfg
         dqkv = attn_bwd(qkv2, mask2d, ctxv, dctx.contiguous(), lse, B, L, nh, D, drop_p, seed, seed_imm)
         return dqkv, None, None, None, None, None, None, None
+
+
+class AttentionGeneralFn(torch.autograd.Function):
+    """softmax(scale q k^T + key_mask + attn_mask) v with separate q / k / v [B*L, nh*D] tensors (cross-attention,
+    additive attn_mask): the general form behind MultiheadAttention (model/attention.py:12-264); fp32 math, no dropout"""
+
+    @staticmethod
+    def forward(ctx, q2, k2, v2, key_mask, attn_mask, B, Lq, Lk, nh, D):
+        q2, k2, v2 = q2.contiguous(), k2.contiguous(), v2.contiguous()
+        H = nh * D
+        out = torch.empty((B * Lq, H), dtype=q2.dtype, device=q2.device)
+        lse = torch.empty((B, nh, Lq), dtype=torch.float32, device=q2.device)
+        call("uc2_attn_general_fwd", dt(q2.dtype), B, Lq, Lk, nh, D, ptr(q2), H, ptr(k2), H, ptr(v2), H, ptr(key_mask),
+             ptr(attn_mask), 1.0 / math.sqrt(D), ptr(out), H, ptr(lse), stream())
+        ctx.save_for_backward(q2, k2, v2, key_mask, attn_mask, out, lse)
+        ctx.cfg = (B, Lq, Lk, nh, D)
+        ctx.mark_non_differentiable(lse)
+        return out, lse
+
+    @staticmethod
+    def backward(ctx, dout, _dlse):
+        q2, k2, v2, key_mask, attn_mask, out, lse = ctx.saved_tensors
+        B, Lq, Lk, nh, D = ctx.cfg
+        H = nh * D
+        dout = dout.contiguous()
+        dq, dk, dv = torch.empty_like(q2), torch.empty_like(k2), torch.empty_like(v2)
+        delta = torch.empty((B, nh, Lq), dtype=torch.float32, device=q2.device)
+        call("uc2_attn_general_bwd", dt(q2.dtype), B, Lq, Lk, nh, D, ptr(q2), H, ptr(k2), H, ptr(v2), H, ptr(key_mask),
+             ptr(attn_mask), 1.0 / math.sqrt(D), ptr(out), ptr(dout), H, ptr(lse), ptr(delta), ptr(dq), H, ptr(dk), H,
+             ptr(dv), H, stream())
+        return dq, dk, dv, None, None, None, None, None, None, None
+
+
+def attn_general_probs_mean(q2, k2, key_mask, attn_mask, lse, B, Lq, Lk, nh, D):
+    out = torch.empty((B, Lq, Lk), dtype=torch.float32, device=q2.device)
+    H = nh * D
+    call("uc2_attn_general_probs_mean", dt(q2.dtype), B, Lq, Lk, nh, D, ptr(q2), H, ptr(k2), H, ptr(key_mask), ptr(attn_mask),
+         1.0 / math.sqrt(D), ptr(lse), ptr(out), stream())
+    return out
 
 
 def attn_probs_mean(qkv2, mask2d, B, L, nh, D):
