@@ -6,7 +6,7 @@ from uc2_amd import ops
 from bench_gemm import timeit
 
 def main():
-    B, L, nh, D = 512, 96, 12, 64
+    B, L, nh, D = 1024, 96, 12, 64
     H = nh * D
     qkv = (torch.randn(B * L, 3 * H, device="cuda") * 0.5).to(torch.bfloat16)
     mask = torch.zeros(B, L, device="cuda")

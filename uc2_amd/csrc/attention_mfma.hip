@@ -242,6 +242,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
+// One orientation only (key on the lane): wave w owns keys 32w .. 32w+31 of the head.  Per 32-query block it forms
+// S = Q K^T and dP = dO V^T with the key on the lane (K and V rows of the wave are its B fragments, held in registers),
+// so P and dS come out as accumulator tiles that ARE the B operands of dV^T += dO^T P and dK^T += Q^T dS; only dS
+// crosses LDS, once, as a bf16 [key][query] image that the dQ phase reads back with the transposing read
+// (dQ^T = K^T dS^T, each wave its own 32 queries over all keys).  Against the two-orientation version of round 1
+// (S, dP and the softmax / dropout arithmetic evaluated twice): 60 instead of 84 MFMAs and about half the VALU work per
+// wave and head, and no V tile in LDS.
 template <int D, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, const bf16* __restrict__ qkv,
                                                                 const float* __restrict__ mask, float scale,
@@ -252,12 +259,13 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
                                                                 const float* __restrict__ lse,
                                                                 bf16* __restrict__ dqkv, float* __restrict__ dbias, int nbh, int hpw) {
   constexpr int KS = D / 16, DB = D / 32, RS = D * 2 + 16, Lp = NW * 32;
+  constexpr int RSD = Lp * 2 + 16;                     // dS^T image: [key][query] bf16
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qs = smem;
   char* Ks = smem + Lp * RS;
-  char* Vs = smem + 2 * Lp * RS;
-  char* Gs = smem + 3 * Lp * RS;                       // dO
-  float* Ms = reinterpret_cast<float*>(smem + 4 * Lp * RS);
+  char* Gs = smem + 2 * Lp * RS;                       // dO
+  char* Ss = smem + 3 * Lp * RS;                       // dS^T
+  float* Ms = reinterpret_cast<float*>(Ss + Lp * RSD);
   float* Ls = Ms + Lp;
   float* Ds = Ls + Lp;
   uint32_t* Hq = reinterpret_cast<uint32_t*>(Ds + Lp);          // per-query / per-key dropout hashes
@@ -265,20 +273,24 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
   const int H = nh * D, ld = 3 * H;
   const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
   const int tid = threadIdx.x;
+  const int w = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+  const int r0 = 32 * w + c;                           // this lane's key (main loop) and query (dQ phase)
   constexpr int NTHR = NW * 64, CPR = D / 8, NCH = Lp * CPR / NTHR;
   const int bh_end = min(nbh, (int)(blockIdx.x + 1) * hpw);
   int bh = blockIdx.x * hpw;
-  // ---- fetch of one head into registers: Q, K, V, dO, O tiles (NCH chunks each) + mask / lse of row tid
-  bf16x8 rq[NCH], rk[NCH], rv[NCH], rg[NCH], ro[NCH];
+  // ---- fetch of one head into registers: Q, K, dO, O tiles (NCH chunks each), this lane's V fragments, mask / lse of row tid
+  bf16x8 rq[NCH], rk[NCH], rg[NCH], ro[NCH], rvf[KS];
   float rmask = 0.f, rlse = 0.f;
   auto fetch = [&](int hd) __attribute__((always_inline)) {
     const int fb = hd / nh, fh = hd - fb * nh;
     const bf16* fbase = qkv + (size_t)fb * L * ld + fh * D;
     load_tile_regs<D, NCH>(rq, fbase, ld, L, tid, NTHR);
     load_tile_regs<D, NCH>(rk, fbase + H, ld, L, tid, NTHR);
-    load_tile_regs<D, NCH>(rv, fbase + 2 * H, ld, L, tid, NTHR);
     load_tile_regs<D, NCH>(rg, dctx + (size_t)fb * L * H + fh * D, H, L, tid, NTHR);
     load_tile_regs<D, NCH>(ro, ctx + (size_t)fb * L * H + fh * D, H, L, tid, NTHR);
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      rvf[s] = (r0 < L) ? *reinterpret_cast<const bf16x8*>(fbase + 2 * H + (size_t)r0 * ld + 16 * s + 8 * h) : zero8();
     if (tid < Lp && tid < L) {
       rmask = mask ? mask[(size_t)fb * L + tid] : 0.f;
       rlse = lse[(size_t)hd * L + tid];
@@ -291,7 +303,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
   // ---- registers -> LDS (the previous head's readers are past the barrier at the end of the loop body)
   store_tile_regs<D, NCH>(Qs, rq, tid, NTHR);
   store_tile_regs<D, NCH>(Ks, rk, tid, NTHR);
-  store_tile_regs<D, NCH>(Vs, rv, tid, NTHR);
   store_tile_regs<D, NCH>(Gs, rg, tid, NTHR);
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {                      // delta[row] = sum_d dO*O: 8 values per chunk, CPR consecutive lanes per row
@@ -309,73 +320,20 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
     Hq[tid] = attn_line_hash(seed, bh, tid, UC2_ATTN_SALT_Q);
     Hk[tid] = attn_line_hash(seed, bh, tid, UC2_ATTN_SALT_K);
   }
+  bf16x8 vf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) vf[s] = rvf[s];
   __syncthreads();
   if (bh + 1 < bh_end) fetch(bh + 1);                  // in flight during the compute below
 
-  const int w = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
-  const int r0 = 32 * w + c;               // this lane's query (orientation 1) and key (orientation 2)
-
-  // ---------------- orientation 1: rows = key, cols = query (this wave's 32 queries) -> dQ ----------------
+  // ---------------- rows = query, cols = key (this wave's 32 keys) -> dK, dV, and dS^T into LDS ----------------
+  f32x16 dk[DB], dv[DB];
   {
-    bf16x8 qf[KS], gf[KS];
+    bf16x8 kf[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) { qf[s] = ld_row(Qs, RS, r0, 2 * s + h); gf[s] = ld_row(Gs, RS, r0, 2 * s + h); }
-    const float lq = Ls[r0], dl = Ds[r0];
-    const uint32_t hq1 = Hq[r0];
-    f32x16 dq[DB];
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < NW; ++kb) {
-      f32x16 sa, pa;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { sa[r] = 0.f; pa[r] = 0.f; }
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_row(Ks, RS, 32 * kb + c, 2 * s + h), qf[s], sa, 0, 0, 0);
-        pa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_row(Vs, RS, 32 * kb + c, 2 * s + h), gf[s], pa, 0, 0, 0);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 mv = *reinterpret_cast<const float4*>(Ms + 32 * kb + 8 * g + 4 * h);
-        const float m4[4] = {mv.x, mv.y, mv.z, mv.w};
-        bool kp[4] = {true, true, true, true};
-        if (thresh) {
-          const uint4 hk4 = *reinterpret_cast<const uint4*>(Hk + 32 * kb + 8 * g + 4 * h);
-          kp[0] = attn_keep(hq1, hk4.x, thresh); kp[1] = attn_keep(hq1, hk4.y, thresh);
-          kp[2] = attn_keep(hq1, hk4.z, thresh); kp[3] = attn_keep(hq1, hk4.w, thresh);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int i = 4 * g + e;
-          const float p = __expf(sa[i] * scale + m4[e] - lq);
-          float dp = pa[i];
-          if (thresh) dp = kp[e] ? dp * keep_scale : 0.f;
-          sa[i] = p * (dp - dl) * scale;            // dS^T
-        }
-      }
-#pragma unroll
-      for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr(Ks, RS, 32 * kb + 16 * s, 32 * db, lane),
-                                                           pack8(sa, s), dq[db], 0, 0, 0);
-    }
-    if (dbias) acc_colsum_atomic<DB>(dq, r0 < L, dbias + head * D, lane);       // d(query bias)
-#pragma unroll
-    for (int db = 0; db < DB; ++db) store_acc_block(dbase + (size_t)r0 * ld + 32 * db, dq[db], 1.0f, h, r0 < L);
-  }
-
-  // ---------------- orientation 2: rows = query, cols = key (this wave's 32 keys) -> dK, dV ----------------
-  {
-    bf16x8 kf[KS], vf[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) { kf[s] = ld_row(Ks, RS, r0, 2 * s + h); vf[s] = ld_row(Vs, RS, r0, 2 * s + h); }
+    for (int s = 0; s < KS; ++s) kf[s] = ld_row(Ks, RS, r0, 2 * s + h);
     const float mk = Ms[r0];
     const uint32_t hk2 = Hk[r0];
-    f32x16 dk[DB], dv[DB];
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -397,6 +355,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
         const float l4[4] = {lv.x, lv.y, lv.z, lv.w}, d4[4] = {dv4.x, dv4.y, dv4.z, dv4.w};
         const uint4 hq4 = *reinterpret_cast<const uint4*>(Hq + 32 * qb + 8 * g + 4 * h);
         const uint32_t hqv[4] = {hq4.x, hq4.y, hq4.z, hq4.w};
+        bf16x4 ds4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int i = 4 * g + e;
@@ -408,8 +367,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
             dp = keep ? dp * keep_scale : 0.f;
           }
           pa[i] = pd;                                // dropped P
-          sa[i] = p * (dp - d4[e]) * scale;          // dS
+          const float dsv = p * (dp - d4[e]) * scale;
+          sa[i] = dsv;                               // dS
+          ds4[e] = (bf16)dsv;
         }
+        // dS^T image: row = this lane's key, columns = queries 32 qb + 8 g + 4 h .. +3 (registers 4g .. 4g+3)
+        *reinterpret_cast<bf16x4*>(Ss + r0 * RSD + (32 * qb + 8 * g + 4 * h) * 2) = ds4;
       }
 #pragma unroll
       for (int db = 0; db < DB; ++db)
@@ -430,6 +393,25 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
       store_acc_block(dbase + (size_t)r0 * ld + H + 32 * db, dk[db], 1.0f, h, r0 < L);
       store_acc_block(dbase + (size_t)r0 * ld + 2 * H + 32 * db, dv[db], 1.0f, h, r0 < L);
     }
+  }
+  __syncthreads();                                     // every wave's dS^T columns are in LDS
+  // ---------------- dQ^T = K^T dS^T for this wave's 32 queries, contracted over all keys ----------------
+  {
+    f32x16 dq[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2 * NW; ++ks) {              // 16 keys per step; A (K^T) and B (dS^T) read with the same k permutation
+      const bf16x8 bfrag = ld_tr(Ss, RSD, 16 * ks, 32 * w, lane);
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+        dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr(Ks, RS, 16 * ks, 32 * db, lane), bfrag, dq[db], 0, 0, 0);
+    }
+    if (dbias) acc_colsum_atomic<DB>(dq, r0 < L, dbias + head * D, lane);       // d(query bias)
+#pragma unroll
+    for (int db = 0; db < DB; ++db) store_acc_block(dbase + (size_t)r0 * ld + 32 * db, dq[db], 1.0f, h, r0 < L);
   }
   __syncthreads();                                     // every wave is done with this head's LDS tiles
   }
@@ -454,8 +436,8 @@ template <int D, int NW>
 static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, float scale, float drop_p,
                       const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx, const void* dctx,
                       const float* lse, void* dqkv, float* dbias, hipStream_t st) {
-  constexpr int RS = D * 2 + 16, Lp = NW * 32;
-  const size_t smem = 4 * Lp * RS + 5 * Lp * sizeof(float);
+  constexpr int RS = D * 2 + 16, Lp = NW * 32, RSD = Lp * 2 + 16;
+  const size_t smem = 3 * Lp * RS + Lp * RSD + 5 * Lp * sizeof(float);
   auto kern = attn_bwd_mfma_kernel<D, NW>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
