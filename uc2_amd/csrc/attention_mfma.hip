@@ -22,6 +22,9 @@
 #include "common.h"
 
 #define AM_MAXW 5       // up to 160 positions
+#ifndef AM_BWD_PREFETCH
+#define AM_BWD_PREFETCH 0    // backward: fetch the next head into registers during the compute (costs ~80 VGPRs)
+#endif
 
 __device__ __forceinline__ bf16x8 zero8() { return bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
 
@@ -249,8 +252,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
 // (dQ^T = K^T dS^T, each wave its own 32 queries over all keys).  Against the two-orientation version of round 1
 // (S, dP and the softmax / dropout arithmetic evaluated twice): 60 instead of 84 MFMAs and about half the VALU work per
 // wave and head, and no V tile in LDS.
+// (launch bound: 2 waves per SIMD = 256 registers per lane.  Unbounded, hipcc took 254 VGPRs + 96 AGPRs, which admits ONE
+// wave per SIMD: one 3-wave workgroup per CU with a SIMD idle -- rocprofv3 showed wave lifetimes of half the kernel.)
 template <int D, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, const bf16* __restrict__ qkv,
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh, const bf16* __restrict__ qkv,
                                                                 const float* __restrict__ mask, float scale,
                                                                 uint32_t thresh, float keep_scale,
                                                                 const uint64_t* __restrict__ seed_ptr,
@@ -296,10 +301,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
       rlse = lse[(size_t)hd * L + tid];
     }
   };
-  fetch(bh);
+  if (AM_BWD_PREFETCH) fetch(bh);
   for (; bh < bh_end; ++bh) {
   const int b = bh / nh, head = bh - b * nh;
   bf16* dbase = dqkv + (size_t)b * L * ld + head * D;
+  if (!AM_BWD_PREFETCH) fetch(bh);                     // no register prefetch: the CU's other workgroup covers the latency
   // ---- registers -> LDS (the previous head's readers are past the barrier at the end of the loop body)
   store_tile_regs<D, NCH>(Qs, rq, tid, NTHR);
   store_tile_regs<D, NCH>(Ks, rk, tid, NTHR);
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_mfma_kernel(int L, int nh, c
 #pragma unroll
   for (int s = 0; s < KS; ++s) vf[s] = rvf[s];
   __syncthreads();
-  if (bh + 1 < bh_end) fetch(bh + 1);                  // in flight during the compute below
+  if (AM_BWD_PREFETCH && bh + 1 < bh_end) fetch(bh + 1);        // in flight during the compute below
 
   // ---------------- rows = query, cols = key (this wave's 32 keys) -> dK, dV, and dS^T into LDS ----------------
   f32x16 dk[DB], dv[DB];
@@ -444,8 +450,18 @@ static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, 
     if (e != hipSuccess) { uc2_set_error(__FILE__, __LINE__, hipGetErrorString(e)); return (int)e; }
   }
   const int nbh = B * nh;
-  // heads per workgroup (next head prefetched into registers): about two resident workgroups per CU walk the heads
-  const int hpw = nbh >= 1024 ? (nbh / 512 > 16 ? 16 : nbh / 512) : 1;
+  // heads per workgroup (next head prefetched into registers): two workgroups are resident per CU (LDS, registers), so
+  // the grid is ONE full round of 2 x CUs workgroups that walk ceil(nbh / grid) heads each (12 288 heads on 256 CUs:
+  // 512 workgroups x 24 heads; a cap of 16 heads made it 768 workgroups = 1.5 rounds, a quarter of the time half empty)
+  static int cus_cached = 0;
+  if (!cus_cached) {
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    cus_cached = cus;
+  }
+  const int slots = 2 * cus_cached;
+  const int hpw = nbh > slots ? (nbh + slots - 1) / slots : 1;
   hipLaunchKernelGGL(kern, dim3((nbh + hpw - 1) / hpw), dim3(NW * 64), smem, st, L, nh, (const bf16*)qkv, mask, scale,
                      drop_thresh(drop_p), 1.0f / (1.0f - drop_p), seed_ptr, seed_imm, (const bf16*)ctx,
                      (const bf16*)dctx, lse, (bf16*)dqkv, dbias, nbh, hpw);
