@@ -67,6 +67,7 @@ enum { UC2_GEMM_AUTO = -2, UC2_GEMM_GENERIC = 99 };
 enum { UC2_GEMM_DEFER_REDUCE = 1, UC2_GEMM_AUX_DERIV = 2 };
 #define UC2_GEMM_SKEW(n) (((n) & 15) << 4)
 #define UC2_GEMM_DIAG(m) (((m) & 0xFFFF) << 8)
+#define UC2_GEMM_COLGROUP(n) (((n) & 15) << 24)     /* diagnostic: column tiles per L2 group of the ping-pong tile order (0 = default) */
 int uc2_gemm_splitk_reduce(int M, int N, void* C, int ldc, int split_k, int accumulate, const void* workspace,
                            size_t workspace_bytes, void* stream);
 

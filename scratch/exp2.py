@@ -7,7 +7,7 @@ from uc2_amd import ops
 from bench_gemm import timeit
 M = 98304
 cases = [("ffn1 gelu", False, 3072, 768, ops.EPI_GELU, True), ("ffn1 gelu nopre", False, 3072, 768, ops.EPI_GELU, False),
-         ("ffn1 none", False, 3072, 768, ops.EPI_NONE, False), ("out none", False, 768, 768, ops.EPI_NONE, False),
+         ("ffn1 none", False, 3072, 768, ops.EPI_NONE, False), ("qkv none", False, 2304, 768, ops.EPI_NONE, False),
          ("ffn2 add", False, 768, 3072, ops.EPI_ADD, False), ("dgrad dgelu", True, 3072, 768, ops.EPI_DGELU, False)]
 for name, tb, n, k, epi, wpre in cases:
     a = torch.randn((M, k), device="cuda").to(torch.bfloat16)
@@ -18,9 +18,9 @@ for name, tb, n, k, epi, wpre in cases:
     out = torch.empty((M, n), dtype=torch.bfloat16, device="cuda")
     row = []
     for rep in range(2):
-        for diag in (0, 0x8):
+        for cg in (0, 6):
             fn = lambda: ops.gemm(a, b, M, n, k, tb=tb, out=out, bias=bias, epi=epi,
-                                  aux_in=aux if epi in (ops.EPI_ADD, ops.EPI_DGELU) else None, aux_out=pre, variant=8, flags=diag << 8)
+                                  aux_in=aux if epi in (ops.EPI_ADD, ops.EPI_DGELU) else None, aux_out=pre, variant=8, flags=(cg << 24) | ops.GEMM_AUX_DERIV)
             t = timeit(fn)
-            if rep: row.append("%s %6.1f" % ({0: "full", 0x2000: "fullline-stores", 8: "loop-only"}[diag], 2.0 * M * n * k / t / 1e12))
+            if rep: row.append("cg%d %6.1f" % (cg, 2.0 * M * n * k / t / 1e12))
     print("%-18s N=%5d K=%5d  " % (name, n, k) + "  ".join(row))

@@ -1,9 +1,10 @@
-"""Build profiles/pmc_summary.json from three rocprofv3 --pmc passes (not a test).
+"""Build profiles/rNN_pmc_summary.json from three rocprofv3 --pmc passes (not a test).
 
-    python tests/pmc_summarize.py <kernel-substring> <dir FETCH_SIZE> <dir WRITE_SIZE> <dir SQ counters> > profiles/pmc_summary.json
+    python tests/pmc_summarize.py <round> <dir FETCH_SIZE> <dir WRITE_SIZE> <dir SQ counters> <kernel-substring> [...]
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and
-WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads and is doubled."""
+WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads and is doubled.
+The first kernel listed is the dominant one (bench.py reads its hbm_bytes_per_launch as roofline.traffic)."""
 import collections, csv, glob, json, sys
 
 
@@ -25,33 +26,45 @@ def pick(acc, sub):
     return best
 
 
-def main():
-    sub = sys.argv[1]
-    out = {"round": 1, "kernel": None,
-           "command": "rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python3 bench.py --steps 2 --warmup 2 "
-                      "--no-cpu-baseline (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE "
-                      "SQ_WAVE_CYCLES SQ_WAIT_ANY)"}
+def one(sub, F, W, S):
     avg = lambda v: sum(v) / len(v)
-    k, n, cs = pick(load(sys.argv[2]), sub)
+    out = {}
+    hit = pick(F, sub)
+    if hit is None:
+        return None
+    k, n, cs = hit
     out["kernel"] = k.replace("void ", "").split("(")[0]
     out["launches_averaged"] = n
     fetch_kb = avg(cs["FETCH_SIZE"])
-    k2, n2, cs2 = pick(load(sys.argv[3]), sub)
-    write_kb = avg(cs2["WRITE_SIZE"])
+    write_kb = avg(pick(W, sub)[2]["WRITE_SIZE"])
     out["FETCH_SIZE_KB_per_launch_raw"] = round(fetch_kb, 1)
     out["WRITE_SIZE_KB_per_launch"] = round(write_kb, 1)
     out["hbm_bytes_per_launch"] = int((2.0 * fetch_kb + write_kb) * 1024)
-    out["correction"] = ("gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads -> doubled "
-                         "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE as is; Infinity-Cache hits are included in FETCH_SIZE")
-    k3, n3, cs3 = pick(load(sys.argv[4]), sub)
-    for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"):
+    cs3 = pick(S, sub)[2]
+    for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES"):
         if c in cs3:
-            out[c if c != "GRBM_GUI_ACTIVE" else "GRBM_GUI_ACTIVE_sum_over_8_xcd"] = avg(cs3[c])
+            out[c if c != "GRBM_GUI_ACTIVE" else "GRBM_GUI_ACTIVE_sum_over_8_xcd"] = round(avg(cs3[c]), 1)
     if "SQ_VALU_MFMA_BUSY_CYCLES" in cs3 and "GRBM_GUI_ACTIVE" in cs3:
         # busy cycles are summed over 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE over the 8 XCDs
         out["mfma_busy_frac"] = round(avg(cs3["SQ_VALU_MFMA_BUSY_CYCLES"]) / (avg(cs3["GRBM_GUI_ACTIVE"]) / 8.0 * 1024.0), 4)
     if "SQ_WAIT_ANY" in cs3 and "SQ_WAVE_CYCLES" in cs3:
         out["wait_frac"] = round(avg(cs3["SQ_WAIT_ANY"]) / avg(cs3["SQ_WAVE_CYCLES"]), 4)
+    return out
+
+
+def main():
+    rnd = int(sys.argv[1])
+    F, W, S = load(sys.argv[2]), load(sys.argv[3]), load(sys.argv[4])
+    ks = [one(sub, F, W, S) for sub in sys.argv[5:]]
+    ks = [k for k in ks if k]
+    out = dict(ks[0])
+    out["round"] = rnd
+    out["command"] = ("rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python3 bench.py --steps 2 --warmup 2 "
+                      "--no-cpu-baseline --no-extras (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES "
+                      "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES)")
+    out["correction"] = ("gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads -> doubled "
+                         "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE as is; Infinity-Cache hits are included in FETCH_SIZE")
+    out["other_kernels"] = ks[1:]
     print(json.dumps(out, indent=1))
 
 

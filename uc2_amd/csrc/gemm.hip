@@ -324,6 +324,13 @@ extern "C" int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K
   p.epi = epilogue; p.c_f32 = (dtype == 0) ? 1 : c_is_f32; p.accumulate = accumulate;
   p.split_k = split_k; p.atomic = (split_k > 1) ? 1 : 0; p.partial = nullptr;
   p.variant = variant; p.ws = reinterpret_cast<float*>(workspace); p.ws_bytes = workspace ? workspace_bytes : 0;
+  {
+    const int nbx = N / 256 > 0 ? N / 256 : 1;
+    int cg = nbx;
+    if (nbx > 6) { cg = 1; for (int d = 6; d >= 2; --d) if (nbx % d == 0) { cg = d; break; } if (cg == 1) cg = 6; }
+    const int want = (flags >> 24) & 15;                 // diagnostic override: UC2_GEMM_COLGROUP(n)
+    p.col_group = want ? (want > nbx ? nbx : want) : cg;
+  }
   p.defer = flags & 1; p.aux_deriv = (flags >> 1) & 1; p.skew = (flags >> 4) & 15; p.diag = (flags >> 8) & 0xFFFF;
   p.a_vec = (((uintptr_t)A & 15) == 0) && ((lda & 7) == 0);
   p.b_vec = (((uintptr_t)B & 15) == 0) && ((ldb & 7) == 0);

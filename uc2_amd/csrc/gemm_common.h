@@ -3,7 +3,8 @@
 #include "common.h"
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_ADD = 3, EPI_TANH = 4,
-       EPI_GELU_D = 5, EPI_MUL = 6 };     // internal to the ping-pong kernel: EPI_GELU / EPI_DGELU under GemmArgs::aux_deriv
+       EPI_GELU_D = 5, EPI_MUL = 6,       // internal to the ping-pong kernel: EPI_GELU / EPI_DGELU under GemmArgs::aux_deriv
+       EPI_GELU_NOAUX = 7 };              // ... and EPI_GELU without a second output stream (aux_out == NULL)
 
 struct GemmArgs {
   const void* A; const void* B; void* C;
@@ -19,6 +20,7 @@ struct GemmArgs {
   float* ws; size_t ws_bytes;   // caller-owned split-K workspace for THIS call (or null)
   int defer;             // leave the split-K partials in ws (the caller runs uc2_gemm_splitk_reduce)
   int diag;              // diagnostic launch mode (main loop only / epilogue only / stamps), 0 in production
+  int col_group;         // ping-pong kernel: column tiles per L2 group of the tile order (host: largest divisor of N/256 that is <= 6)
   int aux_deriv;         // UC2_GEMM_AUX_DERIV: EPI_GELU stores gelu'(pre) (not pre) to aux_out, EPI_DGELU multiplies by aux_in as is
 };
 

@@ -153,6 +153,7 @@ __device__ __forceinline__ TpAddr tp_addr(unsigned tb, int lane) {
 
 struct PpOut {
   bf16x8 o[2][2][4];          // [A half][i][it], LINE layout: row 8*it + (lane >> 3) of the 32-row block, columns 8*(lane & 7) .. +7
+  bf16x8 pre[2][2][4];        // second output stream of the GELU epilogues (aux_out), same layout; unused otherwise
 };
 
 template <int EPI, int HI>
@@ -205,9 +206,11 @@ __device__ __forceinline__ void pp_epi_compute(const GemmArgs& p, const f32x16 (
             v[e] = __uint_as_float(sw[0]);
             v[4 + e] = __uint_as_float(sw[1]);
           }
-          if (EPI == EPI_GELU) {
+          if (EPI == EPI_GELU || EPI == EPI_GELU_NOAUX) {
+            if (EPI == EPI_GELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pre[k][e] = (bf16)v[e];
+              for (int e = 0; e < 8; ++e) pre[k][e] = (bf16)v[e];
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = gelu_bf(v[e]);
           } else if (EPI == EPI_GELU_D) {               // aux_out <- gelu'(pre): the backward multiplies by it (EPI_MUL)
@@ -235,16 +238,14 @@ __device__ __forceinline__ void pp_epi_compute(const GemmArgs& p, const f32x16 (
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[k][e] = (bf16)v[e];
         }
-      if ((EPI == EPI_GELU || EPI == EPI_GELU_D) && p.aux_out) {
-        // the pre-activation copy leaves from here (older than the next item's LDS-DMA: it has mostly drained by the
-        // time that is waited for)
-        bf16x8 t[4];
+      if (EPI == EPI_GELU || EPI == EPI_GELU_D) {
+        // the second stream is kept in registers (the accumulators are dead by now) and stored AFTER the next item's
+        // LDS-DMA has been issued, like the main output: stores issued before it are older than the DMA in the in-order
+        // vmcnt queue, and the next tile's first wait then has to sit through their write acknowledgements
         tp_write(ta.rh[0], pre[0]); tp_write(ta.rh[1], pre[1]); tp_write(ta.rh[2], pre[2]); tp_write(ta.rh[3], pre[3]);
-        tp_read_o<0>(t[0], ta.line); tp_read_o<1024>(t[1], ta.line); tp_read_o<2048>(t[2], ta.line); tp_read_o<3072>(t[3], ta.line);
-        TP_WAIT4(t[0], t[1], t[2], t[3]);
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.aux_out) + (size_t)(mb0 + hh * 64 + i * 32 + 8 * it + lr) * p.ldaux + nb + 8 * lc) = t[it];
+        tp_read_o<0>(out.pre[hh][i][0], ta.line); tp_read_o<1024>(out.pre[hh][i][1], ta.line);
+        tp_read_o<2048>(out.pre[hh][i][2], ta.line); tp_read_o<3072>(out.pre[hh][i][3], ta.line);
+        TP_WAIT4(out.pre[hh][i][0], out.pre[hh][i][1], out.pre[hh][i][2], out.pre[hh][i][3]);
       }
       tp_write(ta.rh[0], o[0]); tp_write(ta.rh[1], o[1]); tp_write(ta.rh[2], o[2]); tp_write(ta.rh[3], o[3]);
       tp_read_o<0>(out.o[hh][i][0], ta.line); tp_read_o<1024>(out.o[hh][i][1], ta.line);
@@ -271,6 +272,11 @@ __device__ __forceinline__ void pp_epi_store(const GemmArgs& p, const PpOut& out
       bf16* c0 = reinterpret_cast<bf16*>(p.C) + (size_t)(mb0 + hh * 64 + i * 32 + lr) * p.ldc + nb + 8 * lc;
 #pragma unroll
       for (int it = 0; it < 4; ++it) *reinterpret_cast<bf16x8*>(c0 + (size_t)(8 * it) * p.ldc) = out.o[hh][i][it];
+      if (EPI == EPI_GELU || EPI == EPI_GELU_D) {          // (the host only selects these kinds with aux_out set)
+        bf16* a0 = reinterpret_cast<bf16*>(p.aux_out) + (size_t)(mb0 + hh * 64 + i * 32 + lr) * p.ldaux + nb + 8 * lc;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) *reinterpret_cast<bf16x8*>(a0 + (size_t)(8 * it) * p.ldaux) = out.pre[hh][i][it];
+      }
     }
 }
 
@@ -367,7 +373,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   auto setup = [&](int it) __attribute__((always_inline)) {
     const int z = it / ntile, tile = it - z * ntile;
     zsplit = z;
-    m0 = (tile / nbx) * RT; n0 = (tile % nbx) * 256;
+    {
+      // Tile order inside a k-split: column tiles in groups of `cg` (p.diag-selectable; default chosen on the host so that
+      // cg <= 6), row panels inside a group, the group's columns fastest.  The 32 workgroups of an XCD work on 32
+      // consecutive items: with all 12 column tiles of an N = 3072 GEMM in one row they covered 2.7 row panels x 12
+      // weight tiles = 5.8 MB of operands, more than the XCD's 4 MiB L2 -- rocprofv3 FETCH_SIZE showed the 4.7 MB
+      // weight re-fetched from beyond L2 for every row panel (2.4 GB per launch against 1.4 GB algorithmic).
+      const int cg = p.col_group, mt = p.M / RT;
+      const int per_group = mt * cg;
+      const int g = tile / per_group, r = tile - g * per_group;
+      const int cw = min(cg, nbx - g * cg);                  // (the last group may be narrower)
+      const int tm = (g * cg + cw <= nbx && cw == cg) ? r / cg : r / cw;
+      const int tc = r - tm * ((cw == cg) ? cg : cw);
+      m0 = tm * RT; n0 = (g * cg + tc) * 256;
+    }
     const int tbeg = z * per;
     nt = min(ktiles, tbeg + per) - tbeg;
     const int kbeg = tbeg * 64;
@@ -587,14 +606,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int it = 0; it < 4; ++it)
-            if (!(hh == 1 && i >= HI)) asm volatile("" : "+v"(out.o[hh][i][it]));
+            if (!(hh == 1 && i >= HI)) {
+              asm volatile("" : "+v"(out.o[hh][i][it]));
+              if (EPI == EPI_GELU || EPI == EPI_GELU_D) asm volatile("" : "+v"(out.pre[hh][i][it]));
+            }
       PP_STAMP(2);
       if (more) { setup(item); PP_PROLOGUE(); }
       PP_STAMP(3);
       asm volatile("" : "+v"(ln));
       pp_epi_store<EPI, HI>(p, out, em0, en0, ln);
       PP_STAMP(4);
-      younger = GKT + NST;                             // (the pre-activation stores of EPI_GELU are older than the DMA)
+      younger = GKT + ((EPI == EPI_GELU || EPI == EPI_GELU_D) ? 2 * NST : NST);     // stores issued after the DMA
     } else {                                           // fp32 output (accumulate / split-K atomics): row segments per register
       bf16_tile_epilogue<false>(p, acc[0], em0, en0, 0, 0, lane, smem);
       bf16_tile_epilogue<false>(p, acc[1], em0 + 64, en0, 0, 0, lane, smem);
@@ -677,7 +699,8 @@ void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t
     else if (trans_a && !trans_b) pp_launch0<true, false, false, EPI_NONE>(p, st);
     else pp_launch0<true, true, false, EPI_NONE>(p, st);
   } else if (!trans_a && !trans_b) {
-    if (p.epi == EPI_GELU && p.aux_deriv) pp_launch0<false, false, true, EPI_GELU_D>(p, st);
+    if (p.epi == EPI_GELU && !p.aux_out) pp_launch0<false, false, true, EPI_GELU_NOAUX>(p, st);
+    else if (p.epi == EPI_GELU && p.aux_deriv) pp_launch0<false, false, true, EPI_GELU_D>(p, st);
     else if (p.epi == EPI_GELU) pp_launch0<false, false, true, EPI_GELU>(p, st);
     else if (p.epi == EPI_ADD) pp_launch0<false, false, true, EPI_ADD>(p, st);
     else if (p.epi == EPI_TANH) pp_launch0<false, false, true, EPI_TANH>(p, st);
