@@ -71,6 +71,21 @@ enum { UC2_GEMM_DEFER_REDUCE = 1, UC2_GEMM_AUX_DERIV = 2 };
 int uc2_gemm_splitk_reduce(int M, int N, void* C, int ldc, int split_k, int accumulate, const void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* ---- fp8 (OCP e4m3) forward / input-gradient GEMMs (BASELINE.json configs[4]; the reference's mixed precision is apex
+ *      amp O2 fp16 -- pretrain.py:463-465 -- so this extends the bf16 mode behind the same layer interfaces) ----------
+ *   per-tensor power-of-two scales, all on the device: amax (zero the 4-byte cell first; several tensors may share it)
+ *   -> scale = 2^floor(log2(448/amax)) -> x8 = sat_e4m3(x * scale) [transpose != 0: out[c][r], the k-contiguous copy of
+ *   W^T for dX = dY W] -> C = epi((A8 . B8^T) / (*scale_a * *scale_b) + bias) in bf16, fp32 accumulation on
+ *   v_mfma_scale_f32_32x32x64_f8f6f4.  A8 [M,K], B8 [N,K], K % 128 == 0, lda/ldb % 16 == 0.  Weight gradients stay
+ *   bf16 (uc2_gemm).  flags: UC2_GEMM_AUX_DERIV as for uc2_gemm. */
+int uc2_fp8_amax(int dtype, size_t n, const void* x, void* amax_bits, void* stream);
+int uc2_fp8_scale(const void* amax_bits, float* scale, void* stream);
+int uc2_fp8_quant(int dtype, int rows, int cols, const void* x, int ldx, const float* scale, void* out, int ldo,
+                  int transpose, void* stream);
+int uc2_gemm_fp8(int M, int N, int K, const void* A8, int lda, const void* B8, int ldb, const float* scale_a,
+                 const float* scale_b, void* C, int ldc, const float* bias, int epilogue, const void* aux_in, void* aux_out,
+                 int ldaux, int flags, void* stream);
+
 /* ---- LayerNorm fused with dropout + residual (apex FusedLayerNorm, model/layer.py:25; the dense->dropout->
  *      LayerNorm(x + residual) tails at model/layer.py:111-115,152-156; embeddings model/model.py:331,358-362) -----
  *   drop_after == 0: y = LN(dropout(x) + residual) * gamma + beta     (encoder tails, model/layer.py:113-114,154-155)

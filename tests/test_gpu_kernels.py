@@ -502,3 +502,34 @@ def test_gemm_pingpong_skew_and_deferred_reduce():
     ops.call("uc2_gemm", 1, 1, 1, Mo, No, Kt, ops.ptr(x), Mo, ops.ptr(y), No, ops.ptr(out), No, 1, None, 0, None, None, 0,
              1, 8, 8, None, 0, 0, ops.stream())
     assert rel_err(out, fused) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ fp8 (configs[4])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (1000, 768, 768), (2080, 3072, 1024), (260, 1024, 4096)])
+@pytest.mark.parametrize("epi", ["none", "gelu", "add"])
+def test_gemm_fp8_vs_dequantised_reference(M, N, K, epi):
+    """e4m3 x e4m3 -> bf16 on v_mfma_scale_f32_32x32x64_f8f6f4: against a float matmul of the DEQUANTISED operands
+    (pins the operand byte layout, the scale handling and the epilogues; only the bf16 output rounding differs)"""
+    x = rnd((M, K), 1, 1.3, dtype=torch.bfloat16)
+    w = rnd((N, K), 2, 0.03, dtype=torch.bfloat16)
+    bias = rnd((N,), 3)
+    x8, sx = ops.fp8_quantize(x)
+    w8, sw = ops.fp8_quantize(w)
+    xq = x8.view(torch.float8_e4m3fn).float() / sx
+    wq = w8.view(torch.float8_e4m3fn).float() / sw
+    assert rel_err(xq, x.float()) < 0.04 and rel_err(wq, w.float()) < 0.04          # 3-bit mantissa
+    assert float(sx) in [2.0 ** k for k in range(-24, 25)]
+    pre = xq @ wq.t() + bias
+    aux = rnd((M, N), 4, dtype=torch.bfloat16)
+    d = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    if epi == "none":
+        out, ref = ops.gemm_fp8(x8, sx, w8, sw, bias=bias), pre
+    elif epi == "gelu":
+        out = ops.gemm_fp8(x8, sx, w8, sw, bias=bias, epi=ops.EPI_GELU, aux_out=d, flags=ops.GEMM_AUX_DERIV)
+        ref = torch.nn.functional.gelu(pre)
+    else:
+        out, ref = ops.gemm_fp8(x8, sx, w8, sw, bias=bias, epi=ops.EPI_ADD, aux_in=aux), pre + aux.float()
+    assert rel_err(out.float(), ref) < 4e-3
+    # transposed quantisation = quantisation of the transpose
+    wt8, swt = ops.fp8_quantize(w, transpose=True)
+    assert torch.equal(wt8, w8.t().contiguous()) and torch.equal(swt, sw)

@@ -399,6 +399,34 @@ def test_large_geometry_vs_golden(dtype):
     torch.cuda.empty_cache()
 
 
+def test_large_geometry_fp8_vs_golden():
+    """BASELINE.json configs[4]: 24L / 1024H, L = 130, fp8 (e4m3) forward and input-gradient GEMMs with bf16 weight
+    gradients, against the reference's fp32 vectors at fp8 resolution (3 mantissa bits per operand, fp32 accumulation):
+    the measured errors are printed; the loss must stay within a few per cent and the ITM labels must not flip"""
+    g = golden("large")
+    model = build_pretrain(O.LARGE, torch.bfloat16)
+    uc2_amd.set_fp8(model, True)
+    for task in ("itm", "mlm"):
+        batch = synth.make_batch(250002, 2, 80, 50, task=task, seed=1)
+        seq, scores, loss = run_task(model, batch, task)
+        key = "large2/%s" % task
+        e1 = check_against_golden(g, key + "/seq", seq, 0.5, metric="l2")     # 96 GEMMs of e4m3 operands deep
+        ref_mean = float(g[key + "/loss/sum3"][0]) / loss.numel()
+        e2 = abs(loss.mean().item() - ref_mean) / abs(ref_mean)
+        agree = float((scores.argmax(-1).cpu().numpy() == g[key + "/argmax"]).mean())
+        P = dict(model.named_parameters())
+        e3 = check_against_golden(g, "%s/grad/roberta.encoder.layer.23.output.dense.weight" % key,
+                                  P["roberta.encoder.layer.23.output.dense.weight"].grad, 0.6, metric="l2")
+        print("large fp8 %s: seq slice L2 rel %.3g, mean-loss rel %.3g, argmax agreement %.3f, last-layer grad L2 rel %.3g" % (task, e1, e2, agree, e3))
+        assert e2 < 3e-2
+        if task == "itm":
+            assert agree == 1.0
+        else:
+            assert agree >= 0.8
+    del model
+    torch.cuda.empty_cache()
+
+
 def test_submodule_forwards_compose_to_the_fused_layer():
     """BertSelfAttention / BertSelfOutput / BertAttention / BertIntermediate / BertOutput have working forward()s
     (model/layer.py:75-156); composed the reference's way they reproduce the fused BertLayerFn node bit for bit in

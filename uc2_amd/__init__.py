@@ -7,6 +7,6 @@ Importing this package never loads the shared library; the first compute call
 does, and raises if it is missing -- there is no CPU fallback.
 """
 from . import store  # noqa: F401
-from .store import mark_all_dirty, set_compute_dtype  # noqa: F401
+from .store import mark_all_dirty, set_compute_dtype, set_fp8  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,0 +1,141 @@
+// fp8 (OCP e4m3) GEMM inputs for the forward and input-gradient GEMMs of the encoder layer (BASELINE.json configs[4]:
+// "fp8 MFMA GEMMs"; the reference has no fp8 path -- apex amp O2 is fp16 -- so this is an extension of the bf16 mode
+// with the same interfaces).  Per-tensor power-of-two scaling:
+//   amax   = max |x|                                   (uc2_fp8_amax, atomic max on the bit pattern)
+//   scale  = 2^floor(log2(448 / amax))  (1 if amax = 0) (uc2_fp8_scale: on the device, no host round trip)
+//   x8     = sat_e4m3(x * scale)                        (uc2_fp8_quant / uc2_fp8_quant_t)
+//   y      = (x8 . w8) / (scale_x * scale_w)            (uc2_gemm_fp8: v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate)
+// Weight gradients stay bf16 (uc2_gemm).
+#include "gemm_common.h"
+#include <hip/hip_fp8.h>
+
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_amax_kernel(size_t n, const T* __restrict__ x, unsigned* __restrict__ amax_bits) {
+  float m = 0.f;
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float v[4];
+    Vec4<T>::load(x + i * 4, v);
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(to_f<T>(x[(n4 << 2) + threadIdx.x])));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));     // non-negative floats order like their bit patterns
+}
+__global__ void fp8_scale_kernel(const unsigned* __restrict__ amax_bits, float* __restrict__ scale) {
+  const float a = __uint_as_float(*amax_bits);
+  float s = 1.0f;
+  if (a > 0.f && a < INFINITY) s = exp2f(floorf(log2f(448.0f / a)));
+  s = fminf(fmaxf(s, 1.0f / 16777216.0f), 16777216.0f);
+  *scale = s;
+}
+__device__ __forceinline__ unsigned pack4_e4m3(const float (&v)[4]) {
+  unsigned r = 0;
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], r, false);      // saturating OCP e4m3 conversion, bytes 0-1
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], r, true);       // bytes 2-3
+  return r;
+}
+// rows x cols (cols % 4 == 0), out[r * ldo + c] = e4m3(x[r * ldx + c] * scale)
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_quant_kernel(int rows, int cols, const T* __restrict__ x, int ldx,
+                                                        const float* __restrict__ scale, uint8_t* __restrict__ out, int ldo) {
+  const float s = *scale;
+  const int c4 = cols >> 2;
+  const size_t total = (size_t)rows * c4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / c4), c = (int)(i - (size_t)r * c4) * 4;
+    float v[4];
+    Vec4<T>::load(x + (size_t)r * ldx + c, v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= s;
+    *reinterpret_cast<unsigned*>(out + (size_t)r * ldo + c) = pack4_e4m3(v);
+  }
+}
+// transposing variant: out[c * ldo + r] = e4m3(x[r * ldx + c] * scale)  (the k-contiguous copy of W^T for the input
+// gradient dX = dY W); 64 x 64 tiles through LDS
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_quant_t_kernel(int rows, int cols, const T* __restrict__ x, int ldx,
+                                                          const float* __restrict__ scale, uint8_t* __restrict__ out, int ldo) {
+  __shared__ float tile[64][65];
+  const float s = *scale;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, t = threadIdx.x;
+  for (int i = t; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < rows && c0 + c < cols) ? to_f<T>(x[(size_t)(r0 + r) * ldx + c0 + c]) * s : 0.f;
+  }
+  __syncthreads();
+  for (int i = t; i < 64 * 16; i += 256) {
+    const int c = i >> 4, r4 = (i & 15) * 4;                     // output row c0 + c, output columns r0 + r4 .. +3
+    if (c0 + c < cols && r0 + r4 < rows) {
+      const float v[4] = {tile[r4][c], tile[r4 + 1][c], tile[r4 + 2][c], tile[r4 + 3][c]};
+      *reinterpret_cast<unsigned*>(out + (size_t)(c0 + c) * ldo + r0 + r4) = pack4_e4m3(v);
+    }
+  }
+}
+
+// amax_bits must be zeroed by the caller (uc2_fp8_amax accumulates a maximum, so several tensors can share one scale)
+extern "C" int uc2_fp8_amax(int dtype, size_t n, const void* x, void* amax_bits, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  if (n == 0) return 0;
+  UC2_CHECK_ARG(x && amax_bits);
+  const size_t blocks = (n / 4 + 255) / 256;
+  const int grid = (int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
+  if (dtype == 0) hipLaunchKernelGGL(fp8_amax_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, (const float*)x, (unsigned*)amax_bits);
+  else hipLaunchKernelGGL(fp8_amax_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, (const bf16*)x, (unsigned*)amax_bits);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int uc2_fp8_scale(const void* amax_bits, float* scale, void* stream) {
+  UC2_CHECK_ARG(amax_bits && scale);
+  hipLaunchKernelGGL(fp8_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const unsigned*)amax_bits, scale);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int uc2_fp8_quant(int dtype, int rows, int cols, const void* x, int ldx, const float* scale, void* out, int ldo,
+                             int transpose, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  if (rows <= 0 || cols <= 0) return 0;
+  UC2_CHECK_ARG(x && scale && out);
+  hipStream_t st = (hipStream_t)stream;
+  if (!transpose) {
+    UC2_CHECK_ARG((cols & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0);
+    const size_t blocks = ((size_t)rows * (cols / 4) + 255) / 256;
+    const int grid = (int)(blocks > 4096 ? 4096 : blocks);
+    if (dtype == 0) hipLaunchKernelGGL(fp8_quant_kernel<float>, dim3(grid), dim3(256), 0, st, rows, cols, (const float*)x, ldx, scale, (uint8_t*)out, ldo);
+    else hipLaunchKernelGGL(fp8_quant_kernel<bf16>, dim3(grid), dim3(256), 0, st, rows, cols, (const bf16*)x, ldx, scale, (uint8_t*)out, ldo);
+  } else {
+    UC2_CHECK_ARG((rows & 3) == 0 && (ldo & 3) == 0);
+    dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+    if (dtype == 0) hipLaunchKernelGGL(fp8_quant_t_kernel<float>, grid, dim3(256), 0, st, rows, cols, (const float*)x, ldx, scale, (uint8_t*)out, ldo);
+    else hipLaunchKernelGGL(fp8_quant_t_kernel<bf16>, grid, dim3(256), 0, st, rows, cols, (const bf16*)x, ldx, scale, (uint8_t*)out, ldo);
+  }
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+int uc2_gemm_fp8_launch(const GemmArgs& p8, hipStream_t st);      // gemm_fast.hip
+extern "C" int uc2_colsum_accum(int dtype, int M, int N, const void* X, int ldx, const uint8_t* rowmask, float* out, void* stream);
+
+// C[M,N] (bf16) = epi( (sum_k A8(m,k) B8(n,k)) / (*scale_a * *scale_b) + bias[n] ); A8 [M,K], B8 [N,K] e4m3, k-contiguous
+extern "C" int uc2_gemm_fp8(int M, int N, int K, const void* A8, int lda, const void* B8, int ldb, const float* scale_a,
+                            const float* scale_b, void* C, int ldc, const float* bias, int epilogue, const void* aux_in,
+                            void* aux_out, int ldaux, int flags, void* stream) {
+  UC2_CHECK_ARG(M >= 0 && N >= 0 && K > 0 && (K % 128) == 0);
+  UC2_CHECK_ARG(epilogue >= EPI_NONE && epilogue <= EPI_TANH);
+  UC2_CHECK_ARG(!((epilogue == EPI_DGELU || epilogue == EPI_ADD) && aux_in == nullptr));
+  if (M == 0 || N == 0) return 0;
+  UC2_CHECK_ARG(A8 && B8 && C && scale_a && scale_b);
+  UC2_CHECK_ARG((lda % 16) == 0 && (ldb % 16) == 0 && (((uintptr_t)A8 | (uintptr_t)B8) & 15) == 0);
+  GemmArgs p{};
+  p.A = A8; p.B = B8; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux ? ldaux : ldc;
+  p.epi = epilogue; p.c_f32 = 0; p.accumulate = 0; p.split_k = 1; p.atomic = 0; p.partial = nullptr;
+  p.a_vec = 1; p.b_vec = 1; p.variant = 1; p.aux_deriv = (flags >> 1) & 1; p.alpha = 1.0f;
+  p.alpha_dev = scale_a; p.alpha_dev2 = scale_b;
+  uc2_gemm_fp8_launch(p, (hipStream_t)stream);
+  UC2_LAUNCH_CHECK();
+  if (epilogue == EPI_DGELU && aux_out != nullptr) {
+    return uc2_colsum_accum(1, M, N, C, ldc, nullptr, reinterpret_cast<float*>(aux_out), stream);
+  }
+  return 0;
+}

@@ -322,7 +322,7 @@ extern "C" int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K
   p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux ? ldaux : ldc;
   p.epi = epilogue; p.c_f32 = (dtype == 0) ? 1 : c_is_f32; p.accumulate = accumulate;
-  p.split_k = split_k; p.atomic = (split_k > 1) ? 1 : 0; p.partial = nullptr;
+  p.split_k = split_k; p.atomic = (split_k > 1) ? 1 : 0; p.partial = nullptr; p.alpha = 1.0f; p.alpha_dev = nullptr; p.alpha_dev2 = nullptr;
   p.variant = variant; p.ws = reinterpret_cast<float*>(workspace); p.ws_bytes = workspace ? workspace_bytes : 0;
   {
     const int nbx = N / 256 > 0 ? N / 256 : 1;

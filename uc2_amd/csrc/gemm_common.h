@@ -20,6 +20,9 @@ struct GemmArgs {
   float* ws; size_t ws_bytes;   // caller-owned split-K workspace for THIS call (or null)
   int defer;             // leave the split-K partials in ws (the caller runs uc2_gemm_splitk_reduce)
   int diag;              // diagnostic launch mode (main loop only / epilogue only / stamps), 0 in production
+  float alpha;           // accumulator scale applied before bias / epilogue (fp8 GEMM: 1 / (scale_a * scale_b)); 1 otherwise
+  const float* alpha_dev; // ... or read from device memory (product of two device-side scales), NULL = use alpha
+  const float* alpha_dev2;
   int col_group;         // ping-pong kernel: column tiles per L2 group of the tile order (host: largest divisor of N/256 that is <= 6)
   int aux_deriv;         // UC2_GEMM_AUX_DERIV: EPI_GELU stores gelu'(pre) (not pre) to aux_out, EPI_DGELU multiplies by aux_in as is
 };
@@ -30,6 +33,7 @@ struct GemmArgs {
 template <typename T>
 __device__ __forceinline__ void epi_store(const GemmArgs& p, int m, int n, float v) {
   if (m >= p.M || n >= p.N) return;
+  v *= p.alpha;
   if (p.bias) v += p.bias[n];
   const size_t ia = (size_t)m * p.ldaux + n;
   if (p.epi == EPI_GELU) {
@@ -109,7 +113,7 @@ __device__ __forceinline__ void bf16_tile_epilogue(const GemmArgs& p, const f32x
         if (vec_ok) {
           float v[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = raw[e] + bv[e];
+          for (int e = 0; e < 8; ++e) v[e] = raw[e] * p.alpha + bv[e];
           const size_t ia = (size_t)m * p.ldaux + n;
           if (p.epi == EPI_GELU) {
             if (p.aux_out) {
@@ -194,7 +198,7 @@ __device__ __forceinline__ void bf16_tile_epilogue_direct(const GemmArgs& p, con
         const int m = mb0 + i * 32 + c31;
         if (m >= p.M || n >= p.N) continue;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bv[e];
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bv[e];
         const size_t ia = (size_t)m * p.ldaux + n;
         if (p.epi == EPI_GELU) {
           if (p.aux_out) {

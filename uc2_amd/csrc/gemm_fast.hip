@@ -21,9 +21,28 @@
 #include "gemm_tile.h"
 
 // (second launch-bound argument = waves per SIMD: rings of <= 80 KiB are meant to run two workgroups per CU)
-template <bool TA, bool TB, bool TACC, int BM, int BK, int NSTAGE>
+// F8 = true: the same ring with OCP fp8 (e4m3) operands, both k-contiguous (TA = TB = false).  A k-tile is still
+// 128 bytes per row (BK = 64 "bf16 columns" = 128 fp8 values), so staging, swizzles and the LDS image are byte for
+// byte those of the bf16 kernel; a k-tile is two steps of v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales: the
+// per-tensor scales are folded into GemmArgs::alpha) instead of four of v_mfma_f32_32x32x16_bf16 -- the same matrix-pipe
+// cycles for twice the contraction length.  A lane's 32 operand bytes of a step are the two 16-byte chunks
+// 4s + 2h, 4s + 2h + 1 of its row for BOTH operands (any assignment of k to operand bytes is valid as long as A and B
+// use the same one; checked on the device against an fp64 reference).
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+template <int BK>
+__device__ __forceinline__ i32x8 gf_frag_f8(const char* lds, int rbase, int s, int lane) {
+  const int row = rbase + (lane & 31), h = lane >> 5, sw = (row >> 1) & 7;
+  const i32x4 lo = *reinterpret_cast<const i32x4*>(lds + row * (BK * 2) + (((4 * s + 2 * h) ^ sw) << 4));
+  const i32x4 hi = *reinterpret_cast<const i32x4*>(lds + row * (BK * 2) + (((4 * s + 2 * h + 1) ^ sw) << 4));
+  return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <bool TA, bool TB, bool TACC, int BM, int BK, int NSTAGE, bool F8 = false>
 __global__ __launch_bounds__(BM * 2)
 void gemm_bf16_fast_kernel(GemmArgs p) {
+  static_assert(!F8 || (!TA && !TB && TACC && BK == 64), "fp8: k-contiguous operands, bf16 output, 128-byte k-tiles");
+  if (F8 && p.alpha_dev) p.alpha = 1.0f / (p.alpha_dev[0] * p.alpha_dev2[0]);
   constexpr int NW = BM / 32;                         // waves: 8 (BM 256) or 4 (BM 128); wave grid (BM/64) x 2
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = GF_BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int A_PW = A_BYTES / 1024 / NW;           // wave-instructions per wave per k-tile
@@ -117,6 +136,33 @@ void gemm_bf16_fast_kernel(GemmArgs p) {
     // CU's address unit accepts one 1-KiB wave-instruction per ~30 cycles, and a wave that issues all its DMA up
     // front sits in the issue queue instead of feeding the MFMA pipe (measured: fetch alone 50 us + MFMA alone
     // 35 us ran as 97 us when issued back to back).
+    if constexpr (F8) {
+      i32x8 a8[2][2], b8[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a8[0][i] = gf_frag_f8<BK>(As, wm * 64 + i * 32, 0, lane);
+        b8[0][i] = gf_frag_f8<BK>(Bs, wn * 64 + i * 32, 0, lane);
+      }
+#define GF8_STEP(S)                                                                                            \
+      {                                                                                                        \
+        constexpr int c = (S) & 1, n = c ^ 1;                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                          \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8[c][j], a8[c][i], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F); \
+        if constexpr ((S) + 1 < 2) {                                                                           \
+          _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+            a8[n][i] = gf_frag_f8<BK>(As, wm * 64 + i * 32, (S) + 1, lane);                                    \
+            b8[n][i] = gf_frag_f8<BK>(Bs, wn * 64 + i * 32, (S) + 1, lane);                                    \
+          }                                                                                                    \
+        }                                                                                                      \
+        _Pragma("unroll") for (int q = 0; q < LPT; ++q)                                                        \
+          if (q % 2 == (S)) GF_ISSUE1(dst, q, adva, advb, backa, backb);                                       \
+      }
+      GF8_STEP(0)
+      GF8_STEP(1)
+#undef GF8_STEP
+      continue;
+    }
     bf16x8 a[2][2], b[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -337,6 +383,21 @@ static void gf_launch2(const GemmArgs& p, int variant, hipStream_t st) {
     case 7: ws_launch1<TA, TB, TACC, 64, 3, 8>(p, st); break;        // wave-specialised: 8 MFMA + 8 loader waves
     default: gf_launch1<TA, TB, TACC, 256, 64, 3>(p, st); break;    // 144 KiB LDS, 1 workgroup / CU
   }
+}
+
+// fp8 (e4m3) x fp8 -> bf16, both operands k-contiguous: the operands are handed to the ring kernel as "bf16" matrices of
+// half the width (same bytes).  M, N arbitrary (row clamping + guarded epilogue), K % 128 == 0.
+int uc2_gemm_fp8_launch(const GemmArgs& p8, hipStream_t st) {
+  GemmArgs p = p8;
+  p.K = p8.K / 2; p.lda = p8.lda / 2; p.ldb = p8.ldb / 2;
+  constexpr int BM = 256, BK = 64, NSTAGE = 3;
+  constexpr int smem = NSTAGE * (BM * BK * 2 + GF_BN * BK * 2);
+  auto kern = gemm_bf16_fast_kernel<false, false, true, BM, BK, NSTAGE, true>;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
+  const int nwg = ((p.N + GF_BN - 1) / GF_BN) * ((p.M + BM - 1) / BM);
+  hipLaunchKernelGGL(kern, dim3(nwg, 1, 1), dim3(BM * 2), smem, st, p);
+  return 0;
 }
 
 // returns 1 if the shape qualifies and the kernel was launched, 0 if the caller must use the generic kernel

@@ -186,7 +186,8 @@ class BertLayer(nn.Module):
         a = self.attention
         cfg = {"nh": a.self.num_attention_heads, "training": self.training,
                "p_hidden": a.output.dropout.p, "p_attn": a.self.dropout.p,
-               "layer_id": self._layer_id, "grad_ready_hook": self.grad_ready_hook}
+               "layer_id": self._layer_id, "grad_ready_hook": self.grad_ready_hook,
+               "fp8": self.__dict__.get("uc2_fp8", False)}
         return ops.BertLayerFn.apply(x, mask2d, self, cfg, *ops.layer_params(self))
 
 

@@ -30,6 +30,8 @@ class GemmTimer:
 
     @staticmethod
     def kernel_name(key):
+        if key[0] == "fp8":
+            return "gemm_bf16_fast_kernel<false, false, true, 256, 64, 3, true> (fp8 e4m3, epilogue %d)" % key[1]
         ta, tb, variant, atomic, epi = key
         b = lambda x: "true" if x else "false"
         tacc = b(not atomic)
@@ -369,6 +371,70 @@ def _gemm_planned(a, b, M, N, K, ta, tb, wgrad=False, **kw):
     return gemm(a, b, M, N, K, ta=ta, tb=tb, split_k=sp, variant=v, flags=flags, **kw)
 
 
+# --------------------------------------------------------------------------------------
+# fp8 (e4m3) inputs for the forward / input-gradient GEMMs (BASELINE.json configs[4]); weight gradients stay bf16
+# --------------------------------------------------------------------------------------
+def fp8_quantize(x2, transpose=False):
+    """per-tensor power-of-two scaling, all on the device: (x8 uint8 [rows, cols] or [cols, rows], scale fp32 [1])"""
+    rows, cols = x2.shape
+    amax = torch.zeros(1, dtype=torch.int32, device=x2.device)
+    scale = torch.empty(1, dtype=torch.float32, device=x2.device)
+    assert x2.is_contiguous()
+    call("uc2_fp8_amax", dt(x2.dtype), x2.numel(), ptr(x2), ptr(amax), stream())
+    call("uc2_fp8_scale", ptr(amax), ptr(scale), stream())
+    out = torch.empty((cols, rows) if transpose else (rows, cols), dtype=torch.uint8, device=x2.device)
+    call("uc2_fp8_quant", dt(x2.dtype), rows, cols, ptr(x2), x2.stride(0), ptr(scale), ptr(out), out.stride(0), int(transpose), stream())
+    return out, scale
+
+
+def gemm_fp8(a8, sa, b8, sb, bias=None, epi=EPI_NONE, aux_in=None, aux_out=None, flags=0):
+    """bf16 C[M,N] = epi((A8 . B8^T) / (sa * sb) + bias); A8 [M,K], B8 [N,K] e4m3 bytes, K % 128 == 0"""
+    M, K = a8.shape
+    N = b8.shape[0]
+    assert b8.shape[1] == K
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=a8.device)
+    ldaux = 0
+    for x in (aux_in, aux_out):
+        if x is not None and x.dim() == 2:
+            ldaux = x.stride(0)
+    timer = GEMM_TIMER
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("uc2_gemm_fp8", M, N, K, ptr(a8), a8.stride(0), ptr(b8), b8.stride(0), ptr(sa), ptr(sb), ptr(out), out.stride(0),
+         ptr(bias), epi, ptr(aux_in), ptr(aux_out), ldaux, flags, stream())
+    if timer is not None:
+        e1.record()
+        timer.add(("fp8", int(epi)), 2.0 * M * N * K, e0, e1)
+    return out
+
+
+def _fp8_weight(st, p_first, p_last, shape, transpose):
+    """e4m3 copy (+ scale) of a weight span, re-quantised when the parameters change (AdamW step, load_state_dict)"""
+    cache = st.__dict__.setdefault("_fp8_cache", {})
+    key = (st.offsets[id(p_first)], st.offsets[id(p_last)], bool(transpose))
+    hit = cache.get(key)
+    if hit is not None and hit[2] == st.version:
+        return hit[0], hit[1]
+    w = st.span(st.data, p_first, p_last, shape)
+    w8, sc = fp8_quantize(w, transpose)
+    cache[key] = (w8, sc, st.version)
+    return w8, sc
+
+
+def linear_fwd_fp8(x2, st, p_first, p_last, shape, bias, epi=EPI_NONE, aux_out=None, flags=0):
+    w8, sw = _fp8_weight(st, p_first, p_last, shape, False)
+    x8, sx = fp8_quantize(x2)
+    return gemm_fp8(x8, sx, w8, sw, bias=bias, epi=epi, aux_out=aux_out, flags=flags)
+
+
+def linear_dgrad_fp8(dy2, st, p_first, p_last, shape, epi=EPI_NONE, aux_in=None, colsum_out=None, flags=0):
+    """dX = epi(dY W): the k-contiguous operand is the transposed e4m3 copy of W ([in, out])"""
+    wt8, sw = _fp8_weight(st, p_first, p_last, shape, True)
+    d8, sd = fp8_quantize(dy2)
+    return gemm_fp8(d8, sd, wt8, sw, epi=epi, aux_in=aux_in, aux_out=colsum_out, flags=flags)
+
+
 def linear_fwd(x2, w, bias, epi=EPI_NONE, aux_out=None, flags=0):
     M, K = x2.shape
     N = w.shape[0]
@@ -574,20 +640,31 @@ class BertLayerFn(torch.autograd.Function):
             del u
             y, _, _ = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, sid + 3, want_stats=False)
             return y.view(B, L, H)
-        qkv = linear_fwd(x2, wqkv, bqkv)
-        ctxv, lse = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, sid + 1)
-        o1 = linear_fwd(ctxv, st.compute(P["ow"], dtype), P["ob"].data)
-        a, mean1, rstd1 = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, sid + 2)
-        # `pre` holds gelu'(a W1^T + b1), not the pre-activation itself (UC2_GEMM_AUX_DERIV): one more exp2 beside
-        # the forward's Phi(x) there, and the backward's dGELU epilogue becomes a plain multiply
-        pre = torch.empty((M, P["iw"].shape[0]), dtype=dtype, device=x.device)
-        u = linear_fwd(a, st.compute(P["iw"], dtype), P["ib"].data, EPI_GELU, pre, flags=GEMM_AUX_DERIV)
-        o2 = linear_fwd(u, st.compute(P["fw"], dtype), P["fb"].data)
+        fp8 = bool(cfg.get("fp8")) and dtype == torch.bfloat16 and H % 128 == 0 and P["iw"].shape[0] % 128 == 0
+        I_ = P["iw"].shape[0]
+        pre = torch.empty((M, I_), dtype=dtype, device=x.device)
+        if fp8:
+            # e4m3 operands for the four forward GEMMs (per-tensor scales computed on the device), bf16 outputs
+            qkv = linear_fwd_fp8(x2, st, P["qw"], P["vw"], (3 * H, H), bqkv)
+            ctxv, lse = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, sid + 1)
+            o1 = linear_fwd_fp8(ctxv, st, P["ow"], P["ow"], (H, H), P["ob"].data)
+            a, mean1, rstd1 = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, sid + 2)
+            u = linear_fwd_fp8(a, st, P["iw"], P["iw"], (I_, H), P["ib"].data, EPI_GELU, pre, flags=GEMM_AUX_DERIV)
+            o2 = linear_fwd_fp8(u, st, P["fw"], P["fw"], (H, I_), P["fb"].data)
+        else:
+            qkv = linear_fwd(x2, wqkv, bqkv)
+            ctxv, lse = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, sid + 1)
+            o1 = linear_fwd(ctxv, st.compute(P["ow"], dtype), P["ob"].data)
+            a, mean1, rstd1 = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, sid + 2)
+            # `pre` holds gelu'(a W1^T + b1), not the pre-activation itself (UC2_GEMM_AUX_DERIV): one more exp2 beside
+            # the forward's Phi(x) there, and the backward's dGELU epilogue becomes a plain multiply
+            u = linear_fwd(a, st.compute(P["iw"], dtype), P["ib"].data, EPI_GELU, pre, flags=GEMM_AUX_DERIV)
+            o2 = linear_fwd(u, st.compute(P["fw"], dtype), P["fb"].data)
         y, mean2, rstd2 = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, sid + 3)
 
         ctx.save_for_backward(x2, mask2d, qkv, ctxv, lse, o1, mean1, rstd1, a, pre, u, o2, mean2, rstd2, seed)
         ctx.layer, ctx.cfg, ctx.shape, ctx.p = layer, cfg, (B, L, H, nh, D), (p_h, p_a, sid)
-        ctx.params = params
+        ctx.params, ctx.fp8 = params, fp8
         return y.view(B, L, H)
 
     @staticmethod
@@ -607,16 +684,24 @@ class BertLayerFn(torch.autograd.Function):
         # LN2 and FFN
         d_o2, dz2 = ln_bwd(dy2, o2, a, P["g2"].data, mean2, rstd2, G(P["g2"]), G(P["b2"]), p_h, seed, sid + 3,
                            dbias=G(P["fb"]))
+        fp8 = ctx.fp8
+        I_ = P["iw"].shape[0]
         linear_wgrad(d_o2, u, G(P["fw"]), None)
-        d_pre = linear_dgrad(d_o2, st.compute(P["fw"], dtype), EPI_DGELU, pre, colsum_out=G(P["ib"]),
-                             flags=GEMM_AUX_DERIV)                                             # + d(intermediate bias)
+        if fp8:
+            d_pre = linear_dgrad_fp8(d_o2, st, P["fw"], P["fw"], (H, I_), EPI_DGELU, pre, colsum_out=G(P["ib"]), flags=GEMM_AUX_DERIV)
+        else:
+            d_pre = linear_dgrad(d_o2, st.compute(P["fw"], dtype), EPI_DGELU, pre, colsum_out=G(P["ib"]),
+                                 flags=GEMM_AUX_DERIV)                                         # + d(intermediate bias)
         linear_wgrad(d_pre, a, G(P["iw"]), None)
-        da = linear_dgrad(d_pre, st.compute(P["iw"], dtype), EPI_ADD, dz2)
+        if fp8:
+            da = linear_dgrad_fp8(d_pre, st, P["iw"], P["iw"], (I_, H), EPI_ADD, dz2)
+        else:
+            da = linear_dgrad(d_pre, st.compute(P["iw"], dtype), EPI_ADD, dz2)
         # LN1, output projection, attention, fused QKV
         d_o1, dz1 = ln_bwd(da, o1, x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, sid + 2,
                            dbias=G(P["ob"]))
         linear_wgrad(d_o1, ctxv, G(P["ow"]), None)
-        dctx = linear_dgrad(d_o1, st.compute(P["ow"], dtype))
+        dctx = linear_dgrad_fp8(d_o1, st, P["ow"], P["ow"], (H, H)) if fp8 else linear_dgrad(d_o1, st.compute(P["ow"], dtype))
         dwqkv = st.grad_span(P["qw"], P["vw"], (3 * H, H))
         dbqkv = st.grad_span(P["qb"], P["vb"], (3 * H,))
         # (attn_bwd can also produce d(q|k|v bias) itself, dbias=dbqkv, but its 2304 atomic targets are shared by every
@@ -625,7 +710,10 @@ class BertLayerFn(torch.autograd.Function):
         linear_wgrad(dqkv, x2, dwqkv, dbqkv)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = linear_dgrad(dqkv, st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype), EPI_ADD, dz1).view(B, L, H)
+            if fp8:
+                dx = linear_dgrad_fp8(dqkv, st, P["qw"], P["vw"], (3 * H, H), EPI_ADD, dz1).view(B, L, H)
+            else:
+                dx = linear_dgrad(dqkv, st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype), EPI_ADD, dz1).view(B, L, H)
         hook = ctx.cfg.get("grad_ready_hook")
         if hook is not None:
             join_side_streams()                  # this layer's weight gradients must be complete before its all-reduce

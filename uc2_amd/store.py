@@ -225,3 +225,12 @@ def set_compute_dtype(module, dtype):
 
 def compute_dtype_of(module):
     return module.__dict__.get("compute_dtype", torch.float32)
+
+
+def set_fp8(module, on=True):
+    """fp8 (e4m3) operands for the forward and input-gradient GEMMs of every BertLayer under `module` (bf16 compute
+    dtype required; weight gradients, attention, LayerNorm and the heads stay bf16 / fp32): BASELINE.json configs[4]"""
+    for m in module.modules():
+        if m.__class__.__name__ == "BertLayer":
+            m.__dict__["uc2_fp8"] = bool(on)
+    return module
