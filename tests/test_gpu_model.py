@@ -345,8 +345,8 @@ def test_bf16_base_12_layers_vs_golden():
         batch = synth.make_batch(250002, 4, 60, 36, task=task, seed=1)
         seq, scores, loss = run_task(model, batch, task)
         key = "base4/%s" % task
-        report[task + " seq slice rel (max)"] = check_against_golden(g, key + "/seq", seq, 8e-2)
-        report[task + " loss slice rel (max)"] = check_against_golden(g, key + "/loss", loss, 5e-2)
+        report[task + " seq slice rel (max)"] = check_against_golden(g, key + "/seq", seq, 4e-2)        # measured 1.8e-2 / 2.1e-2
+        report[task + " loss slice rel (max)"] = check_against_golden(g, key + "/loss", loss, 1e-2)     # measured 3.7e-3 / 1.0e-3
         ref_mean = float(g[key + "/loss/sum3"][0]) / loss.numel()
         report[task + " mean-loss rel"] = abs(loss.mean().item() - ref_mean) / abs(ref_mean)
         assert report[task + " mean-loss rel"] < 5e-3
@@ -361,7 +361,7 @@ def test_bf16_base_12_layers_vs_golden():
         for name in ("roberta.encoder.layer.0.attention.self.query.weight", "roberta.encoder.layer.11.output.dense.weight",
                      "roberta.img_embeddings.img_linear.weight", "roberta.embeddings.LayerNorm.weight"):
             report["%s grad L2 rel %s" % (task, name.split("roberta.")[1])] = check_against_golden(
-                g, "%s/grad/%s" % (key, name), P[name].grad, 0.12 if task == "mlm" else 0.35, metric="l2")
+                g, "%s/grad/%s" % (key, name), P[name].grad, 0.03 if task == "mlm" else 0.07, metric="l2")   # measured 1.3e-2 / 3.4e-2
     for k, v in report.items():
         print("bf16-12L %-70s %.4g" % (k, v))
     del model
