@@ -144,6 +144,18 @@ int uc2_gather_rows_fwd(int dtype, int B, int S, int L, int H, const void* src, 
 int uc2_gather_rows_bwd(int dtype, int B, int S, int L, int H, const void* dout, const int64_t* index, void* dsrc,
                         void* stream);
 
+/* ---- batch assembly on the device (collates data/itm.py:205-232, data/mrm.py:73-119, data/mlm.py:761-801; helpers
+ *      data/data.py:360-384 pad_tensors / get_gather_index, data/mrm.py:36-39 _mask_img_feat; loader data/loader.py:85-140):
+ *      flat ragged buffers (already on the device) -> the padded batch tensors.  row_off / txt_off: [B+1] prefix sums
+ *      of num_bb / txt_len; mask_flat: one byte per region (masked regions are zero-filled) or NULL;
+ *      outputs img_masks [B,maxR], img_mask_tgt [B,Lout], txt_labels [B,maxT] (-1 padded) are optional (NULL). */
+int uc2_collate_regions(int out_dtype, int B, int maxR, int D, const float* flat, const int64_t* row_off,
+                        const uint8_t* mask_flat, void* out, void* stream);
+int uc2_collate_index(int B, int maxT, int maxR, int Lout, const int64_t* ids_flat, const int64_t* txt_off,
+                      const int64_t* row_off, int64_t pad_id, const uint8_t* mask_flat, const int64_t* labels_flat,
+                      int64_t* input_ids, int64_t* attn_masks, int64_t* gather_index, uint8_t* img_masks,
+                      uint8_t* img_mask_tgt, int64_t* txt_labels, void* stream);
+
 /* ---- heads and losses (model/model.py:583-596, 653-657, 668-688, 697-732, 738-775; model/itm.py:45-53) ----- */
 /* scatter 0: dst[i] = src[rows[i]] (gather); 1: dst[rows[i]] = src[i]; 2: dst[rows[i]] += src[i] (rows unique) */
 int uc2_select_rows(int dtype, int n, int H, const void* src, int ld_src, const int64_t* rows, void* dst, int ld_dst,

@@ -434,8 +434,26 @@ def case_retrieval(mi, out):
     print("  retrieval:", {k: round(v, 4) for k, v in log.items()})
 
 
+def case_collate(out):
+    """the reference's own collate functions (data/itm.py:205-232, data/mrm.py:73-119,253-288) on ragged synthetic
+    samples: pins the device-side batch assembly of uc2_amd/data/loader.py"""
+    sys.modules["cytoolz"].partition_all = lambda n, seq: [seq[i:i + n] for i in range(0, len(seq), n)]
+    sys.modules["cytoolz"].curry = lambda f: f
+    sys.modules["toolz"].curry = lambda f: f
+    d = types.ModuleType("data")
+    d.__path__ = [REF + "/data"]
+    sys.modules["data"] = d
+    di = importlib.import_module("data.itm")
+    dm = importlib.import_module("data.mrm")
+    for task, fn in (("itm", di.xlmr_itm_collate), ("mrfr", dm.xlmr_mrfr_collate), ("mrc", dm.xlmr_mrc_collate)):
+        b = fn(synth.sample_tuples(task, 6))
+        for k, v in b.items():
+            out["collate/%s/%s" % (task, k)] = v.numpy()
+        print("  collate", task, {k: tuple(v.shape) for k, v in b.items()})
+
+
 def main():
-    which = sys.argv[1:] or ["tiny", "gather", "adamw", "mha", "base", "more", "large", "retrieval"]
+    which = sys.argv[1:] or ["tiny", "gather", "adamw", "mha", "base", "more", "large", "retrieval", "collate"]
     install_shims()
     sys.path.insert(0, REF)
     mm = importlib.import_module("model.model")
@@ -461,6 +479,8 @@ def main():
             case_more(mm, out)
         elif w == "retrieval":
             case_retrieval(mi, out)
+        elif w == "collate":
+            case_collate(out)
         else:
             raise SystemExit("unknown case " + w)
         path = os.path.join(HERE, "golden_%s.npz" % w)

@@ -730,3 +730,43 @@ def test_multihead_attention_cross_and_attn_mask_vs_golden():
         check_against_golden(g, "mha_cross/" + key, t.grad, 3e-3)
     for n, p in m.named_parameters():
         check_against_golden(g, "mha_cross/grad/" + n, p.grad, 3e-3)
+
+
+@pytest.mark.parametrize("task", ["itm", "mrfr", "mrc"])
+def test_device_collate_vs_reference_collates(task):
+    """f1: flat pinned buffers -> two kernels -> the padded batch, against the reference's own xlmr_*_collate outputs
+    (tests/golden/golden_collate.npz), value for value; then through the prefetcher (side stream) and in bf16"""
+    from uc2_amd.data.loader import DevicePrefetcher, assemble, ragged_collate
+    g = golden("collate")
+    samples = synth.sample_tuples(task, 6)
+    rb = ragged_collate(task)(samples)
+    b = assemble(rb, torch.device(DEV))
+    torch.cuda.synchronize()
+    keys = [k[len("collate/%s/" % task):] for k in g.files if k.startswith("collate/%s/" % task)]
+    assert set(keys) == set(b.keys()), (sorted(keys), sorted(b.keys()))
+    for k in keys:
+        ref = torch.from_numpy(g["collate/%s/%s" % (task, k)])
+        got = b[k].cpu()
+        assert tuple(got.shape) == tuple(ref.shape), (k, got.shape, ref.shape)
+        assert torch.equal(got.to(ref.dtype) if got.dtype != ref.dtype else got, ref), k
+    pf = DevicePrefetcher([ragged_collate(task)(samples), ragged_collate(task)(samples)], DEV, feat_dtype=torch.bfloat16)
+    outs = list(pf)
+    assert len(outs) == 2 and outs[0]["img_feat"].dtype == torch.bfloat16
+    assert torch.equal(outs[1]["img_feat"].float().cpu(), torch.from_numpy(g["collate/%s/img_feat" % task]).to(torch.bfloat16).float())
+    assert torch.equal(outs[0]["gather_index"], b["gather_index"])
+
+
+def test_device_collate_mlm_feeds_the_model():
+    """the MLM collate (data/mlm.py:761-801 is not importable offline: tokenizer download at import) against the same
+    layout built on the host, then straight into the model"""
+    from uc2_amd.data.loader import assemble, ragged_collate
+    samples = synth.sample_tuples("mlm", 5, T=32, R=36, vocab_size=1000, img_dim=2048)
+    b = assemble(ragged_collate("mlm")(samples), torch.device(DEV))
+    tls = [s[0].numel() for s in samples]
+    nbs = [s[1].shape[0] for s in samples]
+    assert torch.equal(b["gather_index"].cpu(), O.get_gather_index(tls, nbs, 5, max(tls), max(a + c for a, c in zip(tls, nbs))))
+    lab = torch.nn.utils.rnn.pad_sequence([s[4] for s in samples], batch_first=True, padding_value=-1)
+    assert torch.equal(b["txt_labels"].cpu(), lab)
+    model = build_pretrain(O.TINY, torch.float32)
+    loss = model(b, "mlm", compute_loss=True)
+    assert loss.numel() == int((lab != -1).sum()) and torch.isfinite(loss).all()

@@ -292,3 +292,35 @@ def retrieval_batch(pool, i, j0, j1):
         attn[r, :tl + nb] = 1
     return OrderedDict(input_ids=ids, position_ids=torch.arange(0, tl, dtype=torch.long).unsqueeze(0), img_feat=feat,
                        img_pos_feat=pos, attn_masks=attn, gather_index=_gather_index([tl] * n, nbs, n, tl, out_size))
+
+
+def sample_tuples(task, B, T=12, R=9, vocab_size=1000, img_dim=64, img_label_dim=16, seed=5):
+    """per-sample tuples shaped like the reference datasets' __getitem__ output (ragged: text length in [T/2, T],
+    regions in [R/2, R]), for the collate tests (data/itm.py:186-202, data/mrm.py:54-71,233-250, data/mlm.py:375-394)"""
+    s = seed * 7919
+    tls = det_randint((B,), s + 1, max(3, T // 2), T + 1).tolist()
+    nbs = det_randint((B,), s + 2, max(2, R // 2), R + 1).tolist()
+    out = []
+    for i, (tl, nb) in enumerate(zip(tls, nbs)):
+        ids = det_randint((tl,), s + 10 + i, 5, vocab_size)
+        ids[0], ids[-1] = 0, 2
+        feat = det_normal((nb, img_dim), s + 100 + i)
+        pos = det_uniform((nb, 7), s + 200 + i, 0.0, 1.0)
+        attn = torch.ones(tl + nb, dtype=torch.long)
+        if task == "itm":
+            out.append((ids, feat, pos, attn, torch.tensor([i % 2], dtype=torch.long)))
+        elif task == "mlm":
+            lab = torch.full((tl,), -1, dtype=torch.long)
+            lab[1 + i % max(1, tl - 2)] = ids[1 + i % max(1, tl - 2)]
+            out.append((ids, feat, pos, attn, lab))
+        else:
+            m = det_bernoulli((nb,), s + 300 + i, 0.3)
+            if not m.any():
+                m[i % nb] = True
+            tgt = torch.cat([torch.zeros(tl, dtype=torch.bool), m])
+            if task == "mrfr":
+                out.append((ids, feat, pos, attn, m, tgt))
+            else:
+                soft = det_uniform((nb, img_label_dim), s + 400 + i, 0.0, 1.0)
+                out.append((ids, feat, pos, soft / soft.sum(-1, keepdim=True), attn, m, tgt))
+    return out
