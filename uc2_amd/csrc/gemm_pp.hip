@@ -367,12 +367,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   fa1[1] = lds0 + pp_frag_off<TA>(wr * 32 * HI + 32, lane);
   fb = lds0 + pp_frag_off<TB>(wc * 32, lane);
 
-  int m0, n0, nt, zsplit;
+  int m0, n0, nt, zsplit;       // the item being computed
+  int m0x, n0x, ntx, zx;        // the item being staged: the same one, until the tail of its main loop starts fetching the next
   unsigned src[4][2];           // staging sources as 32-bit byte offsets from A / B (SGPR base + VGPR offset addressing:
                                 // half the registers of 64-bit pointers); unit type J (0 A0, 1 B0, 2 B1, 3 A1), wave-instructions w, w + 8
   auto setup = [&](int it) __attribute__((always_inline)) {
     const int z = it / ntile, tile = it - z * ntile;
-    zsplit = z;
+    zx = z;
     {
       // Tile order inside a k-split: column tiles in groups of `cg` (p.diag-selectable; default chosen on the host so that
       // cg <= 6), row panels inside a group, the group's columns fastest.  The 32 workgroups of an XCD work on 32
@@ -385,19 +386,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
       const int cw = min(cg, nbx - g * cg);                  // (the last group may be narrower)
       const int tm = (g * cg + cw <= nbx && cw == cg) ? r / cg : r / cw;
       const int tc = r - tm * ((cw == cg) ? cg : cw);
-      m0 = tm * RT; n0 = (g * cg + tc) * 256;
+      m0x = tm * RT; n0x = (g * cg + tc) * 256;
     }
     const int tbeg = z * per;
-    nt = min(ktiles, tbeg + per) - tbeg;
+    ntx = min(ktiles, tbeg + per) - tbeg;
     const int kbeg = tbeg * 64;
     int ln = lane;                                     // opaque copy: keeps the per-lane address arithmetic from being
     asm volatile("" : "+v"(ln));                       // hoisted out of the item loop (it would live, and spill, across the main loop)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      src[0][q] = (unsigned)((const char*)pp_src<TA, 0, HI>(A, p.lda, p.M, m0, kbeg, w + 8 * q, ln) - (const char*)A);
-      src[1][q] = (unsigned)((const char*)pp_src<TB, 1, HI>(B, p.ldb, p.N, n0, kbeg, w + 8 * q, ln) - (const char*)B);
-      src[2][q] = (unsigned)((const char*)pp_src<TB, 2, HI>(B, p.ldb, p.N, n0, kbeg, w + 8 * q, ln) - (const char*)B);
-      src[3][q] = (unsigned)((const char*)pp_src<TA, 3, HI>(A, p.lda, p.M, m0, kbeg, w + 8 * q, ln) - (const char*)A);
+      src[0][q] = (unsigned)((const char*)pp_src<TA, 0, HI>(A, p.lda, p.M, m0x, kbeg, w + 8 * q, ln) - (const char*)A);
+      src[1][q] = (unsigned)((const char*)pp_src<TB, 1, HI>(B, p.ldb, p.N, n0x, kbeg, w + 8 * q, ln) - (const char*)B);
+      src[2][q] = (unsigned)((const char*)pp_src<TB, 2, HI>(B, p.ldb, p.N, n0x, kbeg, w + 8 * q, ln) - (const char*)B);
+      src[3][q] = (unsigned)((const char*)pp_src<TA, 3, HI>(A, p.lda, p.M, m0x, kbeg, w + 8 * q, ln) - (const char*)A);
     }
   };
 
@@ -464,6 +465,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   } while (0)
 
+  bool more = false;                                   // another item follows the current one
   auto body = [&](auto tail_c, auto swap_c, int kt) __attribute__((always_inline)) {
     constexpr bool TAIL = decltype(tail_c)::value;
     constexpr bool SW = decltype(swap_c)::value;       // k-tile parity: B0 lives in by, B1 in bx
@@ -481,26 +483,31 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     // consumes exactly the unit the previous phase's wait retired.
     // ---- phase 0
     PP_READ_A(cb + 0 * PP_UNIT);
-    if (!TAIL || f0 + 6 < nunits) PP_ISSUE(2, nb);
-    PP_SYNC_L(TAIL ? nunits - 3 - f0 : 4, 0);
+    if (!TAIL || f0 + 6 < nunits || more) PP_ISSUE(2, nb);
+    PP_SYNC_L((TAIL && !more) ? nunits - 3 - f0 : 4, 0);
     PP_MFMA(0, 0, b0);
     PP_SYNC_C();
     // ---- phase 1
     PP_READ_B(b1, cb + 2 * PP_UNIT);
-    if (!TAIL || f0 + 7 < nunits) PP_ISSUE(3, nb);
-    PP_SYNC_L(TAIL ? nunits - 4 - f0 : 4, 1);
+    if (!TAIL || f0 + 7 < nunits || more) PP_ISSUE(3, nb);
+    PP_SYNC_L((TAIL && !more) ? nunits - 4 - f0 : 4, 1);
     PP_MFMA(0, 1, b1);
     PP_SYNC_C();
     // ---- phase 2
+    // The stream does not drain at the end of an item: the last six phases (from here on in the first of the two tail
+    // k-tiles; every unit of the current item has been issued) fetch the NEXT item's first six units, in the order and
+    // into the ring positions a prologue would use (nt is even).  The next item then starts with its operands in LDS
+    // instead of issuing 96 KiB of LDS-DMA and waiting for it with the matrix pipe idle.
+    if (TAIL && !SW && more) setup(item + item_step);
     PP_READ_A1(cb + 3 * PP_UNIT);
-    if (!TAIL || f0 + 8 < nunits) PP_ISSUE(1, nb ^ 1);
-    PP_SYNC_L(TAIL ? nunits - 5 - f0 : 4, 2);
+    if (!TAIL || f0 + 8 < nunits || more) PP_ISSUE(1, nb ^ 1);
+    PP_SYNC_L((TAIL && !more) ? nunits - 5 - f0 : 4, 2);
     PP_MFMA(1, 1, b1);
     PP_SYNC_C();
     // ---- phase 3
     if (!TAIL || kt + 1 < nt) PP_READ_B(b1, (cb ^ 65536u) + 1 * PP_UNIT);
-    if (!TAIL || f0 + 9 < nunits) PP_ISSUE(0, nb ^ 1);
-    PP_SYNC_L(TAIL ? nunits - 6 - f0 : 4, 3);
+    if (!TAIL || f0 + 9 < nunits || more) PP_ISSUE(0, nb ^ 1);
+    PP_SYNC_L((TAIL && !more) ? nunits - 6 - f0 : 4, 3);
     PP_MFMA(1, 0, b0);
     if (TAIL && kt == nt - 1) {                        // wave row 1 has no partner barrier left after its last C section
       __builtin_amdgcn_s_setprio(0);
@@ -518,51 +525,66 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   int nitem_done = 0;
 #define PP_STAMP(I) do { if (dbg && nitem_done == 2) { unsigned long long t64_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t64_) :: "memory"); ts[I] = (unsigned)t64_; } } while (0)
   setup(item);
+  m0 = m0x; n0 = n0x; nt = ntx; zsplit = zx;
   PP_PROLOGUE();
   int younger = GKT;                                   // VMEM operations issued after the first two units of the current item
   for (;;) {
+    // Accumulators start at the bias (scalar loads: uniform address in constant space, lgkmcnt, no vector registers).
+    // Register 8g+4cc+e of block j is column 32j+16g+8cc+4h+e.  128 VALU writes per wave: wave row 0 does them BEFORE the
+    // item barrier (it finishes its epilogue about a thousand cycles ahead of wave row 1 and would only wait there), wave
+    // row 1 after its second barrier, beside wave row 0's first C section.
+    auto init_acc = [&]() __attribute__((always_inline)) {
+      if (TACC && p.bias) {
+        typedef __attribute__((ext_vector_type(16))) float f32x16c;
+        typedef const __attribute__((address_space(4))) f32x16c* cvec_p;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const f32x16c bvv = *(cvec_p)(uintptr_t)(p.bias + n0 + wc * 64 + 32 * j + 16 * g);
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float lo = bvv[8 * cc + e], hi = bvv[8 * cc + 4 + e];
+                const float b = (lane >> 5) ? hi : lo;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                  for (int i = 0; i < 2; ++i) acc[hh][i][j][8 * g + 4 * cc + e] = b;
+              }
+          }
+      } else {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[hh][i][j][r] = 0.f;
+      }
+    };
     // units 0 and 1 of this item: this wave's part has landed, then publish
-    if (younger == GKT) { if (HI == 2) wait_vmcnt<8>(); else wait_vmcnt<7>(); }
-    else if (younger == GKT + NST) { if (HI == 2) wait_vmcnt<24>(); else wait_vmcnt<19>(); }
-    else if (younger == GKT + 2 * NST) { if (HI == 2) wait_vmcnt<40>(); else wait_vmcnt<31>(); }
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();         // wave row 1 runs one barrier interval behind
-    __builtin_amdgcn_sched_barrier(0);
-    // accumulators start at the bias (scalar loads: uniform address in constant space, lgkmcnt, no vector registers;
-    // this sits in the shadow of the staging wait above).  Register 8g+4cc+e of block j is column 32j+16g+8cc+4h+e.
-    if (TACC && p.bias) {
-      typedef __attribute__((ext_vector_type(16))) float f32x16c;
-      typedef const __attribute__((address_space(4))) f32x16c* cvec_p;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const f32x16c bvv = *(cvec_p)(uintptr_t)(p.bias + n0 + wc * 64 + 32 * j + 16 * g);
-#pragma unroll
-          for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float lo = bvv[8 * cc + e], hi = bvv[8 * cc + 4 + e];
-              const float b = (lane >> 5) ? hi : lo;
-#pragma unroll
-              for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[hh][i][j][8 * g + 4 * cc + e] = b;
-            }
-        }
-    } else {
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[hh][i][j][r] = 0.f;
+    auto item_barrier = [&]() __attribute__((always_inline)) {
+      if (younger == GKT) { if (HI == 2) wait_vmcnt<8>(); else wait_vmcnt<7>(); }
+      else if (younger == GKT + NST) { if (HI == 2) wait_vmcnt<24>(); else wait_vmcnt<19>(); }
+      else if (younger == GKT + 2 * NST) { if (HI == 2) wait_vmcnt<40>(); else wait_vmcnt<31>(); }
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+    };
+    if (wr == 1) {                                     // wave row 1 runs one barrier interval behind
+      item_barrier();
+      __builtin_amdgcn_s_barrier();
     }
+    __builtin_amdgcn_sched_barrier(0);
+    init_acc();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wr == 0) item_barrier();
+    __builtin_amdgcn_sched_barrier(0);
     PP_STAMP(0);
     if (dbg && nitem_done == 3) { unsigned long long t64_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t64_) :: "memory"); ts[6] = (unsigned)t64_; }
+    more = item + item_step < item_end;
     if (!(p.atomic & 0x4000)) {                        // (diagnostic 0x4000: epilogue only)
       using F = std::false_type; using T = std::true_type;
       PP_READ_B(bx, 1 * PP_UNIT);                      // B0 of k-tile 0 (later k-tiles get theirs one phase ahead)
@@ -570,19 +592,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
       for (; kt + 2 < nt; kt += 2) { body(F{}, F{}, kt); body(F{}, T{}, kt + 1); }     // nt is even (host-checked)
       body(T{}, F{}, kt);
       body(T{}, T{}, kt + 1);
+    } else if (more) {
+      setup(item + item_step);
+      PP_PROLOGUE();
     }
-    // The ring is free: no wave reads it after its last L section (wave row 1 is at most in its last C section),
-    // and every LDS-DMA of this item has been waited for.  Start the next item before storing this one.
+    // The next item's first six units are in flight or landed (issued by the tail above); the epilogue below touches
+    // only the transposition buffers behind the ring.
     PP_STAMP(1);
     const int em0 = m0 + wr * RW, en0 = n0 + wc * 64, ez = zsplit;
     item += item_step;
-    const bool more = item < item_end;
+    if (more) { m0 = m0x; n0 = n0x; nt = ntx; zsplit = zx; }
     const bool store = !(p.atomic & 0x800);            // (diagnostic 0x800: main loop only)
     if (!store) {
-      if (more) { setup(item); PP_PROLOGUE(); }
       younger = GKT;
     } else if (TACC && p.partial) {                     // split-K item of a two-stage reduction (fp32 partial, plain stores)
-      if (more) { setup(item); PP_PROLOGUE(); }
       {
         int ln = lane;
         asm volatile("" : "+v"(ln));
@@ -611,7 +634,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
               if (EPI == EPI_GELU || EPI == EPI_GELU_D) asm volatile("" : "+v"(out.pre[hh][i][it]));
             }
       PP_STAMP(2);
-      if (more) { setup(item); PP_PROLOGUE(); }
       PP_STAMP(3);
       asm volatile("" : "+v"(ln));
       pp_epi_store<EPI, HI>(p, out, em0, en0, ln);
@@ -620,8 +642,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     } else {                                           // fp32 output (accumulate / split-K atomics): row segments per register
       bf16_tile_epilogue<false>(p, acc[0], em0, en0, 0, 0, lane, smem);
       bf16_tile_epilogue<false>(p, acc[1], em0 + 64, en0, 0, 0, lane, smem);
-      if (more) { setup(item); PP_PROLOGUE(); }
-      younger = GKT;
+      younger = -1;                                     // (the atomics are younger than the staged units: uncounted -> wait for all)
     }
     ++nitem_done;
     if (!more) break;
