@@ -12,8 +12,13 @@ def main():
     b = torch.randn((k, n) if tb else (n, k), device="cuda").to(torch.bfloat16)
     out = torch.zeros((m, n), dtype=torch.bfloat16, device="cuda")
     dbg = torch.zeros((8, 16), dtype=torch.int32, device="cuda")
+    epi = sys.argv[6] if len(sys.argv) > 6 else "none"
+    aux = torch.randn((m, n), device="cuda").to(torch.bfloat16)
+    kw = {"add": dict(epi=ops.EPI_ADD, aux_in=aux), "mul": dict(epi=ops.EPI_DGELU, aux_in=aux, flags=ops.GEMM_AUX_DERIV)}.get(epi, {})
+    fl = kw.pop("flags", 0)
+    # (the GELU kinds write their second stream to aux_out, which the stamps use: not available here)
     for _ in range(3):
-        ops.gemm(a, b, m, n, k, ta=ta, tb=tb, out=out, aux_out=dbg, variant=8, flags=256 << 8)      # UC2_GEMM_DIAG(256): stamps
+        ops.gemm(a, b, m, n, k, ta=ta, tb=tb, out=out, aux_out=dbg, variant=8, flags=fl | (256 << 8), **kw)      # UC2_GEMM_DIAG(256): stamps
     torch.cuda.synchronize()
     t = dbg.cpu().numpy().astype("int64") & 0xffffffff
     for w in range(8):

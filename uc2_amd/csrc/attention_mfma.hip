@@ -275,12 +275,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
   float* Ds = Ls + Lp;
   uint32_t* Hq = reinterpret_cast<uint32_t*>(Ds + Lp);          // per-query / per-key dropout hashes
   uint32_t* Hk = Hq + Lp;
+  float* Cs = reinterpret_cast<float*>(Hk + Lp);       // [3H] column sums of dQ | dK | dV over this workgroup's heads (dbias only)
   const int H = nh * D, ld = 3 * H;
   const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
   const int tid = threadIdx.x;
   const int w = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
   const int r0 = 32 * w + c;                           // this lane's key (main loop) and query (dQ phase)
   constexpr int NTHR = NW * 64, CPR = D / 8, NCH = Lp * CPR / NTHR;
+  if (dbias) {                                         // (the head loop's first barrier orders this before any accumulation)
+    for (int i = tid; i < 3 * H; i += NTHR) Cs[i] = 0.f;
+  }
   const int bh_end = min(nbh, (int)(blockIdx.x + 1) * hpw);
   int bh = blockIdx.x * hpw;
   // ---- fetch of one head into registers: Q, K, dO, O tiles (NCH chunks each), this lane's V fragments, mask / lse of row tid
@@ -391,8 +395,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
         }
     }
     if (dbias) {                                                               // d(key bias), d(value bias)
-      acc_colsum_atomic<DB>(dk, r0 < L, dbias + H + head * D, lane);
-      acc_colsum_atomic<DB>(dv, r0 < L, dbias + 2 * H + head * D, lane);
+      acc_colsum_atomic<DB>(dk, r0 < L, Cs + H + head * D, lane);
+      acc_colsum_atomic<DB>(dv, r0 < L, Cs + 2 * H + head * D, lane);
     }
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
@@ -415,11 +419,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
       for (int db = 0; db < DB; ++db)
         dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr(Ks, RS, 16 * ks, 32 * db, lane), bfrag, dq[db], 0, 0, 0);
     }
-    if (dbias) acc_colsum_atomic<DB>(dq, r0 < L, dbias + head * D, lane);       // d(query bias)
+    if (dbias) acc_colsum_atomic<DB>(dq, r0 < L, Cs + head * D, lane);          // d(query bias)
 #pragma unroll
     for (int db = 0; db < DB; ++db) store_acc_block(dbase + (size_t)r0 * ld + 32 * db, dq[db], 1.0f, h, r0 < L);
   }
   __syncthreads();                                     // every wave is done with this head's LDS tiles
+  }
+  // d(q|k|v bias): the workgroup's heads were summed in LDS (ds_add_f32); one global atomic per column and workgroup
+  // (2 x CUs workgroups) instead of one per column, wave and head
+  if (dbias) {
+    for (int i = tid; i < 3 * H; i += NTHR) atomicAdd(dbias + i, Cs[i]);
   }
 }
 
@@ -443,7 +452,7 @@ static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, 
                       const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx, const void* dctx,
                       const float* lse, void* dqkv, float* dbias, hipStream_t st) {
   constexpr int RS = D * 2 + 16, Lp = NW * 32, RSD = Lp * 2 + 16;
-  const size_t smem = 3 * Lp * RS + Lp * RSD + 5 * Lp * sizeof(float);
+  const size_t smem = 3 * Lp * RS + Lp * RSD + 5 * Lp * sizeof(float) + (dbias ? 3 * (size_t)nh * D * sizeof(float) : 0);
   auto kern = attn_bwd_mfma_kernel<D, NW>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

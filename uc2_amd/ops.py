@@ -704,10 +704,11 @@ class BertLayerFn(torch.autograd.Function):
         dctx = linear_dgrad_fp8(d_o1, st, P["ow"], P["ow"], (H, H)) if fp8 else linear_dgrad(d_o1, st.compute(P["ow"], dtype))
         dwqkv = st.grad_span(P["qw"], P["vw"], (3 * H, H))
         dbqkv = st.grad_span(P["qb"], P["vb"], (3 * H,))
-        # (attn_bwd can also produce d(q|k|v bias) itself, dbias=dbqkv, but its 2304 atomic targets are shared by every
-        #  batch element: measured +65 us per call against 45 us for the separate column-sum pass)
-        dqkv = attn_bwd(qkv, mask2d, ctxv, dctx, lse, B, L, nh, D, p_a, seed, sid + 1)
-        linear_wgrad(dqkv, x2, dwqkv, dbqkv)
+        # d(q|k|v bias) comes out of attn_bwd: column sums of the dQ/dK/dV accumulators, added up per workgroup in LDS and
+        # flushed with one global atomic per column and workgroup (the separate column-sum pass re-read dqkv: 97 us)
+        # (the fp32-math kernels run the column-sum pass inside uc2_attn_bwd)
+        dqkv = attn_bwd(qkv, mask2d, ctxv, dctx, lse, B, L, nh, D, p_a, seed, sid + 1, dbias=dbqkv)
+        linear_wgrad(dqkv, x2, dwqkv, None)
         dx = None
         if ctx.needs_input_grad[0]:
             if fp8:
