@@ -37,15 +37,19 @@ class NativeComm:
         lib = _lib.load()
         world, rank = _world(), _rank()
         nb = lib.uc2_comm_unique_id_bytes()
-        buf = (torch.zeros(nb, dtype=torch.uint8))
+        obj = [None]
         if rank == 0:
             import ctypes
             raw = (ctypes.c_char * nb)()
-            _lib.check(lib.uc2_comm_unique_id(raw, nb))
-            buf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
-        obj = [buf.tolist()]
+            try:                                             # a failure here must still reach the broadcast below, or the
+                _lib.check(lib.uc2_comm_unique_id(raw, nb))   # other ranks would wait in it for ever
+                obj = [list(raw.raw)]
+            except Exception as e:                           # noqa: BLE001
+                obj = [str(e)]
         if world > 1:
             dist.broadcast_object_list(obj, src=0)
+        if not isinstance(obj[0], list):
+            raise _lib.Uc2Error("rank 0 could not create the RCCL unique id: %s" % obj[0])
         idb = bytes(obj[0])
         torch.cuda.set_device(device)
         _lib.check(lib.uc2_comm_init(rank, world, idb, nb))
