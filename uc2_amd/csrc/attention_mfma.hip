@@ -50,19 +50,7 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {   // registers
 }
 // Column sums across the 32 lanes of a lane half, 32 partial sums per lane (index v): lane (c, h) returns the total
 // of v = c (transposing butterfly, 31 exchanges; same helper as in gemm_pp.hip)
-__device__ __forceinline__ float colsum_butterfly32(float (&v)[32], int lane) {
-#pragma unroll
-  for (int half = 16; half >= 1; half >>= 1) {
-    const bool up = (lane & half) != 0;
-#pragma unroll
-    for (int i = 0; i < half; ++i) {
-      const float lo = v[i], hi = v[i + half];
-      const float keep = up ? hi : lo, send = up ? lo : hi;
-      v[i] = keep + __shfl_xor(send, half);
-    }
-  }
-  return v[0];
-}
+// (colsum_butterfly32: common.h)
 // bias-gradient contribution of one wave's 32 rows x D columns held as DB transposed accumulators (register 4g+e of
 // block db = column 32db + 8g + 4h + e of row r0): dst[col] += sum over the wave's valid rows (D = 64: one atomic
 // per lane; D = 32: the 16 values per lane are padded to the 32-value butterfly)

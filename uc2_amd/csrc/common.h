@@ -187,3 +187,50 @@ static inline uint32_t drop_thresh(float p) {
   if (t > 4294967295.0) t = 4294967295.0;
   return (uint32_t)t;
 }
+
+// Column sums across the 32 lanes of a lane half, 32 partial sums per lane (index v) -> lane (c = lane & 31, h) returns
+// the total of v = c.  Transposing butterfly: at the stage of lane bit `half` a lane keeps the half of its values whose
+// index bit `half` matches its own lane bit and adds the partner's copies of those -- 31 exchanges instead of 5 x 32.
+// No LDS crossbar (ds_bpermute) involved: bit 4 is v_permlane16_swap (one instruction exchanges both directions of a
+// pair), bits 3..0 are DPP operands of the adds (row_ror:8, row_shl/shr:4, quad_perm), each computed only for the
+// lanes that keep it.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float colsum_butterfly32(float (&v)[32], int lane) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {                      // lane bit 4
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 16]), false, false);
+    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  {                                                   // lane bit 3: partner = lane ^ 8 = row_ror:8 within the 16-lane row
+    const bool up = (lane & 8) != 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float a = v[i] + dpp_f32<0x128>(v[i]), b = v[i + 8] + dpp_f32<0x128>(v[i + 8]);
+      v[i] = up ? b : a;
+    }
+  }
+  {                                                   // lane bit 2: lower lanes read lane + 4 (row_shl:4), upper lane - 4 (row_shr:4)
+    const bool up = (lane & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a = v[i] + dpp_f32<0x104>(v[i]), b = v[i + 4] + dpp_f32<0x114>(v[i + 4]);
+      v[i] = up ? b : a;
+    }
+  }
+  {                                                   // lane bit 1: quad_perm [2,3,0,1]
+    const bool up = (lane & 2) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float a = v[i] + dpp_f32<0x4E>(v[i]), b = v[i + 2] + dpp_f32<0x4E>(v[i + 2]);
+      v[i] = up ? b : a;
+    }
+  }
+  {                                                   // lane bit 0: quad_perm [1,0,3,2]
+    const float a = v[0] + dpp_f32<0xB1>(v[0]), b = v[1] + dpp_f32<0xB1>(v[1]);
+    v[0] = (lane & 1) ? b : a;
+  }
+  return v[0];
+}

@@ -99,19 +99,7 @@ template <bool TR, int S> __device__ __forceinline__ void pp_read(bf16x8& dst, u
 // Column sums across the 32 lanes of a lane half, 32 partial sums per lane (index v) -> lane (c31, h) returns the
 // total of v = c31.  Transposing butterfly: at step k a lane keeps the half of its values whose bit (4-k) of v
 // matches its own lane bit and adds the partner's copies of those -- 31 exchanges instead of 5 x 32.
-__device__ __forceinline__ float colsum_butterfly32(float (&v)[32], int lane) {
-#pragma unroll
-  for (int half = 16; half >= 1; half >>= 1) {
-    const bool up = (lane & half) != 0;
-#pragma unroll
-    for (int i = 0; i < half; ++i) {
-      const float lo = v[i], hi = v[i + half];
-      const float keep = up ? hi : lo, send = up ? lo : hi;
-      v[i] = keep + __shfl_xor(send, half);
-    }
-  }
-  return v[0];
-}
+// (colsum_butterfly32: common.h)
 
 // ---- full-line epilogue I/O through a wave-private 4 KiB LDS transposition buffer ---------------------------------
 // After the lane-half exchange a lane owns (row r = lane & 31, half h) of a 32-row block: four 16-byte pieces of one
