@@ -139,7 +139,7 @@ __device__ __forceinline__ void bf16_tile_epilogue(const GemmArgs& p, const f32x
           bf16x8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = o;
+          __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n));   // streamed output: keep the operands in L2
         } else {
           // ragged / unaligned / fp32-output tiles: element-wise path (bias is applied inside epi_store)
 #pragma unroll

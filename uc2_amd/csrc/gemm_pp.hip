@@ -165,7 +165,7 @@ __device__ __forceinline__ void pp_epi_compute(const GemmArgs& p, const f32x16 (
         for (int it = 0; it < 4; ++it) {
           if (hh == 1 && i >= HI) continue;
           const int m = mb0 + hh * 64 + i * 32 + 8 * it + lr;
-          ax[hh][i][it] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.aux_in) + (size_t)m * p.ldaux + nb + 8 * lc);
+          ax[hh][i][it] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.aux_in) + (size_t)m * p.ldaux + nb + 8 * lc));
         }
   }
 #pragma unroll
@@ -259,11 +259,11 @@ __device__ __forceinline__ void pp_epi_store(const GemmArgs& p, const PpOut& out
       if (hh == 1 && i >= HI) continue;
       bf16* c0 = reinterpret_cast<bf16*>(p.C) + (size_t)(mb0 + hh * 64 + i * 32 + lr) * p.ldc + nb + 8 * lc;
 #pragma unroll
-      for (int it = 0; it < 4; ++it) *reinterpret_cast<bf16x8*>(c0 + (size_t)(8 * it) * p.ldc) = out.o[hh][i][it];
+      for (int it = 0; it < 4; ++it) __builtin_nontemporal_store(out.o[hh][i][it], reinterpret_cast<bf16x8*>(c0 + (size_t)(8 * it) * p.ldc));
       if (EPI == EPI_GELU || EPI == EPI_GELU_D) {          // (the host only selects these kinds with aux_out set)
         bf16* a0 = reinterpret_cast<bf16*>(p.aux_out) + (size_t)(mb0 + hh * 64 + i * 32 + lr) * p.ldaux + nb + 8 * lc;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) *reinterpret_cast<bf16x8*>(a0 + (size_t)(8 * it) * p.ldaux) = out.pre[hh][i][it];
+        for (int it = 0; it < 4; ++it) __builtin_nontemporal_store(out.pre[hh][i][it], reinterpret_cast<bf16x8*>(a0 + (size_t)(8 * it) * p.ldaux));
       }
     }
 }
@@ -271,6 +271,7 @@ __device__ __forceinline__ void pp_epi_store(const GemmArgs& p, const PpOut& out
 // fp32 partial tile of one split-K item (two-stage reduction): transposed accumulators, lane = row m with 4
 // consecutive columns per register group; through the same LDS transposition -> whole 128-byte lines,
 // 32 stores per wave (compile-time count, full tiles)
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
 template <int HI>
 __device__ __forceinline__ void pp_partial_store(float* __restrict__ dst, int ldn, const f32x16 (&acc)[2][2][2], int mb0, int nb,
                                                  int lane, const TpAddr& ta) {
@@ -291,7 +292,7 @@ __device__ __forceinline__ void pp_partial_store(float* __restrict__ dst, int ld
         TP_WAIT4(t[0], t[1], t[2], t[3]);
         float* row = dst + (size_t)(mb0 + hh * 64 + i * 32 + lr) * ldn + nb + 32 * j + 4 * lc;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) *reinterpret_cast<float4*>(row + (size_t)(8 * it) * ldn) = __builtin_bit_cast(float4, t[it]);
+        for (int it = 0; it < 4; ++it) __builtin_nontemporal_store(__builtin_bit_cast(f32x4v, t[it]), reinterpret_cast<f32x4v*>(row + (size_t)(8 * it) * ldn));
       }
     }
 }
