@@ -17,7 +17,9 @@ Prints ONE JSON line on rank 0 (metric contract in the task description) with ex
                    stream over the timed steps, against the dense bf16 MFMA peak; `traffic` is carried from the
                    committed rocprofv3 PMC passes (profiles/), `hbm_kernels` are the HBM-bound kernels' GB/s
   workloads     -- the same step on the MLM task, and the reference's own regime: 104-pair micro-batches x 3
-                   accumulation micro-steps per optimizer step (config/uc2_pretrain.json:17-19)
+                   accumulation micro-steps per optimizer step (config/uc2_pretrain.json:17-19); at N = 1 also the other
+                   BASELINE.json configs on one GPU: retrieval inference (forward-only), the hard-negative finetune step
+                   (configs[3]) and the uc2-large geometry in bf16 and with fp8 GEMMs (configs[4])
   cpu_baseline  -- the CPU oracle (oracle/uc2_oracle.py, kind "port") timed on the host cores per BASELINE.md
                    section 3: B = 32, median of 3 after one warm-up, ITM and MLM (rank 0, N = 1 only)
 """
@@ -81,7 +83,7 @@ def make_cfg(layers):
     return VLXLMRConfig.from_dict(d)
 
 
-def synth_batch(B, task, seed, device):
+def synth_batch(B, task, seed, device, T_TXT=T_TXT, N_REG=N_REG):
     """CC-shaped synthetic batch, generated directly on the device"""
     import torch
     g = torch.Generator(device=device)
@@ -175,6 +177,110 @@ def cpu_baseline(B, layers):
                       "one warm-up, median of %d (ITM, %.2f s/iter) and %d (MLM, %.2f s/iter) timed iterations; `value` is "
                       "the ITM step, `mlm_value` the MLM step" % (B, cores, res["itm"][1], res["itm"][2], res["mlm"][1],
                                                                   res["mlm"][2])}
+
+
+def other_configs(dev, timed, steps):
+    """BASELINE.json configs[3] and configs[4] and the SURVEY 8(f)-2 retrieval path on one GPU (extra keys, never `value`):
+    forward-only retrieval scoring, the hard-negative finetune step, and the uc2-large geometry in bf16 and with fp8 GEMMs"""
+    import torch
+    import uc2_amd
+    from uc2_amd.model.model import VLXLMRConfig, VLXLMRForPretraining
+    from uc2_amd.model.itm import VLXLMRForImageTextRetrievalHardNeg
+    from uc2_amd.optim.adamw import AdamW, clip_grad_norm_
+    from uc2_amd.optim.misc import param_groups
+    from uc2_amd.store import set_compute_dtype, store_of
+    out = {}
+    L = T_TXT + N_REG
+
+    def finish(model):
+        st = store_of(model)
+        st.sync_shadow()
+        st.auto_sync = False
+
+    # ---- retrieval model: inference (itm.py:516-538, 400-pair mini-batches) and the hard-negative step (model/itm.py:105-186)
+    torch.manual_seed(1)
+    model = VLXLMRForImageTextRetrievalHardNeg(make_cfg(12), img_dim=IMG_DIM, margin=0.2, hard_size=31)
+    model.to(dev)
+    set_compute_dtype(model, torch.bfloat16)
+    opt = AdamW(param_groups(model, 0.0), lr=1e-5, betas=(0.9, 0.98))
+    finish(model)
+    nb = 400                                                        # config/uc2_mscoco_itm.json val/test_minibatch_size
+    eb = [synth_batch(nb, "itm", 31 + i, dev) for i in range(2)]
+    for b in eb:
+        b.pop("targets")
+    model.eval()
+    with torch.no_grad():
+        d, _ = timed(lambda i: model(eb[i % 2], compute_loss=False), 2, 2 * steps)
+    fwd_gflop = ENC_GFLOP_PER_PAIR / 3.0
+    out["retrieval_inference"] = {
+        "pairs_per_s": round(nb * 2 * steps / d, 1), "ms_per_minibatch": round(d / (2 * steps) * 1e3, 2), "minibatch_pairs": nb,
+        "mfma_frac_encoder_fwd": round(nb * 2 * steps / d * fwd_gflop * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
+        "note": "forward-only scoring of image-text pairs (encoder -> pooler -> rank_output), eval mode, no autograd state: the "
+                "inner loop of itm.py:516-538 at the reference's 400-pair evaluation mini-batch"}
+    del eb
+    model.train()
+    npool, hard = 128, 31
+
+    def hn_batch(seed):
+        b = synth_batch(npool, "itm", seed, dev)
+        b.pop("targets")
+        b["input_ids"] = b["input_ids"][:1].contiguous()             # one text against `npool` images: the first is the positive
+        return b
+    hb = [hn_batch(77 + i) for i in range(2)]
+
+    def hn_step(i):
+        loss = model(hb[i % 2], sample_from="t", compute_loss=True)
+        loss = loss[0] if isinstance(loss, tuple) else loss
+        loss.mean().backward()
+        _, coef = clip_grad_norm_([p for p in model.parameters() if p.grad is not None], 2.0, fused=True)
+        opt.step(grad_scale=coef, zero_grad=True)
+        return loss
+    d, _ = timed(hn_step, 2, steps)
+    out["hard_negative_finetune"] = {
+        "scored_pairs_per_s": round(npool * steps / d, 1), "trained_pairs_per_s": round((hard + 1) * steps / d, 1),
+        "ms_per_step": round(d / steps * 1e3, 2), "pool_pairs": npool, "hard_size": hard,
+        "note": "BASELINE.json configs[3] on one GPU: score 1 positive + %d candidates without autograd state (eval mode), keep "
+                "the %d hardest on the device, forward + backward + clip + AdamW on those %d pairs (triplet loss)"
+                % (npool - 1, hard, hard + 1)}
+    del model, opt, hb
+    torch.cuda.empty_cache()
+
+    # ---- uc2-large (configs[4]): 24L / 1024H / 16 heads / 4096, 80 tokens + 50 regions (L = 130), MLM-type step, bf16 and fp8
+    large = dict(BASE, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
+                 hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, max_position_embeddings=514,
+                 type_vocab_size=2, initializer_range=0.02, layer_norm_eps=1e-5, pad_token_id=1)
+    TL, RL, BL = 80, 50, 256
+    LL = TL + RL
+    gflop = (24 * 1024 * 1024 + 4 * LL * 1024) * LL * 24 * 3 / 1e9
+    torch.manual_seed(2)
+    model = VLXLMRForPretraining(VLXLMRConfig.from_dict(large), img_dim=IMG_DIM, img_label_dim=1601)
+    model.to(dev).train()
+    set_compute_dtype(model, torch.bfloat16)
+    opt = AdamW(param_groups(model, 0.01), lr=2e-5, betas=(0.9, 0.98))
+    finish(model)
+    lb = [synth_batch(BL, "itm", 91 + i, dev, TL, RL) for i in range(2)]
+
+    def lg_step(i):
+        loss = model(lb[i % 2], "itm", compute_loss=True)
+        loss = loss[0] if isinstance(loss, tuple) else loss
+        loss.mean().backward()
+        _, coef = clip_grad_norm_([p for p in model.parameters() if p.grad is not None], 5.0, fused=True)
+        opt.step(grad_scale=coef, zero_grad=True)
+        return loss
+    for tag in ("bf16", "fp8"):
+        uc2_amd.set_fp8(model, tag == "fp8")
+        d, loss = timed(lg_step, 2, steps)
+        lv = float(loss.mean().item())
+        assert lv == lv, "uc2-large %s: loss is NaN" % tag
+        out["uc2_large_" + tag] = {
+            "pairs_per_s": round(BL * steps / d, 1), "ms_per_step": round(d / steps * 1e3, 2), "pairs_per_step": BL, "seq_len": LL,
+            "mfma_frac_encoder_vs_bf16_peak": round(BL * steps / d * gflop * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "note": "BASELINE.json configs[4] geometry on one GPU (24L/1024H/16 heads/4096, 80 tokens + 50 regions), ITM training "
+                    "step incl. clip + AdamW; %s" % ("bf16 GEMMs" if tag == "bf16" else
+                    "e4m3 forward and input-gradient GEMMs (per-tensor power-of-two scales, just-in-time quantisation), bf16 weight gradients")}
+    del model, opt, lb
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -330,6 +436,16 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         in_sync = bool((lo == hi).item())
         assert in_sync, "replicas diverged: parameter checksums differ across ranks"
+
+    if world == 1 and not a.no_extras and a.layers == 12:
+        # configs[3] / configs[4] / retrieval inference on one GPU; the headline model is released first
+        del model, opt, st, sync
+        torch.cuda.empty_cache()
+        try:
+            workloads.update(other_configs(dev, timed, min(a.steps, 4)))
+        except Exception as e:                                 # noqa: BLE001 -- never lose the headline line to an extra
+            import traceback
+            workloads["other_configs_error"] = "%s: %s | %s" % (type(e).__name__, str(e)[:300], traceback.format_exc()[-400:])
 
     if rank == 0 and os.environ.get("UC2_SAVE_PLANS"):
         ops.save_plans(os.environ["UC2_SAVE_PLANS"])

@@ -82,6 +82,9 @@ int uc2_fp8_amax(int dtype, size_t n, const void* x, void* amax_bits, void* stre
 int uc2_fp8_scale(const void* amax_bits, float* scale, void* stream);
 int uc2_fp8_quant(int dtype, int rows, int cols, const void* x, int ldx, const float* scale, void* out, int ldo,
                   int transpose, void* stream);
+/* the same with the scale derived from the amax cell inside the kernel and written to *scale_out (one launch less per tensor) */
+int uc2_fp8_quant_amax(int dtype, int rows, int cols, const void* x, int ldx, const void* amax_bits, float* scale_out,
+                       void* out, int ldo, int transpose, void* stream);
 int uc2_gemm_fp8(int M, int N, int K, const void* A8, int lda, const void* B8, int ldb, const float* scale_a,
                  const float* scale_b, void* C, int ldc, const float* bias, int epilogue, const void* aux_in, void* aux_out,
                  int ldaux, int flags, void* stream);

@@ -27,6 +27,7 @@ SIGNATURES = {
     "uc2_fp8_amax": (I, [I, SZ, P, P, P]),
     "uc2_fp8_scale": (I, [P, P, P]),
     "uc2_fp8_quant": (I, [I, I, I, P, I, P, P, I, I, P]),
+    "uc2_fp8_quant_amax": (I, [I, I, I, P, I, P, P, P, I, I, P]),
     "uc2_gemm_fp8": (I, [I, I, I, P, I, P, I, P, P, P, I, P, I, P, P, I, I, P]),
     "uc2_ln_fwd": (I, [I, I, I, P, P, P, P, F, F, I, P, U64, P, P, P, P]),
     "uc2_ln_bwd_workspace": (SZ, [I, I]),

@@ -19,16 +19,22 @@ __global__ __launch_bounds__(256) void fp8_amax_kernel(size_t n, const T* __rest
     m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(to_f<T>(x[(n4 << 2) + threadIdx.x])));
+  // one atomic per workgroup: with one per wave, 8192 atomics on a single address serialised into ~100 us
+  __shared__ float wm[4];
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));     // non-negative floats order like their bit patterns
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(amax_bits, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));   // non-negative floats order like their bit patterns
 }
-__global__ void fp8_scale_kernel(const unsigned* __restrict__ amax_bits, float* __restrict__ scale) {
-  const float a = __uint_as_float(*amax_bits);
+// the power-of-two scale that maps `amax` just below the e4m3 maximum (448)
+__device__ __forceinline__ float fp8_scale_of(unsigned amax_bits) {
+  const float a = __uint_as_float(amax_bits);
   float s = 1.0f;
   if (a > 0.f && a < INFINITY) s = exp2f(floorf(log2f(448.0f / a)));
-  s = fminf(fmaxf(s, 1.0f / 16777216.0f), 16777216.0f);
-  *scale = s;
+  return fminf(fmaxf(s, 1.0f / 16777216.0f), 16777216.0f);
 }
+__global__ void fp8_scale_kernel(const unsigned* __restrict__ amax_bits, float* __restrict__ scale) { *scale = fp8_scale_of(*amax_bits); }
 __device__ __forceinline__ unsigned pack4_e4m3(const float (&v)[4]) {
   unsigned r = 0;
   r = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], r, false);      // saturating OCP e4m3 conversion, bytes 0-1
@@ -38,8 +44,10 @@ __device__ __forceinline__ unsigned pack4_e4m3(const float (&v)[4]) {
 // rows x cols (cols % 4 == 0), out[r * ldo + c] = e4m3(x[r * ldx + c] * scale)
 template <typename T>
 __global__ __launch_bounds__(256) void fp8_quant_kernel(int rows, int cols, const T* __restrict__ x, int ldx,
-                                                        const float* __restrict__ scale, uint8_t* __restrict__ out, int ldo) {
-  const float s = *scale;
+                                                        const float* __restrict__ scale, uint8_t* __restrict__ out, int ldo,
+                                                        const unsigned* __restrict__ amax_bits, float* __restrict__ scale_out) {
+  const float s = amax_bits ? fp8_scale_of(*amax_bits) : *scale;            // (amax given: the scale is derived here and published)
+  if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
   const int c4 = cols >> 2;
   const size_t total = (size_t)rows * c4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -55,9 +63,11 @@ __global__ __launch_bounds__(256) void fp8_quant_kernel(int rows, int cols, cons
 // gradient dX = dY W); 64 x 64 tiles through LDS
 template <typename T>
 __global__ __launch_bounds__(256) void fp8_quant_t_kernel(int rows, int cols, const T* __restrict__ x, int ldx,
-                                                          const float* __restrict__ scale, uint8_t* __restrict__ out, int ldo) {
+                                                          const float* __restrict__ scale, uint8_t* __restrict__ out, int ldo,
+                                                          const unsigned* __restrict__ amax_bits, float* __restrict__ scale_out) {
   __shared__ float tile[64][65];
-  const float s = *scale;
+  const float s = amax_bits ? fp8_scale_of(*amax_bits) : *scale;
+  if (scale_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *scale_out = s;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, t = threadIdx.x;
   for (int i = t; i < 64 * 64; i += 256) {
     const int r = i >> 6, c = i & 63;
@@ -79,7 +89,7 @@ extern "C" int uc2_fp8_amax(int dtype, size_t n, const void* x, void* amax_bits,
   if (n == 0) return 0;
   UC2_CHECK_ARG(x && amax_bits);
   const size_t blocks = (n / 4 + 255) / 256;
-  const int grid = (int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
+  const int grid = (int)(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks));
   if (dtype == 0) hipLaunchKernelGGL(fp8_amax_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, (const float*)x, (unsigned*)amax_bits);
   else hipLaunchKernelGGL(fp8_amax_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, (const bf16*)x, (unsigned*)amax_bits);
   UC2_LAUNCH_CHECK();
@@ -91,26 +101,35 @@ extern "C" int uc2_fp8_scale(const void* amax_bits, float* scale, void* stream) 
   UC2_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int uc2_fp8_quant(int dtype, int rows, int cols, const void* x, int ldx, const float* scale, void* out, int ldo,
-                             int transpose, void* stream) {
+static int fp8_quant_impl(int dtype, int rows, int cols, const void* x, int ldx, const float* scale, void* out, int ldo,
+                          int transpose, const unsigned* amax_bits, float* scale_out, void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
   if (rows <= 0 || cols <= 0) return 0;
-  UC2_CHECK_ARG(x && scale && out);
+  UC2_CHECK_ARG(x && (scale || amax_bits) && out);
   hipStream_t st = (hipStream_t)stream;
   if (!transpose) {
     UC2_CHECK_ARG((cols & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0);
     const size_t blocks = ((size_t)rows * (cols / 4) + 255) / 256;
     const int grid = (int)(blocks > 4096 ? 4096 : blocks);
-    if (dtype == 0) hipLaunchKernelGGL(fp8_quant_kernel<float>, dim3(grid), dim3(256), 0, st, rows, cols, (const float*)x, ldx, scale, (uint8_t*)out, ldo);
-    else hipLaunchKernelGGL(fp8_quant_kernel<bf16>, dim3(grid), dim3(256), 0, st, rows, cols, (const bf16*)x, ldx, scale, (uint8_t*)out, ldo);
+    if (dtype == 0) hipLaunchKernelGGL(fp8_quant_kernel<float>, dim3(grid), dim3(256), 0, st, rows, cols, (const float*)x, ldx, scale, (uint8_t*)out, ldo, amax_bits, scale_out);
+    else hipLaunchKernelGGL(fp8_quant_kernel<bf16>, dim3(grid), dim3(256), 0, st, rows, cols, (const bf16*)x, ldx, scale, (uint8_t*)out, ldo, amax_bits, scale_out);
   } else {
     UC2_CHECK_ARG((rows & 3) == 0 && (ldo & 3) == 0);
     dim3 grid((cols + 63) / 64, (rows + 63) / 64);
-    if (dtype == 0) hipLaunchKernelGGL(fp8_quant_t_kernel<float>, grid, dim3(256), 0, st, rows, cols, (const float*)x, ldx, scale, (uint8_t*)out, ldo);
-    else hipLaunchKernelGGL(fp8_quant_t_kernel<bf16>, grid, dim3(256), 0, st, rows, cols, (const bf16*)x, ldx, scale, (uint8_t*)out, ldo);
+    if (dtype == 0) hipLaunchKernelGGL(fp8_quant_t_kernel<float>, grid, dim3(256), 0, st, rows, cols, (const float*)x, ldx, scale, (uint8_t*)out, ldo, amax_bits, scale_out);
+    else hipLaunchKernelGGL(fp8_quant_t_kernel<bf16>, grid, dim3(256), 0, st, rows, cols, (const bf16*)x, ldx, scale, (uint8_t*)out, ldo, amax_bits, scale_out);
   }
   UC2_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int uc2_fp8_quant(int dtype, int rows, int cols, const void* x, int ldx, const float* scale, void* out, int ldo,
+                             int transpose, void* stream) {
+  return fp8_quant_impl(dtype, rows, cols, x, ldx, scale, out, ldo, transpose, nullptr, nullptr, stream);
+}
+extern "C" int uc2_fp8_quant_amax(int dtype, int rows, int cols, const void* x, int ldx, const void* amax_bits, float* scale_out,
+                                  void* out, int ldo, int transpose, void* stream) {
+  UC2_CHECK_ARG(amax_bits && scale_out);
+  return fp8_quant_impl(dtype, rows, cols, x, ldx, nullptr, out, ldo, transpose, (const unsigned*)amax_bits, scale_out, stream);
 }
 
 int uc2_gemm_fp8_launch(const GemmArgs& p8, hipStream_t st);      // gemm_fast.hip

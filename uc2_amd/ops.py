@@ -374,16 +374,42 @@ def _gemm_planned(a, b, M, N, K, ta, tb, wgrad=False, **kw):
 # --------------------------------------------------------------------------------------
 # fp8 (e4m3) inputs for the forward / input-gradient GEMMs (BASELINE.json configs[4]); weight gradients stay bf16
 # --------------------------------------------------------------------------------------
-def fp8_quantize(x2, transpose=False):
-    """per-tensor power-of-two scaling, all on the device: (x8 uint8 [rows, cols] or [cols, rows], scale fp32 [1])"""
-    rows, cols = x2.shape
-    amax = torch.zeros(1, dtype=torch.int32, device=x2.device)
-    scale = torch.empty(1, dtype=torch.float32, device=x2.device)
+_FP8_CELLS = {}
+
+
+def _fp8_cell(device):
+    """a zeroed 4-byte amax cell + a 4-byte scale cell.  Cells come from a pool that is zero-filled once per 4096
+    quantisations (a torch.zeros per tensor was one fill launch each, 384 per uc2-large step)"""
+    pool = _FP8_CELLS.get(device)
+    if pool is None or pool[1] >= pool[0].numel():
+        pool = [torch.zeros(4096, dtype=torch.int32, device=device), 0, torch.empty(4096, dtype=torch.float32, device=device)]
+        _FP8_CELLS[device] = pool
+    i = pool[1]
+    pool[1] = i + 1
+    return pool[0][i:i + 1], pool[2][i:i + 1]
+
+
+def fp8_amax(x2, amax=None):
+    """amax cell (int32 bit pattern of the running maximum of |x|) of a contiguous tensor; pass `amax` to keep accumulating"""
+    if amax is None:
+        amax = _fp8_cell(x2.device)[0]
     assert x2.is_contiguous()
     call("uc2_fp8_amax", dt(x2.dtype), x2.numel(), ptr(x2), ptr(amax), stream())
-    call("uc2_fp8_scale", ptr(amax), ptr(scale), stream())
+    return amax
+
+
+def fp8_quantize(x2, transpose=False, amax=None):
+    """per-tensor power-of-two scaling, all on the device, two launches (amax, then scale + quantise):
+    (x8 uint8 [rows, cols] or [cols, rows], scale fp32 [1]).  `amax`: a cell already holding the maximum (weights are
+    quantised in both orientations from one amax pass)"""
+    rows, cols = x2.shape
+    assert x2.is_contiguous()
+    if amax is None:
+        amax = fp8_amax(x2)
+    scale = _fp8_cell(x2.device)[1]
     out = torch.empty((cols, rows) if transpose else (rows, cols), dtype=torch.uint8, device=x2.device)
-    call("uc2_fp8_quant", dt(x2.dtype), rows, cols, ptr(x2), x2.stride(0), ptr(scale), ptr(out), out.stride(0), int(transpose), stream())
+    call("uc2_fp8_quant_amax", dt(x2.dtype), rows, cols, ptr(x2), x2.stride(0), ptr(amax), ptr(scale), ptr(out), out.stride(0),
+         int(transpose), stream())
     return out, scale
 
 
@@ -417,7 +443,12 @@ def _fp8_weight(st, p_first, p_last, shape, transpose):
     if hit is not None and hit[2] == st.version:
         return hit[0], hit[1]
     w = st.span(st.data, p_first, p_last, shape)
-    w8, sc = fp8_quantize(w, transpose)
+    akey = (key[0], key[1], "amax")
+    ahit = cache.get(akey)
+    if ahit is None or ahit[1] != st.version:                # one amax pass serves both orientations
+        ahit = (fp8_amax(w), st.version)
+        cache[akey] = ahit
+    w8, sc = fp8_quantize(w, transpose, amax=ahit[0])
     cache[key] = (w8, sc, st.version)
     return w8, sc
 
