@@ -1236,6 +1236,14 @@ _DEC_ROWS = 8192          # rows per decoder chunk: 2 * rows * 250 112 bytes of 
                           # kernel addresses its operands with 32-bit byte offsets), and a chunk's logits are 4.1 GB
 
 
+def _dec_chunks(npad):
+    """equal row chunks (multiples of 256, at most _DEC_ROWS): 9216 masked rows are 2 x 4608, not 8192 + 1024 -- the
+    remainder chunk ran the vocabulary-long GEMMs on a handful of tiles"""
+    n = (npad + _DEC_ROWS - 1) // _DEC_ROWS
+    rows = ((npad + n - 1) // n + 255) // 256 * 256 if npad % 256 == 0 else _DEC_ROWS
+    return [(r0, min(npad, r0 + rows)) for r0 in range(0, npad, rows)]
+
+
 class DecoderCEFn(torch.autograd.Function):
     """tied-decoder logits + cross entropy in one node (model/layer.py:257-265, model/model.py:590-596).
     The vocabulary tables are padded to whole 256-row GEMM tiles inside the arena (store.padded) and the masked rows
@@ -1270,8 +1278,7 @@ class DecoderCEFn(torch.autograd.Function):
         lse = torch.empty(npad, dtype=torch.float32, device=z.device)
         am = torch.empty(npad, dtype=torch.int64, device=z.device)
         chunks = []
-        for r0 in range(0, npad, _DEC_ROWS):
-            r1 = min(npad, r0 + _DEC_ROWS)
+        for r0, r1 in _dec_chunks(npad):
             m = r1 - r0
             logits = torch.empty((m, Vp), dtype=dtype, device=z.device)
             if Wp.shape[0] == Vp and Vp != V:         # whole padded tiles: N = Vp (padding columns = padding bias = 0)
@@ -1309,8 +1316,7 @@ class DecoderCEFn(torch.autograd.Function):
         db = st.padded(st.grad, bias) if in_arena else st.grad_buf(bias)
         full = Wp.shape[0] == Vp and Vp != V
         dz = torch.empty((npad, H), dtype=dtype, device=z.device)
-        for ci, r0 in enumerate(range(0, npad, _DEC_ROWS)):
-            r1 = min(npad, r0 + _DEC_ROWS)
+        for ci, (r0, r1) in enumerate(_dec_chunks(npad)):
             m = r1 - r0
             dlog = chunks[ci]                          # in place: the logits buffer becomes dlogits (padding columns zeroed)
             call("uc2_ce_bwd", dt(dtype), m, V, ptr(dlog), Vp, ptr(labels[r0:r1]), ignore_index, ptr(lse[r0:r1]),
@@ -1319,7 +1325,14 @@ class DecoderCEFn(torch.autograd.Function):
             if full:
                 _gemm_planned(dlog, z[r0:r1], Vp, H, m, True, True, wgrad=True, out=dE, accumulate=True, lda=Vp)
                 call("uc2_colsum_accum", dt(dtype), m, Vp, ptr(dlog), Vp, None, ptr(db), stream())
-                _gemm_planned(dlog, Wp, m, H, Vp, False, True, out=dz[r0:r1], lda=Vp)
+                if dtype == torch.bfloat16 and m >= 256:
+                    # m x H is only (m/256) x 3 tiles (96 at 8192 rows) under a contraction of 250 112: split it over the
+                    # vocabulary like a weight gradient (fp32 partial tiles + one reduction pass), then round once
+                    dz32 = torch.zeros((m, H), dtype=torch.float32, device=z.device)
+                    _gemm_planned(dlog, Wp, m, H, Vp, False, True, wgrad=True, out=dz32, accumulate=True, lda=Vp)
+                    call("uc2_cast", dt(torch.float32), dt(dtype), m * H, ptr(dz32), ptr(dz[r0:r1]), stream())
+                else:
+                    _gemm_planned(dlog, Wp, m, H, Vp, False, True, out=dz[r0:r1], lda=Vp)
             else:
                 gemm(dlog, z[r0:r1], V, H, m, ta=True, tb=True, out=dE, accumulate=True, lda=Vp,
                      split_k=_wgrad_split(dtype, V, H, m))
