@@ -176,6 +176,11 @@ int uc2_ce_fwd(int dtype, int n, int V, const void* logits, int ld, const int64_
                float* loss, float* lse, int64_t* argmax, void* stream);
 int uc2_ce_bwd(int dtype, int n, int V, void* logits_inout, int ld, const int64_t* labels, int64_t ignore_index,
                const float* lse, const float* gout, void* stream);
+/* uc2_ce_bwd + the decoder-bias gradient in one pass: dbias[0..ncol_bias) += column sums of dlogits (column-strip tiling;
+ * replaces the column-sum pass of model/layer.py:257-265's bias).  Returns -2 (nothing done) unless rows are 16-byte
+ * aligned with ld % 8 == 0 (bf16) / % 4 (fp32). */
+int uc2_ce_bwd_colsum(int dtype, int n, int V, void* logits_inout, int ld, const int64_t* labels, int64_t ignore_index,
+                      const float* lse, const float* gout, float* dbias, int ncol_bias, void* stream);
 int uc2_kl_fwd(int dtype, int n, int V, const void* pred, int ld, const float* target, const float* lse, float* loss,
                void* stream);
 int uc2_kl_bwd(int dtype, int n, int V, const void* pred, int ld, const float* target, const float* lse,

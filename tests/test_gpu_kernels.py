@@ -245,6 +245,42 @@ def test_cross_entropy(dtype, n, V):
     assert rel_err(lg.grad[:, :V].float(), x.grad) < tol(dtype, 1e-5, 1e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,V,pad_bias", [(300, 1000, False), (77, 2043, True), (1, 16, False)])
+def test_cross_entropy_backward_with_bias_gradient(dtype, n, V, pad_bias):
+    """uc2_ce_bwd_colsum: dlogits in place (identical to uc2_ce_bwd) + dbias += column sums of dlogits from the same
+    pass (the decoder-bias gradient, model/layer.py:257-265); ignored rows contribute nothing, padding columns stay 0"""
+    from uc2_amd import _lib
+    Vp = (V + 7) // 8 * 8
+    logits = torch.zeros((n, Vp), dtype=dtype, device=DEV)
+    logits[:, :V] = rnd((n, V), 1, 3.0, dtype=dtype)
+    labels = synth.det_randint((n,), 2, 0, V).to(DEV)
+    labels[0] = -100
+    g = rnd((n,), 3)
+    lse = torch.logsumexp(logits[:, :V].float(), -1)
+    ref = logits.clone()
+    _lib.call("uc2_ce_bwd", _lib.dt(dtype), n, V, _lib.ptr(ref), Vp, _lib.ptr(labels), -100, _lib.ptr(lse), _lib.ptr(g), _lib.stream())
+    got = logits.clone()
+    nb = Vp if pad_bias else V
+    db0 = rnd((nb,), 4)
+    db = db0.clone()
+    rc = _lib.load().uc2_ce_bwd_colsum(_lib.dt(dtype), n, V, _lib.ptr(got), Vp, _lib.ptr(labels), -100, _lib.ptr(lse), _lib.ptr(g),
+                                       _lib.ptr(db), nb, _lib.stream())
+    assert rc == 0
+    assert torch.equal(got, ref)                                        # same arithmetic, element for element
+    x = logits[:, :V].float().requires_grad_(True)
+    torch.nn.functional.cross_entropy(x, labels, ignore_index=-100, reduction="none").backward(g)
+    want = db0.clone()
+    want[:V] += x.grad.sum(0)
+    assert rel_err(db, want) < tol(dtype, 1e-5, 2e-3)                    # fp32 sums of the unrounded dlogits
+    assert (got[:, V:] == 0).all()
+    # rows that are not vectorisable are refused, not mangled
+    odd = torch.zeros((4, 15), dtype=dtype, device=DEV)
+    rc = _lib.load().uc2_ce_bwd_colsum(_lib.dt(dtype), 4, 15, _lib.ptr(odd), 15, _lib.ptr(labels[:4]), -100, _lib.ptr(lse[:4]),
+                                       _lib.ptr(g[:4]), _lib.ptr(db), 15, _lib.stream())
+    assert rc == -2
+
+
 def test_kl_mse_triplet():
     n, V = 17, 1601
     pred = rnd((n, V), 1, 2.0)

@@ -53,6 +53,7 @@ SIGNATURES = {
     "uc2_add_rowvec": (I, [I, I, I, I, P, P, P, P, P, P]),
     "uc2_ce_fwd": (I, [I, I, I, P, I, P, I64, P, P, P, P]),
     "uc2_ce_bwd": (I, [I, I, I, P, I, P, I64, P, P, P]),
+    "uc2_ce_bwd_colsum": (I, [I, I, I, P, I, P, I64, P, P, P, I, P]),
     "uc2_kl_fwd": (I, [I, I, I, P, I, P, P, P, P]),
     "uc2_kl_bwd": (I, [I, I, I, P, I, P, P, P, P, P]),
     "uc2_mse": (I, [I, SZ, P, P, P, P, P, P]),

@@ -516,6 +516,63 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(int V, T* __restrict__ logi
     for (int c = V + blockIdx.x * 256 + threadIdx.x; c < ld; c += gridDim.x * 256) x[c] = from_f<T>(0.f);
   }
 }
+// The same with the column sums of dlogits (the decoder-bias gradient) produced on the way: given lse the backward is
+// element-wise, so it can be tiled by column strips -- a workgroup owns 32 * VEC columns (32 column vectors x 8 row lanes)
+// of a slice of the rows, keeps per-column partial sums in registers and adds them to dbias once (gridDim.y atomics per
+// column).  Saves the separate column-sum pass over the [rows, 250 112] buffer (4.6 GB per 1024 pairs).
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void ce_bwd_colsum_kernel(int n, int V, T* __restrict__ logits, int ld,
+                                                            const int64_t* __restrict__ labels, int64_t ignore_index,
+                                                            const float* __restrict__ lse, const float* __restrict__ gout,
+                                                            float* __restrict__ dbias, int ncol_bias) {
+  __shared__ float red[8][32 * VEC + 1];
+  const int cv = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c0 = (blockIdx.x * 32 + cv) * VEC;
+  const int rows_per = (n + gridDim.y - 1) / gridDim.y;
+  const int r_beg = blockIdx.y * rows_per, r_end = min(n, r_beg + rows_per);
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  if (c0 < ld) {
+    constexpr int U = 4;                               // rows in flight per thread
+    for (int row0 = r_beg + rl; row0 < r_end; row0 += 8 * U) {
+      float v[U][VEC], g[U], l[U];
+      int64_t lab[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = min(row0 + 8 * u, r_end - 1);
+        ce_load<T, VEC>(logits + (size_t)row * ld + c0, v[u]);
+        lab[u] = labels[row];
+        g[u] = (lab[u] == ignore_index) ? 0.f : gout[row];
+        l[u] = lse[row];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = row0 + 8 * u;
+        if (row >= r_end) break;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const int c = c0 + e;
+          v[u][e] = (c < V && g[u] != 0.f) ? (__expf(v[u][e] - l[u]) - (c == lab[u] ? 1.f : 0.f)) * g[u] : 0.f;
+          acc[e] += v[u][e];
+        }
+        ce_store<T, VEC>(logits + (size_t)row * ld + c0, v[u]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) red[rl][cv * VEC + e] = acc[e];
+  __syncthreads();
+  for (int t = threadIdx.x; t < 32 * VEC; t += 256) {
+    const int c = blockIdx.x * 32 * VEC + t;
+    if (c < ncol_bias) {
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sum += red[r][t];
+      atomicAdd(dbias + c, sum);
+    }
+  }
+}
 template <typename T> static bool ce_vec_ok(const void* p, int ld) {
   return (ld % CeVec<T>::N) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
 }
@@ -553,6 +610,28 @@ extern "C" int uc2_ce_bwd(int dtype, int n, int V, void* logits, int ld, const i
     if (vec == 8) hipLaunchKernelGGL((ce_bwd_kernel<bf16, 8>), grid, dim3(256), 0, st, V, (bf16*)logits, ld, labels, ignore_index, lse, gout);
     else hipLaunchKernelGGL((ce_bwd_kernel<bf16, 1>), grid, dim3(256), 0, st, V, (bf16*)logits, ld, labels, ignore_index, lse, gout);
   }
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+// dbias[0 .. ncol_bias) += column sums of dlogits (ncol_bias = V, or ld when the bias vector is padded like the rows).
+// Needs the vectorised layout (ld % 8 == 0 for bf16 / % 4 for fp32, 16-byte aligned rows): returns -2 otherwise so that
+// the caller can run uc2_ce_bwd + uc2_colsum_accum instead.
+extern "C" int uc2_ce_bwd_colsum(int dtype, int n, int V, void* logits, int ld, const int64_t* labels, int64_t ignore_index,
+                                 const float* lse, const float* gout, float* dbias, int ncol_bias, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  if (n <= 0) return 0;
+  UC2_CHECK_ARG(V > 0 && ld >= V && logits && labels && lse && gout && dbias && ncol_bias >= V && ncol_bias <= ld);
+  const bool ok = dtype == 0 ? ce_vec_ok<float>(logits, ld) : ce_vec_ok<bf16>(logits, ld);
+  if (!ok) return -2;
+  hipStream_t st = (hipStream_t)stream;
+  const int vec = dtype == 0 ? 4 : 8;
+  const int gx = (ld + 32 * vec - 1) / (32 * vec);
+  int gy = (2048 + gx - 1) / gx;                     // >= 2048 workgroups, each with >= 64 rows
+  if (gy > (n + 63) / 64) gy = (n + 63) / 64;
+  if (gy < 1) gy = 1;
+  dim3 grid(gx, gy);
+  if (dtype == 0) hipLaunchKernelGGL((ce_bwd_colsum_kernel<float, 4>), grid, dim3(256), 0, st, n, V, (float*)logits, ld, labels, ignore_index, lse, gout, dbias, ncol_bias);
+  else hipLaunchKernelGGL((ce_bwd_colsum_kernel<bf16, 8>), grid, dim3(256), 0, st, n, V, (bf16*)logits, ld, labels, ignore_index, lse, gout, dbias, ncol_bias);
   UC2_LAUNCH_CHECK();
   return 0;
 }

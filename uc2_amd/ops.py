@@ -1319,12 +1319,20 @@ class DecoderCEFn(torch.autograd.Function):
         for ci, (r0, r1) in enumerate(_dec_chunks(npad)):
             m = r1 - r0
             dlog = chunks[ci]                          # in place: the logits buffer becomes dlogits (padding columns zeroed)
-            call("uc2_ce_bwd", dt(dtype), m, V, ptr(dlog), Vp, ptr(labels[r0:r1]), ignore_index, ptr(lse[r0:r1]),
-                 ptr(g[r0:r1]), stream())
-            # dE[V,H] += dlogits^T z ; dbias[V] += colsum(dlogits) ; dz = dlogits E
+            # dlogits in place, with dbias[V] += colsum(dlogits) from the same pass when the rows are vectorisable
+            rc = _lib.load().uc2_ce_bwd_colsum(dt(dtype), m, V, ptr(dlog), Vp, ptr(labels[r0:r1]), ignore_index,
+                                               ptr(lse[r0:r1]), ptr(g[r0:r1]), ptr(db), Vp if full else V, stream())
+            have_db = rc == 0
+            if rc not in (0, -2):
+                _lib.check(rc)
+            if not have_db:
+                call("uc2_ce_bwd", dt(dtype), m, V, ptr(dlog), Vp, ptr(labels[r0:r1]), ignore_index, ptr(lse[r0:r1]),
+                     ptr(g[r0:r1]), stream())
+            # dE[V,H] += dlogits^T z ; dz = dlogits E
             if full:
                 _gemm_planned(dlog, z[r0:r1], Vp, H, m, True, True, wgrad=True, out=dE, accumulate=True, lda=Vp)
-                call("uc2_colsum_accum", dt(dtype), m, Vp, ptr(dlog), Vp, None, ptr(db), stream())
+                if not have_db:
+                    call("uc2_colsum_accum", dt(dtype), m, Vp, ptr(dlog), Vp, None, ptr(db), stream())
                 if dtype == torch.bfloat16 and m >= 256:
                     # m x H is only (m/256) x 3 tiles (96 at 8192 rows) under a contraction of 250 112: split it over the
                     # vocabulary like a weight gradient (fp32 partial tiles + one reduction pass), then round once
@@ -1336,7 +1344,8 @@ class DecoderCEFn(torch.autograd.Function):
             else:
                 gemm(dlog, z[r0:r1], V, H, m, ta=True, tb=True, out=dE, accumulate=True, lda=Vp,
                      split_k=_wgrad_split(dtype, V, H, m))
-                call("uc2_colsum_accum", dt(dtype), m, V, ptr(dlog), Vp, None, ptr(db), stream())
+                if not have_db:
+                    call("uc2_colsum_accum", dt(dtype), m, V, ptr(dlog), Vp, None, ptr(db), stream())
                 gemm(dlog, Wp, m, H, V, tb=True, out=dz[r0:r1], lda=Vp)
         return dz[:n], None, None, None, None, None
 
