@@ -329,3 +329,19 @@ def test_model_saver_and_training_restorer_formats(tmp_path):
     assert r2.global_step == 4
     w, w2 = m.cls.dense.weight, m2.cls.dense.weight
     assert w2.dtype == torch.float32 and torch.equal(w2, w.half().float())            # widened again on load
+
+
+def test_decoder_row_chunks_cover_the_rows_evenly():
+    """ops._dec_chunks (MLM decoder): equal chunks, multiples of 256, at most 8192 rows (32-bit operand offsets of the
+    ping-pong GEMM at 250 112 columns), covering [0, npad) exactly once"""
+    from uc2_amd import ops
+    for npad in (256, 4608, 8192, 8448, 9216, 16384, 16640, 24832, 7, 300):
+        ch = ops._dec_chunks(npad)
+        assert ch[0][0] == 0 and ch[-1][1] == npad
+        assert all(a[1] == b[0] for a, b in zip(ch, ch[1:]))
+        assert all(0 < r1 - r0 <= 8192 for r0, r1 in ch)
+        if npad % 256 == 0:
+            assert all((r1 - r0) % 256 == 0 for r0, r1 in ch)
+            sizes = [r1 - r0 for r0, r1 in ch]
+            assert max(sizes) - min(sizes) <= 256 * (len(ch) - 1) or len(ch) == 1
+            assert len(ch) == (npad + 8191) // 8192
