@@ -335,6 +335,7 @@ def test_decoder_row_chunks_cover_the_rows_evenly():
     """ops._dec_chunks (MLM decoder): equal chunks, multiples of 256, at most 8192 rows (32-bit operand offsets of the
     ping-pong GEMM at 250 112 columns), covering [0, npad) exactly once"""
     from uc2_amd import ops
+    assert ops._dec_chunks(0) == []
     for npad in (256, 4608, 8192, 8448, 9216, 16384, 16640, 24832, 7, 300):
         ch = ops._dec_chunks(npad)
         assert ch[0][0] == 0 and ch[-1][1] == npad

@@ -317,7 +317,8 @@ extern "C" int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K
   UC2_CHECK_ARG(!(split_k > 1 && !(accumulate && (c_is_f32 || dtype == 0))));   // split-K needs f32 accumulate
   UC2_CHECK_ARG(!(split_k > 1 && (bias != nullptr || epilogue != EPI_NONE)));
   if (M == 0 || N == 0) return 0;
-  UC2_CHECK_ARG(A && B && C);
+  if (K == 0 && accumulate) return 0;                 // empty contraction (a weight gradient over zero rows): C += 0
+  UC2_CHECK_ARG(C && (K == 0 || (A && B)));
   GemmArgs p;
   p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux ? ldaux : ldc;

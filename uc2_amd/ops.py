@@ -1239,6 +1239,8 @@ _DEC_ROWS = 8192          # rows per decoder chunk: 2 * rows * 250 112 bytes of 
 def _dec_chunks(npad):
     """equal row chunks (multiples of 256, at most _DEC_ROWS): 9216 masked rows are 2 x 4608, not 8192 + 1024 -- the
     remainder chunk ran the vocabulary-long GEMMs on a handful of tiles"""
+    if npad <= 0:
+        return []
     n = (npad + _DEC_ROWS - 1) // _DEC_ROWS
     rows = ((npad + n - 1) // n + 255) // 256 * 256 if npad % 256 == 0 else _DEC_ROWS
     return [(r0, min(npad, r0 + rows)) for r0 in range(0, npad, rows)]
