@@ -33,6 +33,26 @@ def test_bench_self_launches_two_ranks_and_replicas_stay_in_sync():
     assert d["config"]["global_batch"] == 128 and d["value"] > 0
 
 
+def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible():
+    """the real data plane -- backend nccl (= RCCL) with the library's own communicator -- needs one GPU per rank: runs
+    on a multi-GPU node, skipped on the 1-GPU test box.  Same assertions as the gloo run + the communicator in use."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL rejects two ranks on one device)")
+    if torch.cuda.is_initialized():
+        pytest.skip("the GPU is already initialised in this pytest process")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", UC2_AUTOTUNE="0", UC2_HANG_TRACE="300")
+    for k in ("WORLD_SIZE", "RANK", "UC2_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "64", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=420)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["replicas_in_sync"] is True
+    assert "uc2_comm" in d["config"]["gradient_allreduce"] or "torch.distributed/nccl" in d["config"]["gradient_allreduce"]
+
+
 def test_native_rccl_communicator_single_rank():
     """include/uc2_hip.h uc2_comm_*: the library's RCCL communicator (dlopen of librccl, side stream, event ordering)
     with world = 1 -- the only size a 1-GPU box admits (RCCL rejects two ranks on one device); the 8-GPU run is the
