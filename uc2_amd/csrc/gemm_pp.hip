@@ -27,10 +27,13 @@
 // 576 tiles of 256 rows on 256 CUs (2.25 rounds, the last a quarter full); with 192 rows they are 768 = three full
 // rounds.  Unit A1 is then 8 KiB (one LDS-DMA per wave, 7 per k-tile instead of 8) and phases 2, 3 run 4 MFMAs.
 //
-// The kernel is persistent: one workgroup per CU walks over (output tile, k-split) work items.  The epilogue
-// never touches the ring (it transposes through 4 KiB of wave-private LDS beside it, see tp_* below), so the LDS ring is
-// free as soon as the main loop ends: the next item's first six units are issued BEFORE the epilogue's stores
-// and land while they drain (`vmcnt(8 + stores)` then retires only the two units the first phase reads).
+// The kernel is persistent: one workgroup per CU walks over (output tile, k-split) work items, and the LDS-DMA stream
+// does not drain between them: the last six phases of an item's main loop (which have no unit of their own item left to
+// issue) fetch the NEXT item's first six units, in the order and ring positions a prologue would use (k-tile counts are
+// even), so the next main loop starts with its operands in LDS.  The epilogue never touches the ring (it transposes
+// through 4 KiB of wave-private LDS beside it, see tp_* below); its stores are issued after those units
+// (`vmcnt(8 + stores)` at the item barrier then retires exactly the two units the first phase reads) and are
+// non-temporal: outputs stream past the L2 instead of evicting the weight tiles every row panel re-reads.
 // At K = 768 the per-tile launch + first-fetch latency and the store tail were 40 % of a non-persistent tile.
 // ------------------------------------------------------------------------------------------------------
 #define PP_UNIT 16384
@@ -87,13 +90,14 @@ template <bool TR, int S> __device__ __forceinline__ void pp_read(bf16x8& dst, u
   }
 }
 
-// Direct epilogue in two parts, so that the next item's LDS-DMA can be issued in between:
-//   pp_epi_compute: aux_in loads (EPI_ADD / EPI_DGELU), lane-half exchange, bias, activation, conversion.  It leaves
-//                   the wave's 128x64 outputs as 16 packed bf16x8 registers per lane (the pre-activation copy of
-//                   EPI_GELU is stored on the way) -- every VMEM load of the epilogue is issued here, BEFORE the DMA, because
-//                   vmcnt retires in order: a load issued after the DMA would wait for the whole prologue.
+// Direct epilogue in two parts (loads + arithmetic, then stores only):
+//   pp_epi_compute: aux_in loads (EPI_ADD / EPI_DGELU), lane-half exchange, activation, conversion.  It leaves
+//                   the wave's 128x64 outputs (and the second stream of the GELU kinds) as packed bf16x8 registers.  Its
+//                   loads queue behind the next item's staged units (vmcnt retires in order; those were issued four
+//                   or more phases earlier by the main loop's tail), so their exposed cost is their own latency.
 //                   (The bias is not added here: the accumulators START at the bias, see the kernel.)
-//   pp_epi_store  : the stores only; full tiles, so their number is a compile-time function of the epilogue kind.
+//   pp_epi_store  : the stores only; full tiles, so their number is a compile-time function of the epilogue kind
+//                   (the item barrier's counted vmcnt relies on it).
 // Layout after the exchange (v_permlane32_swap, see gemm_common.h): lane (row m, half h) holds columns
 // 32j + 16g + 8h .. +7 of the wave's 64 for j, g in {0,1}.
 // Column sums across the 32 lanes of a lane half, 32 partial sums per lane (index v) -> lane (c31, h) returns the
@@ -610,8 +614,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
         const TpAddr tpa = tp_addr(lds0 + 131072u + (unsigned)w * 4096u, ln);
         pp_epi_compute<EPI, HI>(p, acc, out, em0, en0, ln, tpa);
       }
-      // pin the finished outputs here: otherwise hipcc sinks the aux-dependent arithmetic below the DMA issue that
-      // follows, and its wait for the aux loads (vmcnt is in order) becomes a wait for the whole next-item prologue
+      // pin the finished outputs here: hipcc must not sink the aux-dependent arithmetic into the store sequence below
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
