@@ -340,11 +340,15 @@ def gemm_plan(dtype, ta, tb, M, N, K, wgrad=False):
         cands.append((9, 1))                      # ping-pong kernel with 192-row tiles (tile-count quantisation at N = 768)
     if wgrad and M % 256 == 0 and N % 256 == 0:
         # persistent ping-pong kernel: one (tile, split) item per CU, or two
+        # (a split must leave every slice an even number >= 2 of k-tiles -- _plan_fits -- so the candidates are the valid
+        #  factors closest to one item per CU, two, and a half: K = 9984 admits 13 and 26 but not 28, 14 or 56)
         tiles = (M // 256) * (N // 256)
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        for s in sorted({max(1, cus // tiles), max(1, 2 * cus // tiles), max(1, (cus // tiles) // 2)}):
-            if s * 256 <= K:
-                cands.append((8, s))
+        valid = [s for s in range(1, 129) if s * 256 <= K and _plan_fits((8, s), key)]
+        for target in (cus, 2 * cus, cus // 2):
+            if valid:
+                cands.append((8, min(valid, key=lambda s: (abs(tiles * s - target), s))))
+        cands = list(dict.fromkeys(cands))
     best, best_t = default, None
     timer_was, GEMM_TIMER = GEMM_TIMER, None          # tuning launches are not part of anybody's timed region
     try:
