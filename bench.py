@@ -333,6 +333,11 @@ def main():
         else:
             comm_path = "libuc2_hip.so uc2_comm_* (RCCL, library-owned side stream)"
 
+    # the all-reduces overlap the backward GEMMs and hold CUs while they run: the persistent GEMM takes its work items from
+    # the per-XCD queue then (include/uc2_hip.h uc2_gemm_queued; scratch/exp9.py: +25 % per launch with the static stride
+    # under contention, +0 % with the queue).  At N = 1 nothing competes for CUs and the static stride is kept.
+    if world > 1 and os.environ.get("UC2_GEMM_QUEUE", "1") != "0":
+        ops.GEMM_QUEUE = True
     ops.rng.manual_seed(20260101 + rank, dev)              # dropout streams differ per rank
     torch.manual_seed(0)                                   # weights seed 0 (random init, N(0, 0.02))
     model = VLXLMRForPretraining(make_cfg(a.layers), img_dim=IMG_DIM, img_label_dim=1601)
@@ -478,7 +483,7 @@ def main():
                                    % (a.layers, a.task.upper()),
                        "pairs_per_gpu_per_step": a.batch, "global_batch": a.batch * world,
                        "seq_len": T_TXT + N_REG, "parallelism": "dp%d" % world, "final_loss": round(lossv, 4), "replicas_in_sync": in_sync,
-                       "gradient_allreduce": comm_path,
+                       "gradient_allreduce": comm_path, "gemm_item_queue": bool(ops.GEMM_QUEUE),
                        "gemm_plans": {"%s%s %dx%dx%d" % ("T" if k[0] else "N", "T" if k[1] else "N", k[2], k[3], k[4]):
                                       "%s split %d" % ("generic" if v[0] == 99 else "ping-pong" if v[0] == 8 else "ring v%d" % v[0], v[1])
                                       for k, v in sorted(ops._TUNE.items())}},

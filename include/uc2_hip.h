@@ -68,6 +68,15 @@ enum { UC2_GEMM_DEFER_REDUCE = 1, UC2_GEMM_AUX_DERIV = 2 };
 #define UC2_GEMM_SKEW(n) (((n) & 15) << 4)
 #define UC2_GEMM_DIAG(m) (((m) & 0xFFFF) << 8)
 #define UC2_GEMM_COLGROUP(n) (((n) & 15) << 24)     /* diagnostic: column tiles per L2 group of the ping-pong tile order (0 = default) */
+/* uc2_gemm with a caller-owned item queue for the persistent ping-pong kernel: `queue` = 9 ints of device memory, zeroed once
+ * (the kernel leaves them zeroed), one queue per stream that issues GEMMs concurrently.  Workgroups take their third and
+ * later (tile, k-split) items from a per-XCD counter instead of a fixed stride, so a workgroup that is placed late because
+ * another kernel (an overlapped all-reduce) holds its CU delays two items instead of its whole share.  Results are
+ * identical to uc2_gemm; kernels other than the ping-pong variants ignore the queue; NULL = uc2_gemm. */
+int uc2_gemm_queued(int dtype, int trans_a, int trans_b, int M, int N, int K, const void* A, int lda, const void* B, int ldb,
+                    void* C, int ldc, int c_is_f32, const float* bias, int epilogue, const void* aux_in, void* aux_out,
+                    int ldaux, int accumulate, int split_k, int variant, void* workspace, size_t workspace_bytes, int flags,
+                    void* queue, void* stream);
 int uc2_gemm_splitk_reduce(int M, int N, void* C, int ldc, int split_k, int accumulate, const void* workspace,
                            size_t workspace_bytes, void* stream);
 

@@ -31,6 +31,7 @@ def test_bench_self_launches_two_ranks_and_replicas_stay_in_sync():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["replicas_in_sync"] is True
     assert d["config"]["global_batch"] == 128 and d["value"] > 0
+    assert d["config"]["gemm_item_queue"] is True      # N > 1: GEMM work items come from the queue (two processes share this GPU)
 
 
 def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible():

@@ -434,6 +434,33 @@ def test_gemm_pingpong_persistent():
     assert rel_err(o, r) < 1e-4
 
 
+@pytest.mark.parametrize("ta,tb,M,N,K,split", [(False, False, 256 * 40, 768, 768, 1), (False, True, 256 * 23, 512, 1536, 1),
+                                               (True, True, 768, 512, 256 * 36, 6), (False, False, 512, 256, 128, 1)])
+def test_gemm_item_queue_gives_the_same_result_and_is_left_zeroed(ta, tb, M, N, K, split):
+    """uc2_gemm_queued (persistent ping-pong kernel, work items from a per-XCD queue from a workgroup's third item on):
+    bit-identical to the static partition -- every item is computed exactly once -- and the 9 queue cells are zero again
+    after every launch (the next launch on the stream relies on it)"""
+    a = rnd((K, M) if ta else (M, K), 1, dtype=torch.bfloat16)
+    b = rnd((K, N) if tb else (N, K), 2, 0.05, dtype=torch.bfloat16)
+    wg = ta and tb
+    bias = None if wg else rnd((N,), 3)
+    def run():
+        out = torch.zeros((M, N), dtype=torch.float32 if wg else torch.bfloat16, device=DEV)
+        for _ in range(3):                               # repeated launches reuse the queue
+            ops.gemm(a, b, M, N, K, ta=ta, tb=tb, bias=bias, out=out, accumulate=wg, split_k=split, variant=8)
+        return out
+    ref = run()
+    ops.GEMM_QUEUE = True
+    try:
+        got = run()
+        q = ops._gemm_queue(a.device)
+        torch.cuda.synchronize()
+        assert int(q.abs().sum()) == 0
+    finally:
+        ops.GEMM_QUEUE = False
+    assert torch.equal(got, ref)
+
+
 @pytest.mark.parametrize("variant", [8, 7, 99])
 def test_gemm_gelu_saves_derivative_for_the_backward(variant):
     """UC2_GEMM_AUX_DERIV: the GELU epilogue stores gelu'(pre) (not pre) and the DGELU epilogue multiplies by it as

@@ -23,6 +23,7 @@ SIGNATURES = {
     "uc2_last_error": (c_char_p, []),
     "uc2_device_info": (I, [P, P, P, I]),
     "uc2_gemm": (I, [I, I, I, I, I, I, P, I, P, I, P, I, I, P, I, P, P, I, I, I, I, P, SZ, I, P]),
+    "uc2_gemm_queued": (I, [I, I, I, I, I, I, P, I, P, I, P, I, I, P, I, P, P, I, I, I, I, P, SZ, I, P, P]),
     "uc2_gemm_splitk_reduce": (I, [I, I, P, I, I, I, P, SZ, P]),
     "uc2_fp8_amax": (I, [I, SZ, P, P, P]),
     "uc2_fp8_scale": (I, [P, P, P]),

@@ -303,11 +303,11 @@ extern "C" int uc2_gemm_splitk_reduce(int M, int N, void* C, int ldc, int split_
   return 0;
 }
 
-extern "C" int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K,
-                        const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_is_f32,
-                        const float* bias, int epilogue, const void* aux_in, void* aux_out, int ldaux,
-                        int accumulate, int split_k, int variant, void* workspace, size_t workspace_bytes, int flags,
-                        void* stream) {
+static int gemm_impl(int dtype, int trans_a, int trans_b, int M, int N, int K,
+                     const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_is_f32,
+                     const float* bias, int epilogue, const void* aux_in, void* aux_out, int ldaux,
+                     int accumulate, int split_k, int variant, void* workspace, size_t workspace_bytes, int flags,
+                     void* queue, void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
   UC2_CHECK_ARG(variant == -2 || variant == 99 || (variant >= 0 && variant <= 9));
   UC2_CHECK_ARG(M >= 0 && N >= 0 && K >= 0);
@@ -325,6 +325,7 @@ extern "C" int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K
   p.epi = epilogue; p.c_f32 = (dtype == 0) ? 1 : c_is_f32; p.accumulate = accumulate;
   p.split_k = split_k; p.atomic = (split_k > 1) ? 1 : 0; p.partial = nullptr; p.alpha = 1.0f; p.alpha_dev = nullptr; p.alpha_dev2 = nullptr;
   p.variant = variant; p.ws = reinterpret_cast<float*>(workspace); p.ws_bytes = workspace ? workspace_bytes : 0;
+  p.queue = reinterpret_cast<int*>(queue);
   {
     const int nbx = N / 256 > 0 ? N / 256 : 1;
     int cg = nbx;
@@ -359,4 +360,25 @@ extern "C" int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K
   if (epilogue == EPI_DGELU && aux_out != nullptr)      // kernels without the fused column sums: one more pass over C
     return uc2_colsum_accum(dtype, M, N, C, ldc, nullptr, reinterpret_cast<float*>(aux_out), stream);
   return 0;
+}
+
+extern "C" int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K,
+                        const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_is_f32,
+                        const float* bias, int epilogue, const void* aux_in, void* aux_out, int ldaux,
+                        int accumulate, int split_k, int variant, void* workspace, size_t workspace_bytes, int flags,
+                        void* stream) {
+  return gemm_impl(dtype, trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, c_is_f32, bias, epilogue, aux_in, aux_out, ldaux,
+                   accumulate, split_k, variant, workspace, workspace_bytes, flags, nullptr, stream);
+}
+// The same with a caller-owned item queue for the persistent ping-pong kernel (9 ints, zeroed once; the kernel leaves them
+// zeroed; one queue per stream that launches GEMMs concurrently): workgroups take their third and later work items from a
+// per-XCD counter instead of a fixed stride, so a workgroup that starts late (CUs held by a communication kernel) simply
+// takes fewer items.  Other kernels ignore it.
+extern "C" int uc2_gemm_queued(int dtype, int trans_a, int trans_b, int M, int N, int K,
+                               const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_is_f32,
+                               const float* bias, int epilogue, const void* aux_in, void* aux_out, int ldaux,
+                               int accumulate, int split_k, int variant, void* workspace, size_t workspace_bytes, int flags,
+                               void* queue, void* stream) {
+  return gemm_impl(dtype, trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, c_is_f32, bias, epilogue, aux_in, aux_out, ldaux,
+                   accumulate, split_k, variant, workspace, workspace_bytes, flags, queue, stream);
 }

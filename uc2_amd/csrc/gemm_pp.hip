@@ -341,7 +341,28 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     item_step = (G - xcd + 7) >> 3;                              // workgroups on this XCD
     item = beg + slot;
   }
-  if (item >= item_end) return;
+  // Item queue (GemmArgs::queue, optional): the first two items of a workgroup are the static ones (beg + slot and one
+  // stride further); from the third on the index comes from a per-XCD counter.  A workgroup that is placed late -- another
+  // kernel (an overlapped all-reduce) holds its CU -- then delays two items instead of its whole share.  The fetch for
+  // the item after next is issued by one lane at the start of an item (an ordinary vector atomic: counted vmcnt waits
+  // only get stricter by one operation while it is in flight) and consumed in that item's epilogue, where everything
+  // older has landed anyway; wave 0 publishes it through the first word of its transposition buffer (free between two
+  // epilogues) and every wave picks it up behind the next item barrier.  The last workgroup to leave zeroes the queue.
+  int* const queue = p.queue;
+  const int qslot = blockIdx.x & 7;
+  const int dyn0 = item - (int)(blockIdx.x >> 3) + 2 * item_step;
+  auto queue_leave = [&]() __attribute__((always_inline)) {
+    if (queue && threadIdx.x == 0) {
+      const int old = atomicAdd(queue + 8, 1);
+      if (old == (int)gridDim.x - 1) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) atomicExch(queue + i, 0);
+      }
+    }
+  };
+  if (item >= item_end) { queue_leave(); return; }
+  int nxt = item + item_step;                          // the item after the current one
+  int pend = 0;                                        // (wave 0, lane 0) ticket of the item after that
   // De-phasing: with equal tiles every CU reaches its epilogue at the same moment and the 256 store bursts (plus the
   // next tiles' first fetches) queue on HBM while the matrix pipes idle.  Four phase groups (by slot within the XCD)
   // start p.skew * ~8k cycles apart, so at most a quarter of the chip stores at a time.
@@ -491,7 +512,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     // k-tiles; every unit of the current item has been issued) fetch the NEXT item's first six units, in the order and
     // into the ring positions a prologue would use (nt is even).  The next item then starts with its operands in LDS
     // instead of issuing 96 KiB of LDS-DMA and waiting for it with the matrix pipe idle.
-    if (TAIL && !SW && more) setup(item + item_step);
+    if (TAIL && !SW && more) setup(nxt);
     PP_READ_A1(cb + 3 * PP_UNIT);
     if (!TAIL || f0 + 8 < nunits || more) PP_ISSUE(1, nb ^ 1);
     PP_SYNC_L((TAIL && !more) ? nunits - 5 - f0 : 4, 2);
@@ -577,7 +598,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     PP_STAMP(0);
     if (dbg && nitem_done == 3) { unsigned long long t64_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t64_) :: "memory"); ts[6] = (unsigned)t64_; }
-    more = item + item_step < item_end;
+    if (queue) {
+      if (nitem_done > 0) nxt = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(smem + 131072));
+      if (w == 0 && lane == 0) pend = __hip_atomic_fetch_add(queue + qslot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      nxt = item + item_step;
+    }
+    more = nxt < item_end;
     if (!(p.atomic & 0x4000)) {                        // (diagnostic 0x4000: epilogue only)
       using F = std::false_type; using T = std::true_type;
       PP_READ_B(bx, 1 * PP_UNIT);                      // B0 of k-tile 0 (later k-tiles get theirs one phase ahead)
@@ -586,25 +613,40 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
       body(T{}, F{}, kt);
       body(T{}, T{}, kt + 1);
     } else if (more) {
-      setup(item + item_step);
+      setup(nxt);
       PP_PROLOGUE();
     }
     // The next item's first six units are in flight or landed (issued by the tail above); the epilogue below touches
     // only the transposition buffers behind the ring.
     PP_STAMP(1);
     const int em0 = m0 + wr * RW, en0 = n0 + wc * 64, ez = zsplit;
-    item += item_step;
+    item = nxt;
     if (more) { m0 = m0x; n0 = n0x; nt = ntx; zsplit = zx; }
+    // (queue) the ticket fetched at the start of this item -> index of the item after the next one; the use makes hipcc wait
+    // for it here, after the epilogue arithmetic and before the stores; wave 0 writes it once its transposition buffer is free
+    int ticket_item = 0;
+    auto ticket_ready = [&]() __attribute__((always_inline)) {
+      if (queue && w == 0 && lane == 0) { ticket_item = dyn0 + pend; asm volatile("" : "+v"(ticket_item)); }
+    };
+    auto ticket_publish = [&]() __attribute__((always_inline)) {
+      if (queue && w == 0 && lane == 0) {
+        *reinterpret_cast<volatile int*>(smem + 131072) = ticket_item;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    };
     const bool store = !(p.atomic & 0x800);            // (diagnostic 0x800: main loop only)
     if (!store) {
+      ticket_ready(); ticket_publish();
       younger = GKT;
     } else if (TACC && p.partial) {                     // split-K item of a two-stage reduction (fp32 partial, plain stores)
       {
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const TpAddr tpa = tp_addr(lds0 + 131072u + (unsigned)w * 4096u, ln);
+        ticket_ready();
         pp_partial_store<HI>(p.partial + (size_t)ez * p.M * p.N, p.N, acc, em0, en0, ln, tpa);
       }
+      ticket_publish();
       younger = GKT + 2 * NST;
     } else if (TACC) {
       PpOut out;
@@ -626,6 +668,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
               if (EPI == EPI_GELU || EPI == EPI_GELU_D) asm volatile("" : "+v"(out.pre[hh][i][it]));
             }
       PP_STAMP(2);
+      ticket_ready(); ticket_publish();
       PP_STAMP(3);
       asm volatile("" : "+v"(ln));
       pp_epi_store<EPI, HI>(p, out, em0, en0, ln);
@@ -634,11 +677,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     } else {                                           // fp32 output (accumulate / split-K atomics): row segments per register
       bf16_tile_epilogue<false>(p, acc[0], em0, en0, 0, 0, lane, smem);
       bf16_tile_epilogue<false>(p, acc[1], em0 + 64, en0, 0, 0, lane, smem);
+      ticket_ready(); ticket_publish();
       younger = -1;                                     // (the atomics are younger than the staged units: uncounted -> wait for all)
     }
     ++nitem_done;
     if (!more) break;
   }
+  queue_leave();
   if (dbg) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) {

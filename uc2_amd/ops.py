@@ -155,6 +155,22 @@ rng = _Rng()
 # --------------------------------------------------------------------------------------
 # raw kernel wrappers
 # --------------------------------------------------------------------------------------
+# Item queue of the persistent ping-pong GEMM (include/uc2_hip.h uc2_gemm_queued): dynamic work distribution from the third
+# item of a workgroup on, for steps that overlap GEMMs with a communication kernel.  One 9-int queue per (device, stream):
+# launches on one stream are serialised and the kernel leaves its queue zeroed.  UC2_GEMM_QUEUE=1 / ops.GEMM_QUEUE = True.
+GEMM_QUEUE = False
+_GEMM_QUEUES = {}
+
+
+def _gemm_queue(device):
+    key = (device.index, stream())
+    q = _GEMM_QUEUES.get(key)
+    if q is None:
+        q = torch.zeros(16, dtype=torch.int32, device=device)
+        _GEMM_QUEUES[key] = q
+    return q
+
+
 def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=None, epi=EPI_NONE,
          aux_in=None, aux_out=None, accumulate=False, split_k=1, lda=None, ldb=None, ldc=None, variant=None, flags=0):
     """C[M,N] (=|+=) epi(sum_k A(m,k) B(n,k) + bias[n]); see uc2_amd/csrc/gemm.hip.
@@ -192,9 +208,14 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
     defer = two_stage and e0 is not None         # time the GEMM kernel alone: run the reduction pass separately
     if defer:
         flags |= GEMM_DEFER_REDUCE
-    call("uc2_gemm", dt(dtype), int(ta), int(tb), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc, int(c_f32),
-         ptr(bias), epi, ptr(aux_in), ptr(aux_out), ldaux, int(accumulate), split_k, variant,
-         ptr(ws), 0 if ws is None else ws.numel(), flags, stream())
+    if GEMM_QUEUE and dtype == torch.bfloat16:
+        call("uc2_gemm_queued", dt(dtype), int(ta), int(tb), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc, int(c_f32),
+             ptr(bias), epi, ptr(aux_in), ptr(aux_out), ldaux, int(accumulate), split_k, variant,
+             ptr(ws), 0 if ws is None else ws.numel(), flags, ptr(_gemm_queue(a.device)), stream())
+    else:
+        call("uc2_gemm", dt(dtype), int(ta), int(tb), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc, int(c_f32),
+             ptr(bias), epi, ptr(aux_in), ptr(aux_out), ldaux, int(accumulate), split_k, variant,
+             ptr(ws), 0 if ws is None else ws.numel(), flags, stream())
     if e0 is not None:
         e1.record()
         if defer:
@@ -1455,6 +1476,8 @@ def attn_probs_mean(qkv2, mask2d, B, L, nh, D):
 import os as _os
 if _os.environ.get("UC2_AUTOTUNE", "1") == "0":     # variable-shape runs that must never stall on a tuning pass
     AUTOTUNE = False
+if _os.environ.get("UC2_GEMM_QUEUE", "0") == "1":
+    GEMM_QUEUE = True
 if _os.environ.get("UC2_PP_SKEW"):          # e.g. "1:2,2:2" = skew 2 for the GELU and dGELU epilogue GEMMs
     PP_SKEW = {int(k): int(v) for k, v in (kv.split(":") for kv in _os.environ["UC2_PP_SKEW"].split(","))}
 if _os.environ.get("UC2_GEMM_PLANS", "1") != "0":
