@@ -270,6 +270,12 @@ class GradSync:
         self._red, self._views, self._done = _Reducer(), [], []
         for l in self.layers:
             l.grad_ready_hook = self._on_layer_done
+        if _world() > 1:
+            # collectives will run beside the backward GEMMs and hold CUs: persistent GEMMs take their items from the queue
+            import os
+            from .. import ops
+            if os.environ.get("UC2_GEMM_QUEUE", "1") != "0":
+                ops.GEMM_QUEUE = True
 
     def arm(self):
         self.armed = True
