@@ -73,6 +73,33 @@ def self_launch(a):
     return subprocess.call(cmd, env=env)
 
 
+def start_watchdog(n_gpus):
+    """N > 1: a rank that makes no progress for UC2_STEP_TIMEOUT seconds (default 240; 0 = off) -- a collective some rank never
+    joined, a wedged GPU -- dumps its stacks and leaves with exit code 3, so the launcher tears the job down and the run
+    fails loudly instead of hanging until somebody's outer limit.  (os._exit of this process; nothing is re-executed.)
+    Returns beat(): call it whenever a step, a fence or a set-up stage completes."""
+    import threading
+    state = {"t": time.monotonic()}
+    limit = float(os.environ.get("UC2_STEP_TIMEOUT", "240" if n_gpus > 1 else "0"))
+
+    def beat():
+        state["t"] = time.monotonic()
+    if limit <= 0:
+        return beat
+
+    def watch():
+        import faulthandler
+        while True:
+            time.sleep(2.0)
+            if time.monotonic() - state["t"] > limit:
+                sys.stderr.write("bench.py rank %s: no progress for %.0f s -- giving up\n" % (os.environ.get("RANK", "0"), limit))
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                sys.stderr.flush()
+                os._exit(3)
+    threading.Thread(target=watch, daemon=True).start()
+    return beat
+
+
 def make_cfg(layers):
     from uc2_amd.model.model import VLXLMRConfig
     d = dict(hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
@@ -290,8 +317,10 @@ def main():
     if os.environ.get("UC2_HANG_TRACE"):               # debugging aid: dump every thread's stack after N seconds and exit
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["UC2_HANG_TRACE"]), exit=True)
+    beat = start_watchdog(a.gpus)
     import torch
     import torch.distributed as dist
+    beat()                                             # (the first import of torch on a fresh box can take minutes)
     from uc2_amd import ops
     from uc2_amd.model.model import VLXLMRForPretraining
     from uc2_amd.optim.adamw import AdamW, clip_grad_norm_
@@ -332,12 +361,17 @@ def main():
             NativeComm.destroy()
         else:
             comm_path = "libuc2_hip.so uc2_comm_* (RCCL, library-owned side stream)"
+    # what RCCL itself reports, for the run record: ranks in the library's communicator (ncclCommCount; 0 = not in use) and
+    # the version of the librccl that was loaded
+    rccl_ranks = NativeComm.world()
+    rccl_version = NativeComm.version() if world > 1 else ""
 
     # the all-reduces overlap the backward GEMMs and hold CUs while they run: the persistent GEMM takes its work items from
     # the per-XCD queue then (include/uc2_hip.h uc2_gemm_queued; scratch/exp9.py: +25 % per launch with the static stride
     # under contention, +0 % with the queue).  At N = 1 nothing competes for CUs and the static stride is kept.
     if world > 1 and os.environ.get("UC2_GEMM_QUEUE", "1") != "0":
         ops.GEMM_QUEUE = True
+    beat()
     ops.rng.manual_seed(20260101 + rank, dev)              # dropout streams differ per rank
     torch.manual_seed(0)                                   # weights seed 0 (random init, N(0, 0.02))
     model = VLXLMRForPretraining(make_cfg(a.layers), img_dim=IMG_DIM, img_label_dim=1601)
@@ -347,6 +381,7 @@ def main():
     broadcast_tensors([p.data for p in model.parameters()], 0)        # pretrain.py:457
     opt = AdamW(param_groups(model, 0.01), lr=4e-5, betas=(0.9, 0.98))
     sync = GradSync(model) if world > 1 else None
+    beat()
     st.sync_shadow()
     st.auto_sync = False            # AdamW rewrites the bf16 copies in its own pass from here on
 
@@ -364,6 +399,7 @@ def main():
         all_reduce_and_rescale_tensors(grads, float(1))              # pretrain.py:564-566
         _, coef = clip_grad_norm_([p for p in model.parameters() if p.grad is not None], 5.0, fused=True)
         opt.step(grad_scale=coef, zero_grad=True)
+        beat()
         return loss
 
     def fence():
@@ -371,6 +407,7 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        beat()
 
     def timed(fn, warmup, steps):
         """W untimed + EXACTLY K timed calls of fn(i), bracketed by barrier + synchronize; max over ranks"""
@@ -483,9 +520,10 @@ def main():
                                    % (a.layers, a.task.upper()),
                        "pairs_per_gpu_per_step": a.batch, "global_batch": a.batch * world,
                        "seq_len": T_TXT + N_REG, "parallelism": "dp%d" % world, "final_loss": round(lossv, 4), "replicas_in_sync": in_sync,
-                       "gradient_allreduce": comm_path, "gemm_item_queue": bool(ops.GEMM_QUEUE),
+                       "gradient_allreduce": comm_path, "rccl_ranks": rccl_ranks, "rccl_version": rccl_version,
+                       "gemm_item_queue": bool(ops.GEMM_QUEUE),
                        "gemm_plans": {"%s%s %dx%dx%d" % ("T" if k[0] else "N", "T" if k[1] else "N", k[2], k[3], k[4]):
-                                      "%s split %d" % ("generic" if v[0] == 99 else "ping-pong" if v[0] == 8 else "ring v%d" % v[0], v[1])
+                                      "%s split %d" % ("generic" if v[0] == 99 else "ping-pong" if v[0] == 8 else "ping-pong 192" if v[0] == 9 else "ping-pong rolling" if v[0] == 10 else "ring v%d" % v[0], v[1])
                                       for k, v in sorted(ops._TUNE.items())}},
             "mfma_frac_encoder": round(value * ENC_GFLOP_PER_PAIR * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": {"bound": "mfma", "kernel": kname,

@@ -51,8 +51,9 @@ int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, const voi
              void* stream);
 /* Per-call plan -- the library keeps NO process-global kernel-selection state and reads no environment variables:
  *   variant    UC2_GEMM_AUTO = the library's default kernel for the shape; UC2_GEMM_GENERIC = the register-staged
- *              kernel (any shape/alignment); 0..9 = one specific kernel (0-2 LDS-DMA rings, 6/7 wave-specialised
- *              rings, 8 = persistent ping-pong 256x256, 9 = ping-pong with 192-row tiles).  A variant that does not
+ *              kernel (any shape/alignment); 0..10 = one specific kernel (0-2 LDS-DMA rings, 6/7 wave-specialised
+ *              rings, 8 = persistent ping-pong 256x256, 9 = ping-pong with 192-row tiles, 10 = ping-pong whose epilogue rolls into the
+ *              next tile's main loop; calls it does not cover run as 8).  A variant that does not
  *              support the shape falls back to the generic kernel.  uc2_amd/ops.py::gemm_plan picks it per shape.
  *   workspace  optional caller-owned device memory (>= split_k*M*N*4 bytes, 16-byte aligned) for split-K weight
  *              gradients: partial tiles are stored plainly and reduced in a second pass instead of fp32 atomics
@@ -246,7 +247,8 @@ int uc2_comm_unique_id_bytes(void);
 int uc2_comm_unique_id(void* out, int bytes);                       /* rank 0; carry the bytes to the other ranks out of band */
 int uc2_comm_init(int rank, int world, const void* unique_id, int bytes);
 int uc2_comm_rank(void);
-int uc2_comm_world(void);
+int uc2_comm_world(void);                                           /* ranks RCCL itself counted (ncclCommCount) at init; 0 = no communicator */
+int uc2_comm_version(char* out, int bytes);                         /* "major.minor.patch" of the loaded librccl (hvd.init has no counterpart; for run records) */
 int uc2_comm_allreduce_bucket(void* buf, size_t count, int dtype, int average, void* compute_stream);
 int uc2_comm_broadcast(void* buf, size_t count, int dtype, int root, void* compute_stream);
 int uc2_comm_wait(void* stream);

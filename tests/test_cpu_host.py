@@ -69,6 +69,13 @@ def test_argument_errors_do_not_need_a_gpu():
     assert b"dtype" in lib.uc2_last_error()
     with pytest.raises(_lib.Uc2Error):
         _lib.check(rc)
+    # a gemm variant the library does not know is an argument error, not a silent fall-back
+    rc = lib.uc2_gemm(1, 0, 0, 256, 256, 256, 16, 256, 16, 256, 16, 256, 0, None, 0, None, None, 0, 0, 1, 11, None, 0, 0, None)
+    assert rc < 0 and b"variant" in lib.uc2_last_error()
+    # the IPOT kernel keeps 3 T R floats in LDS: 128 x 128 (196 KB) does not fit a workgroup and must be rejected as an
+    # argument error up front (it used to fail at launch); every pointer is a dummy, nothing is dereferenced before the check
+    rc = lib.uc2_ot_fwd(1, 1, 256, 128, 128, 64, 16, 16, 16, 16, 0.5, 50, 16, 16, 16, None)
+    assert rc == -1 and b"LDS" in lib.uc2_last_error()
 
 
 # ------------------------------------------------------------------------------------------ module surface
@@ -229,7 +236,16 @@ D.all_reduce_and_rescale_tensors([p.grad.data for p in enc.parameters()] + loose
 mean = sum(range(world)) / world
 assert all(torch.allclose(p.grad, torch.full_like(p, mean)) for p in enc.parameters())
 assert torch.allclose(loose[0], torch.full((5, 3), mean)) and torch.allclose(loose[1], torch.full((7,), 2 * mean))
-# 3. python-object helpers
+# 3. score rows of a text set dealt out as ids[rank::size] (data/data.py:201-203) with n_txt %% world != 0:
+#    hvd.allgather semantics (itm.py:496) -- ragged first dimension, rows back in rank order
+from uc2_amd.eval.itm import allgather_rows
+n_txt, n_img = 7, 5
+full = torch.arange(n_txt * n_img, dtype=torch.float32).view(n_txt, n_img)
+mine = full[rank::world].contiguous()
+got = allgather_rows(mine)
+want = torch.cat([full[r::world] for r in range(world)], 0)
+assert got.shape == (n_txt, n_img) and torch.equal(got, want), "ragged all-gather mismatch"
+# 4. python-object helpers
 assert D.all_gather_list({"rank": rank}) == [{"rank": r} for r in range(world)]
 assert D.any_broadcast("task-%%d" %% rank, 0) == "task-0"
 dist.barrier(); dist.destroy_process_group()

@@ -51,7 +51,10 @@ def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible():
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["replicas_in_sync"] is True
-    assert "uc2_comm" in d["config"]["gradient_allreduce"] or "torch.distributed/nccl" in d["config"]["gradient_allreduce"]
+    # the library's own communicator must be the data plane (a silent fall-back to torch.distributed would pass the sync
+    # check too), and RCCL itself must have counted both ranks
+    assert "uc2_comm" in d["config"]["gradient_allreduce"], d["config"]["gradient_allreduce"]
+    assert d["config"]["rccl_ranks"] == 2 and d["config"]["rccl_version"]
 
 
 def test_native_rccl_communicator_single_rank():
@@ -77,17 +80,27 @@ def test_native_rccl_communicator_single_rank():
         NativeComm.wait()
         torch.cuda.synchronize()
         assert torch.equal(h, h2) and torch.equal(x, y)
-        # through the reference-shaped entry point, on a gradient arena: small spans stay fp32 (exact),
-        # the >= 1M-element span takes the bf16 staging path (one rounding), then / rescale_denom
+        assert NativeComm.world() == 1 and NativeComm.version().count(".") == 2
+        # through the reference-shaped entry point, on a gradient arena, then / rescale_denom: fp32 reduction by default
+        # (exact for one rank); with the bf16 tail opted in (UC2_ALLREDUCE_TAIL=bf16) the >= 1M-element span is staged
+        # through bf16 (one rounding)
+        from uc2_amd.utils import distributed as D
         m = torch.nn.Sequential(torch.nn.Linear(1500, 1024), torch.nn.Linear(64, 8)).to(dev)
         st = ParamStore(m)
-        for p in m.parameters():
-            st.grad_buf(p).copy_(torch.randn_like(p))
-        ref = [p.grad.clone() for p in m.parameters()]
-        all_reduce_and_rescale_tensors([p.grad.data for p in m.parameters()], 2.0)
-        torch.cuda.synchronize()
-        for p, r in zip(m.parameters(), ref):           # adjacent parameters travel as one span: all of it rounds to bf16 once
-            assert torch.allclose(p.grad, r.to(torch.bfloat16).float() / 2.0, rtol=1e-6, atol=0)
+        assert D.TAIL_BF16 is False
+        for tail_bf16 in (False, True):
+            D.TAIL_BF16 = tail_bf16
+            try:
+                for p in m.parameters():
+                    st.grad_buf(p).copy_(torch.randn_like(p))
+                ref = [p.grad.clone() for p in m.parameters()]
+                all_reduce_and_rescale_tensors([p.grad.data for p in m.parameters()], 2.0)
+                torch.cuda.synchronize()
+            finally:
+                D.TAIL_BF16 = False
+            for p, r in zip(m.parameters(), ref):       # adjacent parameters travel as one span: all of it rounds to bf16 once
+                want = (r.to(torch.bfloat16).float() if tail_bf16 else r) / 2.0
+                assert torch.allclose(p.grad, want, rtol=1e-6, atol=0)
         broadcast_tensors([p.data for p in m.parameters()], 0)
         torch.cuda.synchronize()
     finally:

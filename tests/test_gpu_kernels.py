@@ -535,6 +535,66 @@ def test_gemm_pingpong_192_row_tiles(tb, epi, M, N, K):
     assert rel_err(o1.float(), ref.float()) < 3e-3
 
 
+@pytest.mark.parametrize("tb,epi,bias", [(False, "none", True), (False, "gelu", True), (False, "tanh", True), (True, "none", False)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (4096, 768, 768), (16384, 2304, 512), (9472, 768, 3072)])
+def test_gemm_rolling_epilogue_equals_pingpong(tb, epi, bias, M, N, K):
+    """variant 10 (gemm_roll.hip: the epilogue of a tile rides in the L sections around the item boundary, the k-tile stream never
+    stops): bit-identical to the ping-pong kernel (same MFMA order, same rounding), on one tile, a few items per workgroup and
+    many; three launches into NaN-filled outputs (race screen: every element written, identically, every time)"""
+    a = rnd((M, K), 1, dtype=torch.bfloat16)
+    b = rnd((K, N) if tb else (N, K), 2, 0.05, dtype=torch.bfloat16)
+    bv = rnd((N,), 3) if bias else None
+    code = {"none": ops.EPI_NONE, "gelu": ops.EPI_GELU, "tanh": ops.EPI_TANH}[epi]
+    ref = ops.gemm(a, b, M, N, K, tb=tb, bias=bv, epi=code, variant=8)
+    gen = ops.gemm(a, b, M, N, K, tb=tb, bias=bv, epi=code, variant=GENERIC)
+    assert rel_err(ref.float(), gen.float()) < 3e-3
+    for _ in range(3):
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.gemm(a, b, M, N, K, tb=tb, bias=bv, epi=code, out=out, variant=10)
+        assert torch.equal(out, ref)
+
+
+def test_gemm_rolling_variant_falls_back_to_pingpong_where_it_does_not_apply():
+    """variant 10 only takes bf16-output forward (bias) / input-gradient (no bias) GEMMs without aux streams and with >= 4
+    k-tiles; every other call that names it runs on variant 8 and gives variant 8's result"""
+    M, N, K = 512, 512, 128                                  # 2 k-tiles
+    a, b, bv = rnd((M, K), 1, dtype=torch.bfloat16), rnd((N, K), 2, 0.05, dtype=torch.bfloat16), rnd((N,), 3)
+    assert torch.equal(ops.gemm(a, b, M, N, K, bias=bv, variant=10), ops.gemm(a, b, M, N, K, bias=bv, variant=8))
+    K = 512
+    a, b = rnd((M, K), 1, dtype=torch.bfloat16), rnd((K, N), 2, 0.05, dtype=torch.bfloat16)
+    aux = rnd((M, N), 4, dtype=torch.bfloat16)
+    r10 = ops.gemm(a, b, M, N, K, tb=True, epi=ops.EPI_ADD, aux_in=aux, variant=10)
+    assert torch.equal(r10, ops.gemm(a, b, M, N, K, tb=True, epi=ops.EPI_ADD, aux_in=aux, variant=8))
+
+
+@pytest.mark.parametrize("epi", ["none", "gelu", "gelu_d", "add", "tanh", "dgelu", "mul"])
+def test_gemm_pingpong_epilogue_route_without_lane_exchange(epi):
+    """the ping-pong kernel's epilogue moves 8-byte pieces straight from the accumulator layout into the transposition buffer
+    (pp_epi_compute_q); the older route through v_permlane32_swap stays behind UC2_GEMM_DIAG(0x20): same bits out, second
+    stream and bias-gradient column sums included"""
+    M, N, K = 2048, 768, 512
+    tb = epi in ("dgelu", "mul")
+    a = rnd((M, K), 1, dtype=torch.bfloat16)
+    b = rnd((K, N) if tb else (N, K), 2, 0.05, dtype=torch.bfloat16)
+    bv = None if tb else rnd((N,), 3)
+    aux = rnd((M, N), 4, dtype=torch.bfloat16)
+    code = {"none": ops.EPI_NONE, "gelu": ops.EPI_GELU, "gelu_d": ops.EPI_GELU, "add": ops.EPI_ADD, "tanh": ops.EPI_TANH,
+            "dgelu": ops.EPI_DGELU, "mul": ops.EPI_DGELU}[epi]
+    fl = ops.GEMM_AUX_DERIV if epi in ("gelu_d", "mul") else 0
+
+    def run(flags):
+        second = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV) if code == ops.EPI_GELU else (
+            torch.zeros(N, dtype=torch.float32, device=DEV) if code == ops.EPI_DGELU else None)
+        o = ops.gemm(a, b, M, N, K, tb=tb, bias=bv, epi=code, aux_in=aux if code in (ops.EPI_ADD, ops.EPI_DGELU) else None,
+                     aux_out=second, variant=8, flags=fl | flags)
+        return o, second
+    o_new, s_new = run(0)
+    o_old, s_old = run(0x20 << 8)
+    assert torch.equal(o_new, o_old)
+    if s_new is not None:
+        assert torch.equal(s_new, s_old) if s_new.dtype == torch.bfloat16 else rel_err(s_new, s_old) < 1e-5
+
+
 def test_gemm_pingpong_skew_and_deferred_reduce():
     """start skew between phase groups changes timing only; the split-K reduction pass run on its own
     (UC2_GEMM_DEFER_REDUCE + uc2_gemm_splitk_reduce) equals the fused call; without a workspace the same call

@@ -77,6 +77,7 @@ SIGNATURES = {
     "uc2_comm_init": (I, [I, I, P, I]),
     "uc2_comm_rank": (I, []),
     "uc2_comm_world": (I, []),
+    "uc2_comm_version": (I, [P, I]),
     "uc2_comm_allreduce_bucket": (I, [P, SZ, I, I, P]),
     "uc2_comm_broadcast": (I, [P, SZ, I, I, P]),
     "uc2_comm_wait": (I, [P]),

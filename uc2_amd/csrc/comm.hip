@@ -13,6 +13,7 @@
 #include "common.h"
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <stdio.h>
 #include <string.h>
 
 namespace {
@@ -21,6 +22,8 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -41,6 +44,7 @@ int rccl_open() {
   if (!g_rccl.so) { uc2_set_error(__FILE__, __LINE__, "librccl.so not found (dlopen)"); return -2; }
 #define UC2_SYM(F, N) do { *(void**)(&g_rccl.F) = dlsym(g_rccl.so, N); if (!g_rccl.F) { uc2_set_error(__FILE__, __LINE__, "librccl: missing symbol " N); return -2; } } while (0)
   UC2_SYM(GetUniqueId, "ncclGetUniqueId"); UC2_SYM(CommInitRank, "ncclCommInitRank"); UC2_SYM(CommDestroy, "ncclCommDestroy");
+  UC2_SYM(CommCount, "ncclCommCount"); UC2_SYM(GetVersion, "ncclGetVersion");
   UC2_SYM(AllReduce, "ncclAllReduce"); UC2_SYM(Broadcast, "ncclBroadcast"); UC2_SYM(GetErrorString, "ncclGetErrorString");
 #undef UC2_SYM
   return 0;
@@ -70,15 +74,42 @@ extern "C" int uc2_comm_init(int rank, int world, const void* unique_id, int byt
   if (int rc = rccl_open()) return rc;
   ncclUniqueId id;
   memcpy(id.internal, unique_id, NCCL_UNIQUE_ID_BYTES);
-  UC2_NCCL(g_rccl.CommInitRank(&g_comm.comm, world, id, rank));
-  UC2_HIP(hipStreamCreateWithFlags(&g_comm.side, hipStreamNonBlocking));
-  UC2_HIP(hipEventCreateWithFlags(&g_comm.ready, hipEventDisableTiming));
-  UC2_HIP(hipEventCreateWithFlags(&g_comm.done, hipEventDisableTiming));
-  g_comm.rank = rank; g_comm.world = world; g_comm.pending = false;
+  // built in a local object and published only when every piece exists: a failed stream / event creation must not
+  // leave a communicator that looks initialised (comm != nullptr) with null handles and refuses a second init
+  Comm c;
+  UC2_NCCL(g_rccl.CommInitRank(&c.comm, world, id, rank));
+  hipError_t e = hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c.ready, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c.done, hipEventDisableTiming);
+  int count = 0;
+  ncclResult_t r = (e == hipSuccess) ? g_rccl.CommCount(c.comm, &count) : ncclSuccess;
+  if (e != hipSuccess || r != ncclSuccess || count != world) {
+    if (c.done) (void)hipEventDestroy(c.done);
+    if (c.ready) (void)hipEventDestroy(c.ready);
+    if (c.side) (void)hipStreamDestroy(c.side);
+    g_rccl.CommDestroy(c.comm);
+    if (e != hipSuccess) { uc2_set_error(__FILE__, __LINE__, hipGetErrorString(e)); return (int)e; }
+    if (r != ncclSuccess) { uc2_set_error(__FILE__, __LINE__, g_rccl.GetErrorString(r)); return 10000 + (int)r; }
+    uc2_set_error(__FILE__, __LINE__, "ncclCommCount disagrees with the world size passed to uc2_comm_init");
+    return -3;
+  }
+  c.rank = rank; c.world = count; c.pending = false;
+  g_comm = c;
   return 0;
 }
 extern "C" int uc2_comm_rank(void) { return g_comm.comm ? g_comm.rank : -1; }
+// ranks in the communicator as RCCL itself counted them at init (ncclCommCount), 0 when there is none
 extern "C" int uc2_comm_world(void) { return g_comm.comm ? g_comm.world : 0; }
+// "major.minor.patch" of the loaded librccl (ncclGetVersion); works before uc2_comm_init
+extern "C" int uc2_comm_version(char* out, int bytes) {
+  UC2_CHECK_ARG(out && bytes >= 16);
+  if (int rc = rccl_open()) return rc;
+  int v = 0;
+  UC2_NCCL(g_rccl.GetVersion(&v));
+  const int major = v >= 10000 ? v / 10000 : v / 1000, minor = v >= 10000 ? (v % 10000) / 100 : (v % 1000) / 100, patch = v % 100;
+  snprintf(out, bytes, "%d.%d.%d", major, minor, patch);
+  return 0;
+}
 
 static int comm_dtype(int dtype, ncclDataType_t* t) {
   if (dtype == 0) { *t = ncclFloat32; return 0; }

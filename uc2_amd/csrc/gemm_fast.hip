@@ -359,6 +359,8 @@ static void ws_launch1(const GemmArgs& p, hipStream_t st) {
 
 bool uc2_gemm_pp_supported(int trans_a, int trans_b, int c_f32, int epi, int tile_rows);        // gemm_pp.hip
 void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st, int tile_rows);
+bool uc2_gemm_roll_supported(const GemmArgs& p, int trans_a, int trans_b);                        // gemm_roll.hip
+void uc2_gemm_roll_launch(const GemmArgs& p, int trans_b, hipStream_t st);
 void uc2_splitk_reduce(const GemmArgs& p, hipStream_t st);                                        // gemm.hip
 
 // ------------------------------------------------------------------------------------------------------
@@ -406,8 +408,10 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
   if (!p.a_vec || !p.b_vec) return 0;
   if (trans_a ? ((p.M & 7) != 0 || p.M < 8) : (p.M < 1)) return 0;
   if (trans_b ? ((p.N & 7) != 0 || p.N < 8) : (p.N < 1)) return 0;
-  const int variant = p.variant;                     // per call (uc2_gemm's `variant` argument), never process state
+  int variant = p.variant;                           // per call (uc2_gemm's `variant` argument), never process state
   if (variant == 99) return 0;                       // caller asked for the generic kernel
+  const bool want_roll = variant == 10;              // rolling-epilogue ping-pong kernel (gemm_roll.hip); else the plain one
+  if (want_roll) variant = 8;
   if (variant == 8 || variant == 9) {
     // ping-pong kernel: whole 256x256 (variant 9: 192x256) tiles, >= 2 k-tiles per split, and (bf16 output) an epilogue
     // made of whole 16-byte accesses; anything else runs on the ring kernels above / the generic kernel
@@ -430,6 +434,7 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
   // skew is off unless the call asks for it: back-to-back launches of the double-store GELU GEMM gained 16 % from
   // de-phasing, inside the training step no kernel moved
   if (variant == 9) { uc2_gemm_pp_launch(pd, trans_a, trans_b, st, 192); return 2; }
+  if (want_roll && uc2_gemm_roll_supported(pd, trans_a, trans_b)) { uc2_gemm_roll_launch(pd, trans_b, st); return 2; }
   if (variant == 8) {
     const size_t need = (size_t)p.split_k * p.M * p.N * sizeof(float);
     if (p.c_f32 && p.split_k > 1 && p.ws && need <= p.ws_bytes && (p.N & 3) == 0 && (p.ldc & 3) == 0 &&

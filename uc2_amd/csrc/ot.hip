@@ -176,6 +176,15 @@ extern "C" int uc2_ot_fwd(int dtype, int B, int L, int T, int R, int H, const vo
   UC2_CHECK_ARG(T >= 1 && R >= 1 && T <= OT_MAXN && R <= OT_MAXN && (H % 4) == 0 && L >= 1 && iters >= 0 && beta > 0.f);
   if (B <= 0) return 0;
   UC2_CHECK_ARG(seq && scatter && txt_pad && img_pad && dist && Tm && ws);
+  const size_t smem = ((size_t)3 * T * R + T + R + 8) * sizeof(float);
+  {   // cost, transport plan and kernel matrices live in LDS for the 50 iterations: 3 T R floats must fit one workgroup's share
+    int dev = 0, lim = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) lim = 64 * 1024;
+    if (smem > (size_t)lim) {
+      uc2_set_error(__FILE__, __LINE__, "uc2_ot_fwd: T * R too large for the LDS-resident IPOT kernel (3 * T * R * 4 bytes must fit one workgroup's LDS)");
+      return -1;
+    }
+  }
   const int P = T + R;
   float* xn = reinterpret_cast<float*>(ws);
   float* nrm = xn + (size_t)B * P * H;
@@ -184,7 +193,6 @@ extern "C" int uc2_ot_fwd(int dtype, int B, int L, int T, int R, int H, const vo
   if (dtype == 0) hipLaunchKernelGGL(ot_gather_norm_kernel<float>, dim3(B), dim3(256), 0, st, L, P, H, (const float*)seq, scatter, 1e-5f, xn, nrm, inv);
   else hipLaunchKernelGGL(ot_gather_norm_kernel<bf16>, dim3(B), dim3(256), 0, st, L, P, H, (const bf16*)seq, scatter, 1e-5f, xn, nrm, inv);
   UC2_LAUNCH_CHECK();
-  const size_t smem = ((size_t)3 * T * R + T + R + 8) * sizeof(float);
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)ot_ipot_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { uc2_set_error(__FILE__, __LINE__, hipGetErrorString(e)); return (int)e; }

@@ -85,16 +85,32 @@ def itm_eval(score_matrix, txt_ids, img_ids, txt2img, img2txts, reference_row_te
             'r_mean': (tr_mean + ir_mean) / 2}
 
 
+def allgather_rows(x):
+    """hvd.allgather(x) (itm.py:496): concatenation over ranks along dim 0 where every rank may hold a DIFFERENT number
+    of rows -- the text ids are dealt out as ids[rank::size] (data/data.py:201-203), so n_txt % world != 0 gives ragged
+    shards (COCO: 25 010 texts on 8 ranks).  Row counts are exchanged first; shards are padded to the longest for the
+    fixed-shape all_gather and trimmed again."""
+    import torch.distributed as dist
+    world = _world()
+    n = torch.tensor([x.shape[0]], dtype=torch.long, device=x.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    nmax = max(counts)
+    if x.shape[0] < nmax:
+        x = torch.cat([x, x.new_zeros((nmax - x.shape[0],) + tuple(x.shape[1:]))], 0)
+    parts = [torch.empty_like(x) for _ in range(world)]
+    dist.all_gather(parts, x.contiguous())
+    return torch.cat([p[:c] for p, c in zip(parts, counts)], 0)
+
+
 @torch.no_grad()
 def evaluate(model, eval_loader):
     """itm.py:492-513: local score rows -> gathered over ranks -> metrics on rank 0"""
     score_matrix = inference(model, eval_loader)
     dset = eval_loader.dataset
     if _world() > 1:
-        import torch.distributed as dist
-        parts = [torch.empty_like(score_matrix) for _ in range(_world())]
-        dist.all_gather(parts, score_matrix)
-        score_matrix = torch.cat(parts, 0)
+        score_matrix = allgather_rows(score_matrix)
     all_txt_ids = [i for ids in all_gather_list(dset.ids) for i in ids]
     if _rank() != 0:
         return {}

@@ -37,6 +37,8 @@ class GemmTimer:
         tacc = b(not atomic)
         if variant in (8, 9):
             return "gemm_bf16_pp_kernel<%s, %s, %s, %d, %d>" % (b(ta), b(tb), b(not atomic), epi, 2 if variant == 8 else 1)
+        if variant == 10:
+            return "gemm_bf16_roll_kernel<%s, %d, %s>" % (b(tb), epi, b(not tb))
         if variant == 99:
             return "gemm_bf16_kernel<%s, %s, %s>" % (b(ta), b(tb), tacc)
         if variant in (6, 7):
@@ -220,7 +222,7 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
         e1.record()
         if defer:
             call("uc2_gemm_splitk_reduce", M, N, ptr(out), ldc, split_k, int(accumulate), ptr(ws), ws.numel(), stream())
-        if variant in (8, 9):  # ping-pong kernel: transposed accumulators unless fp32 atomics; the epilogue kind is a template argument
+        if variant in (8, 9, 10):  # ping-pong kernels: transposed accumulators unless fp32 atomics; the epilogue kind is a template argument
             epi_t = int(epi) + 4 if (flags & GEMM_AUX_DERIV and epi in (EPI_GELU, EPI_DGELU)) else int(epi)   # EPI_GELU_D = 5, EPI_MUL = 6
             key = (bool(ta), bool(tb), variant, bool(c_f32 and not two_stage), epi_t)
         else:
@@ -234,15 +236,17 @@ _SPLITK_WS = {}
 
 def _splitk_workspace(device, nbytes):
     """caller-owned device scratch for the two-stage split-K reduction of the ping-pong kernel, handed to uc2_gemm with
-    each call: grown on demand, one per device; every user runs on torch's current stream, in order.  None when it
+    each call: grown on demand, one per (device, stream); every user runs on that stream, in order.  None when it
     cannot be (re)allocated (stream capture): the kernel then reduces with fp32 atomics."""
-    key = (device.type, device.index)
-    ws = _SPLITK_WS.get(key)
+    key = (device.type, device.index, stream())      # per stream, like the item queues: two streams that both run split-K
+    ws = _SPLITK_WS.get(key)                          # GEMMs (WGRAD_SIDE_STREAM) must not share one set of partial tiles
     if ws is None or ws.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
             return None
-        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
-        _SPLITK_WS[key] = ws
+        new = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        if ws is not None:
+            ws.record_stream(torch.cuda.current_stream(device))      # the old buffer may still be read by kernels in flight
+        _SPLITK_WS[key] = ws = new
     return ws
 
 
@@ -272,7 +276,7 @@ def _plan_fits(plan, key):
     """can the kernel of `plan` run the shape `key` (else the library would silently take its generic kernel)"""
     v, sp = plan
     ta, tb, M, N, K, wgrad = key
-    if v in (8, 9):
+    if v in (8, 9, 10):
         rows = 192 if v == 9 else 256
         kt = K // 64
         per = ((kt + sp - 1) // sp + 1) & ~1
@@ -280,7 +284,7 @@ def _plan_fits(plan, key):
     if wgrad and sp * 1024 > K:
         return False
     return K % 64 == 0
-_FWD_CANDIDATES = ((99, 1), (0, 1), (1, 1), (2, 1), (6, 1), (7, 1), (8, 1))     # (kernel variant, split_k); 99 = generic kernel, 8 = ping-pong
+_FWD_CANDIDATES = ((99, 1), (0, 1), (1, 1), (2, 1), (6, 1), (7, 1), (8, 1), (10, 1))     # (kernel variant, split_k); 99 = generic kernel, 8 = ping-pong, 10 = ping-pong with the rolling epilogue
 _WGRAD_SPLITS = (2, 3, 4, 6, 8, 12, 16)
 
 
@@ -372,9 +376,11 @@ def gemm_plan(dtype, ta, tb, M, N, K, wgrad=False):
         cands = list(dict.fromkeys(cands))
     best, best_t = default, None
     timer_was, GEMM_TIMER = GEMM_TIMER, None          # tuning launches are not part of anybody's timed region
+    # forward GEMMs (X W^T) are timed with a bias like the encoder's (the rolling-epilogue kernel only takes those)
+    tbias = torch.zeros(N, dtype=torch.float32, device=dev) if (not wgrad and not ta and not tb) else None
     try:
         for v, sp in cands:
-            t = _time_gemm(lambda: gemm(a, b, M, N, K, ta=ta, tb=tb, out=out, accumulate=wgrad, split_k=sp, variant=v))
+            t = _time_gemm(lambda: gemm(a, b, M, N, K, ta=ta, tb=tb, out=out, bias=tbias, accumulate=wgrad, split_k=sp, variant=v))
             if best_t is None or t < best_t:
                 best, best_t = (v, sp), t
     finally:
@@ -391,7 +397,7 @@ def _gemm_planned(a, b, M, N, K, ta, tb, wgrad=False, **kw):
     """one GEMM with its tuned (variant, split_k) plan, passed to the library with the call"""
     v, sp = gemm_plan(a.dtype, ta, tb, M, N, K, wgrad)
     flags = kw.pop("flags", 0)
-    if PP_SKEW and v in (8, 9):
+    if PP_SKEW and v in (8, 9, 10):
         flags |= (PP_SKEW.get(kw.get("epi", EPI_NONE), 0) & 15) << 4
     return gemm(a, b, M, N, K, ta=ta, tb=tb, split_k=sp, variant=v, flags=flags, **kw)
 

@@ -18,9 +18,11 @@ import torch.distributed as dist
 from .. import _lib
 
 # The gradient tail (embeddings + heads: 0.77 GB of fp32, final only when backward ends, so its all-reduce is exposed)
-# is reduced as bf16 on the GPU data paths -- the reference reduces fp16 gradients too (apex O2 + Horovod,
-# pretrain.py:557-566).  Encoder-layer buckets overlap with backward and stay fp32.  UC2_ALLREDUCE_TAIL=fp32 turns it off.
-TAIL_BF16 = os.environ.get("UC2_ALLREDUCE_TAIL", "bf16") == "bf16"
+# CAN be reduced as bf16 on the GPU data paths (UC2_ALLREDUCE_TAIL=bf16) -- the reference reduces fp16 gradients too (apex
+# O2 + Horovod, pretrain.py:557-566) -- but bf16 carries three mantissa bits fewer than fp16, and no run with more than
+# one rank has compared it with the fp32 reduction yet: the default is the fp32 reduction, bf16 is opt-in.
+# Encoder-layer buckets overlap with backward and are always fp32.
+TAIL_BF16 = os.environ.get("UC2_ALLREDUCE_TAIL", "fp32") == "bf16"
 _TAIL_MIN = 1 << 20              # elements; smaller spans are not worth two cast passes
 
 
@@ -29,6 +31,7 @@ class NativeComm:
     ordered against the compute stream with events.  The 128-byte unique id travels over the torch.distributed control
     group that the launcher (torch.distributed.run) set up -- any backend -- exactly once."""
     active = False
+    _atexit = False
 
     @classmethod
     def init(cls, device):
@@ -54,7 +57,27 @@ class NativeComm:
         torch.cuda.set_device(device)
         _lib.check(lib.uc2_comm_init(rank, world, idb, nb))
         cls.active = True
+        if not cls._atexit:
+            import atexit
+            atexit.register(cls.destroy)                     # ncclCommDestroy + stream / events, once, at interpreter exit
+            cls._atexit = True
         return True
+
+    @staticmethod
+    def world():
+        """ranks the RCCL communicator itself reports (ncclCommCount); 0 when it is not up"""
+        return int(_lib.load().uc2_comm_world()) if NativeComm.active else 0
+
+    @staticmethod
+    def version():
+        """RCCL version string of the loaded librccl ("" when the library cannot be loaded)"""
+        import ctypes
+        buf = ctypes.create_string_buffer(64)
+        try:
+            _lib.load().uc2_comm_version(buf, 64)
+        except Exception:                                    # noqa: BLE001
+            return ""
+        return buf.value.decode()
 
     @classmethod
     def destroy(cls):
@@ -96,8 +119,8 @@ class _Reducer:
         self.works, self.sum_views, self.native_used = [], [], False
 
     def start(self, v):
-        if _world() == 1 and not NativeComm.active:
-            return
+        if _world() == 1 and not (NativeComm.active and _native_ok(v)):
+            return                                           # one rank: the mean is the value (and there may be no process group)
         if _native_ok(v):
             NativeComm.allreduce_avg(v)
             self.native_used = True
