@@ -137,6 +137,7 @@ def synth_batch(B, task, seed, device, T_TXT=T_TXT, N_REG=N_REG):
         ids = ids.clone()
         ids[pick] = 250001
         batch["input_ids"], batch["txt_labels"] = ids, lab
+        batch["n_txt_labels"] = int(pick.sum().item())      # host-side count of the masked tokens, as a data loader has it (uc2_amd/data/loader.py)
     return batch
 
 

@@ -93,9 +93,13 @@ def assemble(rb, device, feat_dtype=torch.float32, pad_id=1):
         batch["targets"] = d["targets"]
     elif task == "mlm":
         batch["txt_labels"] = txt_labels
+        # the number of masked tokens is known here, on the host: with it the model compacts the masked rows without a
+        # device -> host sync (uc2_amd/model/model.py::_masked_rows; the reference's boolean indexing syncs, model/model.py:653-657)
+        batch["n_txt_labels"] = int((rb.t["labels"] != -1).sum())
     else:
         batch["img_masks"] = img_masks.bool()
         batch["img_mask_tgt"] = img_mask_tgt.bool()
+        batch["n_img_mask_tgt"] = int(rb.t["mask"].sum())
         # targets of the masked regions in batch-major, region-minor order (= boolean indexing, data/mrm.py:28-33):
         # rows of the flat buffers selected by the flat mask itself
         rows = torch.nonzero(rb.t["mask"], as_tuple=False).view(-1).to(device, non_blocking=True)     # host-side index list
