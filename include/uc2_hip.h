@@ -68,6 +68,8 @@ enum { UC2_GEMM_AUTO = -2, UC2_GEMM_GENERIC = 99 };
 enum { UC2_GEMM_DEFER_REDUCE = 1, UC2_GEMM_AUX_DERIV = 2 };
 #define UC2_GEMM_SKEW(n) (((n) & 15) << 4)
 #define UC2_GEMM_DIAG(m) (((m) & 0xFFFF) << 8)
+#define UC2_GEMM_SPARE(n) (((n) & 7) << 28)          /* the persistent ping-pong kernels leave 8 n CUs without a workgroup: room for a
+                                                       memory-bound kernel of another stream beside a weight-gradient GEMM */
 #define UC2_GEMM_COLGROUP(n) (((n) & 15) << 24)     /* diagnostic: column tiles per L2 group of the ping-pong tile order (0 = default) */
 /* uc2_gemm with a caller-owned item queue for the persistent ping-pong kernel: `queue` = 9 ints of device memory, zeroed once
  * (the kernel leaves them zeroed), one queue per stream that issues GEMMs concurrently.  Workgroups take their third and

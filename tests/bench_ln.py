@@ -6,7 +6,7 @@ from uc2_amd import ops
 from bench_gemm import timeit
 
 def main():
-    M, H = 49152, 768
+    M, H = (int(sys.argv[1]) if len(sys.argv) > 1 else 98304), 768
     x = torch.randn(M, H, device="cuda").to(torch.bfloat16)
     r = torch.randn(M, H, device="cuda").to(torch.bfloat16)
     dy = torch.randn(M, H, device="cuda").to(torch.bfloat16)

@@ -449,15 +449,17 @@ def test_gemm_item_queue_gives_the_same_result_and_is_left_zeroed(ta, tb, M, N, 
         for _ in range(3):                               # repeated launches reuse the queue
             ops.gemm(a, b, M, N, K, ta=ta, tb=tb, bias=bias, out=out, accumulate=wg, split_k=split, variant=8)
         return out
-    ref = run()
-    ops.GEMM_QUEUE = True
+    was = ops.GEMM_QUEUE
+    ops.GEMM_QUEUE = False
     try:
+        ref = run()
+        ops.GEMM_QUEUE = True
         got = run()
         q = ops._gemm_queue(a.device)
         torch.cuda.synchronize()
         assert int(q.abs().sum()) == 0
     finally:
-        ops.GEMM_QUEUE = False
+        ops.GEMM_QUEUE = was
     assert torch.equal(got, ref)
 
 

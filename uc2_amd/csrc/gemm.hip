@@ -334,6 +334,7 @@ static int gemm_impl(int dtype, int trans_a, int trans_b, int M, int N, int K,
     p.col_group = want ? (want > nbx ? nbx : want) : cg;
   }
   p.defer = flags & 1; p.aux_deriv = (flags >> 1) & 1; p.skew = (flags >> 4) & 15; p.diag = (flags >> 8) & 0xFFFF;
+  p.spare_cus = 8 * ((flags >> 28) & 7);                /* UC2_GEMM_SPARE(n): the persistent kernels leave 8 n CUs without a workgroup */
   p.a_vec = (((uintptr_t)A & 15) == 0) && ((lda & 7) == 0);
   p.b_vec = (((uintptr_t)B & 15) == 0) && ((ldb & 7) == 0);
   hipStream_t st = (hipStream_t)stream;

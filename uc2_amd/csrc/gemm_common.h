@@ -25,6 +25,7 @@ struct GemmArgs {
   const float* alpha_dev2;
   int col_group;         // ping-pong kernel: column tiles per L2 group of the tile order (host: largest divisor of N/256 that is <= 6)
   int aux_deriv;         // UC2_GEMM_AUX_DERIV: EPI_GELU stores gelu'(pre) (not pre) to aux_out, EPI_DGELU multiplies by aux_in as is
+  int spare_cus;         // persistent kernels: CUs left without a workgroup (for a kernel running beside this one on another stream)
   int* queue;            // ping-pong kernel: caller-owned item queue (9 zeroed ints: next-item counter per XCD + exit count), or null = static partition
 };
 

@@ -460,7 +460,9 @@ static void roll_launch0(const GemmArgs& p, hipStream_t st) {
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
   const int nitems = (p.N / 256) * (p.M / 256);
-  const int grid = nitems < roll_num_cus() ? nitems : roll_num_cus();
+  int cus = roll_num_cus() - p.spare_cus;
+  if (cus < 8) cus = 8;
+  const int grid = nitems < cus ? nitems : cus;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, p);
 }
 

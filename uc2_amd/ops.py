@@ -99,6 +99,8 @@ class _Timed:
 
 
 GEMM_AUTO, GEMM_GENERIC = -2, 99      # include/uc2_hip.h: UC2_GEMM_AUTO / UC2_GEMM_GENERIC
+_EXTRA_FLAGS = 0                       # diagnostics: UC2_GEMM_EXTRA_FLAGS=<int> is OR-ed into the flags of every uc2_gemm call (A/B of a
+                                       # UC2_GEMM_DIAG route inside the whole training step; 0 in production)
 GEMM_DEFER_REDUCE = 1
 GEMM_AUX_DERIV = 2                    # EPI_GELU saves gelu'(pre), EPI_DGELU multiplies by it as is
 _FORCED = [None]                       # tests/diagnostics only (force_variant); production passes the plan per call
@@ -160,7 +162,7 @@ rng = _Rng()
 # Item queue of the persistent ping-pong GEMM (include/uc2_hip.h uc2_gemm_queued): dynamic work distribution from the third
 # item of a workgroup on, for steps that overlap GEMMs with a communication kernel.  One 9-int queue per (device, stream):
 # launches on one stream are serialised and the kernel leaves its queue zeroed.  UC2_GEMM_QUEUE=1 / ops.GEMM_QUEUE = True.
-GEMM_QUEUE = False
+GEMM_QUEUE = True       # (on with the weight-gradient side stream: two persistent kernels may meet on the CUs; UC2_GEMM_QUEUE=0 turns it off)
 _GEMM_QUEUES = {}
 
 
@@ -191,6 +193,7 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
     for x in (aux_in, aux_out):
         if x is not None and x.dim() == 2:
             ldaux = x.stride(0)
+    flags |= _EXTRA_FLAGS
     if variant is None:
         if _FORCED[0] is not None:
             variant, fflags = _FORCED[0]
@@ -513,10 +516,13 @@ def linear_dgrad(dy2, w, epi=EPI_NONE, aux_in=None, colsum_out=None, flags=0):
     return _gemm_planned(dy2, w, M, K, N, False, True, epi=epi, aux_in=aux_in, aux_out=colsum_out, flags=flags)
 
 
+WGRAD_SPARE = 0                 # with WGRAD_SIDE_STREAM: weight-gradient GEMMs leave 8 * WGRAD_SPARE CUs free (UC2_GEMM_SPARE)
+
+
 def _linear_wgrad_now(dy2, x2, dw, db):
     M, N = dy2.shape
     K = x2.shape[1]
-    _gemm_planned(dy2, x2, N, K, M, True, True, wgrad=True, out=dw, accumulate=True)
+    _gemm_planned(dy2, x2, N, K, M, True, True, wgrad=True, out=dw, accumulate=True, flags=(WGRAD_SPARE & 7) << 28)
     if db is not None:
         colsum_accum(dy2, db)
 
@@ -524,7 +530,11 @@ def _linear_wgrad_now(dy2, x2, dw, db):
 # Weight-gradient GEMMs are off the critical path of backward (nothing downstream in the same backward pass reads
 # dW), so they are enqueued on a side HIP stream and overlap the dgrad / LayerNorm / attention chain on the main
 # stream.  Every consumer of gradients (optimizer, clipping, all-reduce, end of autograd's backward) joins first.
-WGRAD_SIDE_STREAM = False       # measured: no gain on MI355X (every GEMM here already fills all CUs/LDS), kept as an option
+WGRAD_SIDE_STREAM = True        # round 3, inside the 1024-pair step on one box: 63.1-63.3 ms against 63.8-64.4 on the main stream alone
+                                # (the tails and launch gaps of the memory-bound kernels fill with weight-gradient tiles); the persistent
+                                # GEMMs then take their work items from the per-XCD queue (workgroups of two kernels share the CUs).
+                                # Leaving CUs free for the other stream (UC2_GEMM_SPARE) made it slower (65.5 ms at 16-24 CUs).
+                                # UC2_WGRAD_SIDE=0 turns it off.
 _side_streams = {}
 _side_dirty = set()
 _join_queued = [False]
@@ -1482,8 +1492,14 @@ def attn_probs_mean(qkv2, mask2d, B, L, nh, D):
 import os as _os
 if _os.environ.get("UC2_AUTOTUNE", "1") == "0":     # variable-shape runs that must never stall on a tuning pass
     AUTOTUNE = False
-if _os.environ.get("UC2_GEMM_QUEUE", "0") == "1":
-    GEMM_QUEUE = True
+if _os.environ.get("UC2_WGRAD_SIDE"):            # experiment: "1" or "1:<spare>" (side stream for weight gradients, 8 * spare CUs left free)
+    _v = _os.environ["UC2_WGRAD_SIDE"].split(":")
+    WGRAD_SIDE_STREAM = _v[0] == "1"
+    WGRAD_SPARE = int(_v[1]) if len(_v) > 1 else 0
+if _os.environ.get("UC2_GEMM_EXTRA_FLAGS"):
+    _EXTRA_FLAGS = int(_os.environ["UC2_GEMM_EXTRA_FLAGS"], 0)
+if _os.environ.get("UC2_GEMM_QUEUE"):
+    GEMM_QUEUE = _os.environ["UC2_GEMM_QUEUE"] == "1"
 if _os.environ.get("UC2_PP_SKEW"):          # e.g. "1:2,2:2" = skew 2 for the GELU and dGELU epilogue GEMMs
     PP_SKEW = {int(k): int(v) for k, v in (kv.split(":") for kv in _os.environ["UC2_PP_SKEW"].split(","))}
 if _os.environ.get("UC2_GEMM_PLANS", "1") != "0":
