@@ -52,11 +52,13 @@ template <typename T> struct Raw4;
 template <> struct Raw4<float> {
   typedef float4 type;
   static __device__ __forceinline__ float4 load(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ float4 load_nt(const float* p) { return *reinterpret_cast<const float4*>(p); }
   static __device__ __forceinline__ void to_f(const float4& v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 };
 template <> struct Raw4<bf16> {
   typedef bf16x4 type;
   static __device__ __forceinline__ bf16x4 load(const bf16* p) { return *reinterpret_cast<const bf16x4*>(p); }
+  static __device__ __forceinline__ bf16x4 load_nt(const bf16* p) { return __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(p)); }
   static __device__ __forceinline__ void to_f(const bf16x4& v, float (&o)[4]) {
     o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
   }

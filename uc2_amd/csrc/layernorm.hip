@@ -127,12 +127,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const size_t off = (size_t)row * H + min(lane + 64 * i, nch - 1) * 4;
-      rx[i] = Raw4<T>::load(x + off);
-      rd[i] = Raw4<T>::load(dy + off);
+      rx[i] = Raw4<T>::load_nt(x + off);
+      rd[i] = Raw4<T>::load_nt(dy + off);
     }
     if (res) {
 #pragma unroll
-      for (int i = 0; i < NC; ++i) rr[i] = Raw4<T>::load(res + (size_t)row * H + min(lane + 64 * i, nch - 1) * 4);
+      for (int i = 0; i < NC; ++i) rr[i] = Raw4<T>::load_nt(res + (size_t)row * H + min(lane + 64 * i, nch - 1) * 4);
     }
     const float mean = mean_i[row], rstd = rstd_i[row];
     // (fetching the next row into a second register set during the arithmetic changed nothing: 169 vs 172 us)
@@ -240,10 +240,10 @@ __global__ __launch_bounds__(256) void ln_fwd16_kernel(int M, int H, const bf16*
   const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
   bf16x8 rx[NC8], rr[NC8];
 #pragma unroll
-  for (int i = 0; i < NC8; ++i) rx[i] = *reinterpret_cast<const bf16x8*>(x + (size_t)row * H + min(l32 + 32 * i, nch - 1) * 8);
+  for (int i = 0; i < NC8; ++i) rx[i] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(x + (size_t)row * H + min(l32 + 32 * i, nch - 1) * 8));
   if (res) {
 #pragma unroll
-    for (int i = 0; i < NC8; ++i) rr[i] = *reinterpret_cast<const bf16x8*>(res + (size_t)row * H + min(l32 + 32 * i, nch - 1) * 8);
+    for (int i = 0; i < NC8; ++i) rr[i] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(res + (size_t)row * H + min(l32 + 32 * i, nch - 1) * 8));
   }
   float v[NC8][8];
   float s = 0.f;
