@@ -25,10 +25,10 @@ def main():
         split = 9 if wg else 1
         row = []
         for v in variants:
-            for mode in (0, 8, 64, 8 + 32, 8 + 128, 8 + 32 + 128):
+            for mode in (0, 8, 64, 8 + 1, 8 + 2, 8 + 1 + 2):
                 fn = lambda: ops.gemm(a, b, m, n, k, ta=ta, tb=tb, out=out, accumulate=wg, split_k=split, variant=v, flags=mode << 8)
                 t = timeit(fn)
-                row.append("v%d/%s %6.1f" % (v, {0: "full", 8: "loop", 64: "epi", 40: "loop-nodma", 136: "loop-nord", 168: "loop-mfma"}[mode], 2.0 * m * n * k / t / 1e12))
+                row.append("v%d/%s %6.1f" % (v, {0: "full", 8: "loop", 64: "epi", 9: "loop-nodma", 10: "loop-nord", 11: "loop-mfma"}[mode], 2.0 * m * n * k / t / 1e12))
         print("%-11s M=%6d N=%5d K=%6d  " % (name, m, n, k) + "  ".join(row))
 
 if __name__ == "__main__":

@@ -35,6 +35,7 @@ template <> struct Vec4<float> {
   static __device__ __forceinline__ void store(float* p, const float (&o)[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
   }
+  static __device__ __forceinline__ void store_nt(float* p, const float (&o)[4]) { store(p, o); }
 };
 template <> struct Vec4<bf16> {
   static __device__ __forceinline__ void load(const bf16* p, float (&o)[4]) {
@@ -44,6 +45,10 @@ template <> struct Vec4<bf16> {
   static __device__ __forceinline__ void store(bf16* p, const float (&o)[4]) {
     bf16x4 v; v[0] = (bf16)o[0]; v[1] = (bf16)o[1]; v[2] = (bf16)o[2]; v[3] = (bf16)o[3];
     *reinterpret_cast<bf16x4*>(p) = v;
+  }
+  static __device__ __forceinline__ void store_nt(bf16* p, const float (&o)[4]) {       // streamed: consumed much later, keep it out of the caches
+    bf16x4 v; v[0] = (bf16)o[0]; v[1] = (bf16)o[1]; v[2] = (bf16)o[2]; v[3] = (bf16)o[3];
+    __builtin_nontemporal_store(v, reinterpret_cast<bf16x4*>(p));
   }
 };
 

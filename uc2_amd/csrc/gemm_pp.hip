@@ -38,6 +38,10 @@
 // ------------------------------------------------------------------------------------------------------
 #include "gemm_pp.h"
 
+#ifndef UC2_PP_DIAG
+#define UC2_PP_DIAG 0            /* 1: build the main-loop diagnostics 0x100 / 0x200 (tests/bench_pp.py) */
+#endif
+
 template <bool TA, bool TB, bool TACC, int EPI, int HI>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   constexpr int RW = 64 + 32 * HI, RT = 2 * RW;           // rows per wave row / per tile (128 / 256, or 96 / 192)
@@ -203,6 +207,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   } while (0)
 
+  // main-loop diagnostics (with 0x800): 0x100 = no LDS-DMA issue (stale LDS contents), 0x200 = no fragment reads after the first k-tile
+  const bool dg_nodma = UC2_PP_DIAG && (p.atomic & 0x100) != 0, dg_nord = UC2_PP_DIAG && (p.atomic & 0x200) != 0;     // (make EXTRA=-DUC2_PP_DIAG=1)
   bool more = false;                                   // another item follows the current one
   auto body = [&](auto tail_c, auto swap_c, int kt) __attribute__((always_inline)) {
     constexpr bool TAIL = decltype(tail_c)::value;
@@ -220,14 +226,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     // register sets swap roles every k-tile.  The unit order of the stream is therefore B0, A0, B1, A1: every phase
     // consumes exactly the unit the previous phase's wait retired.
     // ---- phase 0
-    PP_READ_A(cb + 0 * PP_UNIT);
-    if (!TAIL || f0 + 6 < nunits || more) PP_ISSUE(2, nb);
+    if (!dg_nord || kt == 0) PP_READ_A(cb + 0 * PP_UNIT);
+    if ((!TAIL || f0 + 6 < nunits || more) && !dg_nodma) PP_ISSUE(2, nb);
     PP_SYNC_L((TAIL && !more) ? nunits - 3 - f0 : 4, 0);
     PP_MFMA(0, 0, b0);
     PP_SYNC_C();
     // ---- phase 1
-    PP_READ_B(b1, cb + 2 * PP_UNIT);
-    if (!TAIL || f0 + 7 < nunits || more) PP_ISSUE(3, nb);
+    if (!dg_nord || kt == 0) PP_READ_B(b1, cb + 2 * PP_UNIT);
+    if ((!TAIL || f0 + 7 < nunits || more) && !dg_nodma) PP_ISSUE(3, nb);
     PP_SYNC_L((TAIL && !more) ? nunits - 4 - f0 : 4, 1);
     PP_MFMA(0, 1, b1);
     PP_SYNC_C();
@@ -237,14 +243,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     // into the ring positions a prologue would use (nt is even).  The next item then starts with its operands in LDS
     // instead of issuing 96 KiB of LDS-DMA and waiting for it with the matrix pipe idle.
     if (TAIL && !SW && more) setup(nxt);
-    PP_READ_A1(cb + 3 * PP_UNIT);
-    if (!TAIL || f0 + 8 < nunits || more) PP_ISSUE(1, nb ^ 1);
+    if (!dg_nord || kt == 0) PP_READ_A1(cb + 3 * PP_UNIT);
+    if ((!TAIL || f0 + 8 < nunits || more) && !dg_nodma) PP_ISSUE(1, nb ^ 1);
     PP_SYNC_L((TAIL && !more) ? nunits - 5 - f0 : 4, 2);
     PP_MFMA(1, 1, b1);
     PP_SYNC_C();
     // ---- phase 3
-    if (!TAIL || kt + 1 < nt) PP_READ_B(b1, (cb ^ 65536u) + 1 * PP_UNIT);
-    if (!TAIL || f0 + 9 < nunits || more) PP_ISSUE(0, nb ^ 1);
+    if ((!TAIL || kt + 1 < nt) && (!dg_nord || kt == 0)) PP_READ_B(b1, (cb ^ 65536u) + 1 * PP_UNIT);
+    if ((!TAIL || f0 + 9 < nunits || more) && !dg_nodma) PP_ISSUE(0, nb ^ 1);
     PP_SYNC_L((TAIL && !more) ? nunits - 6 - f0 : 4, 3);
     PP_MFMA(1, 0, b0);
     if (TAIL && kt == nt - 1) {                        // wave row 1 has no partner barrier left after its last C section

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
           dbx[i][e] += dxv[e];
         }
         if (dx) Vec4<T>::store(dx + off, dxv);
-        if (dres) Vec4<T>::store(dres + off, dz);
+        if (dres) Vec4<T>::store_nt(dres + off, dz);           // the residual-path gradient is read several kernels later (EPI_ADD of a dgrad GEMM)
       }
     }
   }
