@@ -569,11 +569,12 @@ def test_gemm_rolling_variant_falls_back_to_pingpong_where_it_does_not_apply():
     assert torch.equal(r10, ops.gemm(a, b, M, N, K, tb=True, epi=ops.EPI_ADD, aux_in=aux, variant=8))
 
 
+@pytest.mark.parametrize("variant", [8, 11])
 @pytest.mark.parametrize("epi", ["none", "gelu", "gelu_d", "add", "tanh", "dgelu", "mul"])
-def test_gemm_pingpong_epilogue_route_without_lane_exchange(epi):
-    """the ping-pong kernel's epilogue moves 8-byte pieces straight from the accumulator layout into the transposition buffer
-    (pp_epi_compute_q); the older route through v_permlane32_swap stays behind UC2_GEMM_DIAG(0x20): same bits out, second
-    stream and bias-gradient column sums included"""
+def test_gemm_pingpong_epilogues_with_second_streams(epi, variant):
+    """every fused epilogue of the ping-pong kernels (variant 8: four phases per k-tile, 11: two) incl. the second output stream
+    (pre-activation or gelu') and the bias-gradient column sums, against the generic kernel; two launches agree bit for bit.
+    (The epilogue moves 8-byte pieces straight from the accumulator layout into the transposition buffer, pp_epi_compute_q.)"""
     M, N, K = 2048, 768, 512
     tb = epi in ("dgelu", "mul")
     a = rnd((M, K), 1, dtype=torch.bfloat16)
@@ -584,17 +585,40 @@ def test_gemm_pingpong_epilogue_route_without_lane_exchange(epi):
             "dgelu": ops.EPI_DGELU, "mul": ops.EPI_DGELU}[epi]
     fl = ops.GEMM_AUX_DERIV if epi in ("gelu_d", "mul") else 0
 
-    def run(flags):
+    def run(v):
         second = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV) if code == ops.EPI_GELU else (
             torch.zeros(N, dtype=torch.float32, device=DEV) if code == ops.EPI_DGELU else None)
         o = ops.gemm(a, b, M, N, K, tb=tb, bias=bv, epi=code, aux_in=aux if code in (ops.EPI_ADD, ops.EPI_DGELU) else None,
-                     aux_out=second, variant=8, flags=fl | flags)
+                     aux_out=second, variant=v, flags=fl)
         return o, second
-    o_new, s_new = run(0)
-    o_old, s_old = run(0x20 << 8)
-    assert torch.equal(o_new, o_old)
-    if s_new is not None:
-        assert torch.equal(s_new, s_old) if s_new.dtype == torch.bfloat16 else rel_err(s_new, s_old) < 1e-5
+    o_ref, s_ref = run(GENERIC)
+    o1, s1 = run(variant)
+    o2, s2 = run(variant)
+    assert torch.equal(o1, o2)
+    assert rel_err(o1.float(), o_ref.float()) < 3e-3
+    if s1 is not None:
+        assert rel_err(s1.float(), s_ref.float()) < (3e-3 if s1.dtype == torch.bfloat16 else 2e-3)
+        assert torch.equal(s1, s2) if s1.dtype == torch.bfloat16 else rel_err(s1, s2) < 1e-5
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 512, 1024), (2048, 768, 768), (4096, 2304, 256)])
+def test_gemm_two_phase_pingpong_equals_pingpong(ta, tb, M, N, K):
+    """variant 11 (gemm_pp2.hip: two phases of 16 MFMAs per k-tile) computes every output element in the same order as variant 8:
+    bit-identical bf16 results, fp32 split-K accumulation included; NaN-filled outputs, three launches (race screen)"""
+    a = rnd((K, M) if ta else (M, K), 1, dtype=torch.bfloat16)
+    b = rnd((K, N) if tb else (N, K), 2, dtype=torch.bfloat16)
+    bias = rnd((N,), 3)
+    ref = ops.gemm(a, b, M, N, K, ta=ta, tb=tb, bias=bias, variant=8)
+    for _ in range(3):
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.gemm(a, b, M, N, K, ta=ta, tb=tb, bias=bias, out=out, variant=11)
+        assert torch.equal(out, ref)
+    acc0 = rnd((M, N), 4)
+    sk = 2 if K >= 256 else 1
+    r = ops.gemm(a, b, M, N, K, ta=ta, tb=tb, out=acc0.clone(), accumulate=True, split_k=sk, variant=8)
+    o = ops.gemm(a, b, M, N, K, ta=ta, tb=tb, out=acc0.clone(), accumulate=True, split_k=sk, variant=11)
+    assert torch.equal(o, r)
 
 
 def test_gemm_pingpong_skew_and_deferred_reduce():

@@ -146,6 +146,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
   const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
   const bf16* base = qkv + (size_t)b * L * ld + head * D;
   const int tid = threadIdx.x;
+  const int w = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
+  const int q = 32 * w + c;
+  // this lane's Q fragments: issued together with the K / V tile loads (after the barrier below they were a second, fully
+  // exposed trip to memory per workgroup)
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+    qf[s] = (q < L) ? *reinterpret_cast<const bf16x8*>(base + (size_t)q * ld + 16 * s + 8 * h) : zero8();
   {   // K and V tiles: all 16-byte loads of the thread in flight together, then the LDS stores (a load -> wait -> store
       // loop costs eight dependent memory round trips per workgroup)
     constexpr int NCH = Lp * (D / 8) / (NW * 64);
@@ -160,13 +168,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
     store_tile_regs<D, NCH>(Vs, rv, tid, NW * 64);
   }
   __syncthreads();
-
-  const int w = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
-  const int q = 32 * w + c;
-  bf16x8 qf[KS];
-#pragma unroll
-  for (int s = 0; s < KS; ++s)
-    qf[s] = (q < L) ? *reinterpret_cast<const bf16x8*>(base + (size_t)q * ld + 16 * s + 8 * h) : zero8();
 
   f32x16 sc[NW];
   float mx = -INFINITY;

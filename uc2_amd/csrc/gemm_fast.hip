@@ -359,6 +359,7 @@ static void ws_launch1(const GemmArgs& p, hipStream_t st) {
 
 bool uc2_gemm_pp_supported(int trans_a, int trans_b, int c_f32, int epi, int tile_rows);        // gemm_pp.hip
 void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st, int tile_rows);
+void uc2_gemm_pp2_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st, int tile_rows);                // gemm_pp2.hip
 bool uc2_gemm_roll_supported(const GemmArgs& p, int trans_a, int trans_b);                        // gemm_roll.hip
 void uc2_gemm_roll_launch(const GemmArgs& p, int trans_b, hipStream_t st);
 void uc2_splitk_reduce(const GemmArgs& p, hipStream_t st);                                        // gemm.hip
@@ -411,7 +412,8 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
   int variant = p.variant;                           // per call (uc2_gemm's `variant` argument), never process state
   if (variant == 99) return 0;                       // caller asked for the generic kernel
   const bool want_roll = variant == 10;              // rolling-epilogue ping-pong kernel (gemm_roll.hip); else the plain one
-  if (want_roll) variant = 8;
+  const bool want_pp2 = variant == 11;               // ping-pong kernel with two phases per k-tile (gemm_pp2.hip)
+  if (want_roll || want_pp2) variant = 8;
   if (variant == 8 || variant == 9) {
     // ping-pong kernel: whole 256x256 (variant 9: 192x256) tiles, >= 2 k-tiles per split, and (bf16 output) an epilogue
     // made of whole 16-byte accesses; anything else runs on the ring kernels above / the generic kernel
@@ -440,10 +442,10 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
     if (p.c_f32 && p.split_k > 1 && p.ws && need <= p.ws_bytes && (p.N & 3) == 0 && (p.ldc & 3) == 0 &&
         ((uintptr_t)p.C & 15) == 0 && ((uintptr_t)p.ws & 15) == 0) {
       pd.partial = p.ws;                             // two-stage: plain partial stores, then one reduction pass
-      uc2_gemm_pp_launch(pd, trans_a, trans_b, st, 256);
+      if (want_pp2) uc2_gemm_pp2_launch(pd, trans_a, trans_b, st, 256); else uc2_gemm_pp_launch(pd, trans_a, trans_b, st, 256);
       if (!p.defer) uc2_splitk_reduce(pd, st);
     } else {
-      uc2_gemm_pp_launch(pd, trans_a, trans_b, st, 256);
+      if (want_pp2) uc2_gemm_pp2_launch(pd, trans_a, trans_b, st, 256); else uc2_gemm_pp_launch(pd, trans_a, trans_b, st, 256);
     }
     return 2;                                         // (2: the kernel also produced the EPI_DGELU column sums)
   }

@@ -1,40 +1,22 @@
 #include "gemm_tile.h"
 
 // ------------------------------------------------------------------------------------------------------
-// Ping-pong variant: tile 256x256x64, 8 waves = 2 (M) x 4 (N), 128x64 of output per wave (128 accumulator
-// registers), one workgroup per CU, 128 KiB of LDS = 2 k-tile buffers x 4 staging units of 16 KiB.
+// Ping-pong GEMM with TWO phases per k-tile (variant 11).  Same tile (256 x 256 x 64, 8 waves = 2 x 4, 128 x 64 per wave), same
+// ring of eight 16-KiB units (B0, A0, B1, A1 of two k-tiles), same persistent item walk, epilogues and wave-row offset as
+// gemm_pp.hip -- read its header first.  What changes is the granularity of the hand-over between the two wave rows:
 //
-// A k-tile is consumed in four phases, one 64x32 quadrant of the wave's output each (8 MFMAs); the fragment
-// reads are spread 8 / 4 / 8 / 4 (ds_read_b128 equivalents) over them:
-//     phase 0: read A0 (rows 0-63 of the wave's 128)                         -> A0 x B0   (B0 was read one phase ago)
-//     phase 1: read B1 (columns 32-63 of the wave's 64)                      -> A0 x B1
-//     phase 2: read A1 (overwrites A0)                                       -> A1 x B1
-//     phase 3: read B0 of the NEXT k-tile into the registers of B1 (dead)    -> A1 x B0
-// (the two B register sets swap roles every k-tile; the main loop is unrolled by two, k-tile counts are even).
-// Every phase is  [L: fragment reads + 2 LDS-DMA issues + counted vmcnt] barrier [C: 8 MFMAs] barrier.  The two
-// wave rows run one barrier apart (wave row 1 takes one extra barrier at the start), so in every barrier
-// interval one wave of each SIMD is in its C section while the other is in its L section: the matrix pipe
-// always has a wave feeding it and the other wave's LDS reads / DMA issues cost it nothing.
+//     phase E:  read B0, B1, A0 (16 fragment reads)   issue units B1, A1 of k-tile kt+1   -> 16 MFMAs  (A0 x B0, A0 x B1)
+//     phase O:  read A1 (8 fragment reads)            issue units B0, A0 of k-tile kt+2   -> 16 MFMAs  (A1 x B1, A1 x B0)
 //
-// Staging: the k-tile is cut into four units of 128 rows x 64 k, streamed in the order the phases consume them:
-// B0 (columns 0-31 of all four wave columns), A0 (rows 0-63 of both wave rows), B1, A1 -- one unit per phase.
-// Phase f issues unit f+6 (each wave two 1-KiB LDS-DMA instructions), so a unit is issued 5-6 phases before
-// its first read and at least two barrier intervals after the last read of the unit it overwrites;
-// `s_waitcnt vmcnt(8)` at the end of every L section retires exactly the unit the next phase reads (all but
-// the 4 youngest units), and the barrier that follows publishes it to the other waves.
-//
-// HI = 1 variant: tiles of 192 rows (96 per wave row: A0 = 64 rows, A1 = 32).  The N = 768 GEMMs of the encoder have
-// 576 tiles of 256 rows on 256 CUs (2.25 rounds, the last a quarter full); with 192 rows they are 768 = three full
-// rounds.  Unit A1 is then 8 KiB (one LDS-DMA per wave, 7 per k-tile instead of 8) and phases 2, 3 run 4 MFMAs.
-//
-// The kernel is persistent: one workgroup per CU walks over (output tile, k-split) work items, and the LDS-DMA stream
-// does not drain between them: the last six phases of an item's main loop (which have no unit of their own item left to
-// issue) fetch the NEXT item's first six units, in the order and ring positions a prologue would use (k-tile counts are
-// even), so the next main loop starts with its operands in LDS.  The epilogue never touches the ring (it transposes
-// through 4 KiB of wave-private LDS beside it, see tp_* below); its stores are issued after those units
-// (`vmcnt(8 + stores)` at the item barrier then retires exactly the two units the first phase reads) and are
-// non-temporal: outputs stream past the L2 instead of evicting the weight tiles every row panel re-reads.
-// At K = 768 the per-tile launch + first-fetch latency and the store tail were 40 % of a non-persistent tile.
+// In-kernel stamps put a K = 768 main loop of gemm_pp.hip at 323 cycles per barrier interval for 256 cycles of MFMA: every
+// hand-over (barrier release -> first MFMA of the other wave row) leaves the matrix pipe idle for ~67 cycles, once per 8 MFMAs.
+// With 16 MFMAs per C section the same hand-over is paid once per 512 cycles.  The fragment and LDS-DMA work per MFMA is unchanged
+// (12 reads and 4 DMA issues per 16 MFMAs), only bunched 16 + 4 / 8 + 4 instead of 8 + 2 / 4 + 2.
+// Ring discipline: a unit is overwritten (its DMA issued) in the L section after the phase that read it -- ONE barrier interval
+// after the delayed wave row's reads, not two as in gemm_pp.hip -- so every L section waits for its own fragment reads
+// (lgkmcnt(0)) BEFORE its barrier: behind that barrier nobody still reads the slots the next L section refills.
+// Counted waits: the end of phase E retires unit A1 of this k-tile (4 younger units may fly), the end of phase O unit B1 of the
+// next (3 younger units).  256-row tiles only.
 // ------------------------------------------------------------------------------------------------------
 #include "gemm_pp.h"
 
@@ -43,7 +25,7 @@
 #endif
 
 template <bool TA, bool TB, bool TACC, int EPI, int HI>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pp2_kernel(GemmArgs p) {
   constexpr int RW = 64 + 32 * HI, RT = 2 * RW;           // rows per wave row / per tile (128 / 256, or 96 / 192)
   constexpr int GA1 = HI == 2 ? 2 : 1;                      // LDS-DMA instructions per wave for unit A1
   constexpr int GKT = 6 + GA1;                             // ... per k-tile
@@ -207,51 +189,43 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   } while (0)
 
-  // main-loop diagnostics (with 0x800): 0x100 = no LDS-DMA issue (stale LDS contents), 0x200 = no fragment reads after the first k-tile
-  const bool dg_nodma = UC2_PP_DIAG && (p.atomic & 0x100) != 0, dg_nord = UC2_PP_DIAG && (p.atomic & 0x200) != 0;     // (make EXTRA=-DUC2_PP_DIAG=1)
+  // main-loop diagnostics (with 0x800): 0x100 = no LDS-DMA issue
+  const bool dg_nodma = UC2_PP_DIAG && (p.atomic & 0x100) != 0;
   bool more = false;                                   // another item follows the current one
-  auto body = [&](auto tail_c, auto swap_c, int kt) __attribute__((always_inline)) {
-    constexpr bool TAIL = decltype(tail_c)::value;
-    constexpr bool SW = decltype(swap_c)::value;       // k-tile parity: B0 lives in by, B1 in bx
-    bf16x8 (&b0)[4] = SW ? by : bx;
-    bf16x8 (&b1)[4] = SW ? bx : by;
-    const int nunits = 4 * nt;
+  bf16x8 (&b0)[4] = bx;
+  bf16x8 (&b1)[4] = by;
+  // end of an L section: counted wait, this phase's fragment reads, publish
+#define PP2_SYNC_L(UNITS)                                                                                      \
+  do {                                                                                                         \
+    pp_wait_small(2 * (UNITS));                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                                             \
+  } while (0)
+  auto body = [&](auto tail_c, int kt) __attribute__((always_inline)) {
+    constexpr bool TAIL = decltype(tail_c)::value;     // one of the last two k-tiles of the item
     unsigned cb = (kt & 1) * 65536u;                   // this k-tile's buffer
-    asm volatile("" : "+s"(cb));                       // opaque: the fragment addresses (base ^ step, + buffer, + unit) are recomputed per
-                                                       // read (1-2 VALU) instead of living in ~40 loop-invariant registers
+    asm volatile("" : "+s"(cb));
     const int nb = (kt & 1) ^ 1;                       // buffer of k-tile kt+1 (kt+2 shares this tile's)
-    const int f0 = 4 * kt;                             // first phase; phase f issues unit f+6, may leave min(4, nunits-3-f) units in flight
-    // Fragment reads are spread 8 / 4 / 8 / 4 over the phases: B0 of k-tile kt+1 is read in phase 3 of k-tile kt, into
-    // the registers of B1 (dead after phase 2; the current B0 is still needed by this phase's MFMAs) -- the two B
-    // register sets swap roles every k-tile.  The unit order of the stream is therefore B0, A0, B1, A1: every phase
-    // consumes exactly the unit the previous phase's wait retired.
-    // ---- phase 0
-    if (!dg_nord || kt == 0) PP_READ_A(cb + 0 * PP_UNIT);
-    if ((!TAIL || f0 + 6 < nunits || more) && !dg_nodma) PP_ISSUE(2, nb);
-    PP_SYNC_L((TAIL && !more) ? nunits - 3 - f0 : 4, 0);
+    const bool c1 = !TAIL || kt + 1 < nt || more;      // k-tile kt+1 exists (in this item or the next)
+    const bool c2 = !TAIL || kt + 2 < nt || more;
+    // ---- phase E
+    PP_READ_B(b0, cb + 1 * PP_UNIT);
+    PP_READ_A(cb + 0 * PP_UNIT);
+    PP_READ_B(b1, cb + 2 * PP_UNIT);
+    if (c1 && !dg_nodma) { PP_ISSUE(2, nb); PP_ISSUE(3, nb); }
+    PP2_SYNC_L(c1 ? 4 : 0);                            // A1 of this k-tile has landed; B0, A0 (kt+1) and the two units just issued may fly
     PP_MFMA(0, 0, b0);
-    PP_SYNC_C();
-    // ---- phase 1
-    if (!dg_nord || kt == 0) PP_READ_B(b1, cb + 2 * PP_UNIT);
-    if ((!TAIL || f0 + 7 < nunits || more) && !dg_nodma) PP_ISSUE(3, nb);
-    PP_SYNC_L((TAIL && !more) ? nunits - 4 - f0 : 4, 1);
     PP_MFMA(0, 1, b1);
     PP_SYNC_C();
-    // ---- phase 2
-    // The stream does not drain at the end of an item: the last six phases (from here on in the first of the two tail
-    // k-tiles; every unit of the current item has been issued) fetch the NEXT item's first six units, in the order and
-    // into the ring positions a prologue would use (nt is even).  The next item then starts with its operands in LDS
-    // instead of issuing 96 KiB of LDS-DMA and waiting for it with the matrix pipe idle.
-    if (TAIL && !SW && more) setup(nxt);
-    if (!dg_nord || kt == 0) PP_READ_A1(cb + 3 * PP_UNIT);
-    if ((!TAIL || f0 + 8 < nunits || more) && !dg_nodma) PP_ISSUE(1, nb ^ 1);
-    PP_SYNC_L((TAIL && !more) ? nunits - 5 - f0 : 4, 2);
+    // ---- phase O
+    if (TAIL && kt == nt - 2 && more) setup(nxt);      // from here on the stream fetches the next item (its first six units, prologue order)
+    PP_READ_A1(cb + 3 * PP_UNIT);
+    if (c2 && !dg_nodma) { PP_ISSUE(1, nb ^ 1); PP_ISSUE(0, nb ^ 1); }
+    PP2_SYNC_L((c1 ? 1 : 0) + (c2 ? 2 : 0));           // B0, A0, B1 of k-tile kt+1 have landed; A1 (kt+1) and the two units just issued may fly
     PP_MFMA(1, 1, b1);
-    PP_SYNC_C();
-    // ---- phase 3
-    if ((!TAIL || kt + 1 < nt) && (!dg_nord || kt == 0)) PP_READ_B(b1, (cb ^ 65536u) + 1 * PP_UNIT);
-    if ((!TAIL || f0 + 9 < nunits || more) && !dg_nodma) PP_ISSUE(0, nb ^ 1);
-    PP_SYNC_L((TAIL && !more) ? nunits - 6 - f0 : 4, 3);
     PP_MFMA(1, 0, b0);
     if (TAIL && kt == nt - 1) {                        // wave row 1 has no partner barrier left after its last C section
       __builtin_amdgcn_s_setprio(0);
@@ -311,9 +285,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     };
     // units 0 and 1 of this item: this wave's part has landed, then publish
     auto item_barrier = [&]() __attribute__((always_inline)) {
-      if (younger == GKT) { if (HI == 2) wait_vmcnt<8>(); else wait_vmcnt<7>(); }
-      else if (younger == GKT + NST) { if (HI == 2) wait_vmcnt<24>(); else wait_vmcnt<19>(); }
-      else if (younger == GKT + 2 * NST) { if (HI == 2) wait_vmcnt<40>(); else wait_vmcnt<31>(); }
+      // units B0, A0, B1 of k-tile 0: this wave's part has landed (A1 of k-tile 0, B0 and A0 of k-tile 1 and the stores are younger)
+      if (younger == GKT) wait_vmcnt<6>();
+      else if (younger == GKT + NST) wait_vmcnt<6 + NST>();
+      else if (younger == GKT + 2 * NST) wait_vmcnt<6 + 2 * NST>();
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
     };
@@ -337,11 +312,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     more = nxt < item_end;
     if (!(p.atomic & 0x4000)) {                        // (diagnostic 0x4000: epilogue only)
       using F = std::false_type; using T = std::true_type;
-      PP_READ_B(bx, 1 * PP_UNIT);                      // B0 of k-tile 0 (later k-tiles get theirs one phase ahead)
       int kt = 0;
-      for (; kt + 2 < nt; kt += 2) { body(F{}, F{}, kt); body(F{}, T{}, kt + 1); }     // nt is even (host-checked)
-      body(T{}, F{}, kt);
-      body(T{}, T{}, kt + 1);
+      for (; kt + 2 < nt; kt += 2) { body(F{}, kt); body(F{}, kt + 1); }     // nt is even (host-checked)
+      body(T{}, kt);
+      body(T{}, kt + 1);
     } else if (more) {
       setup(nxt);
       PP_PROLOGUE();
@@ -431,9 +405,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
 #undef PP_READ_B
 #undef PP_SYNC_L
 #undef PP_SYNC_C
+#undef PP2_SYNC_L
 }
 
-static int pp_num_cus() {
+static int pp2_num_cus() {
   static int n = 0;
   if (!n) {
     int dev = 0; hipDeviceProp_t prop;
@@ -444,14 +419,14 @@ static int pp_num_cus() {
 }
 
 template <bool TA, bool TB, bool TACC, int EPI, int HI = 2>
-static void pp_launch0(const GemmArgs& p, hipStream_t st) {
+static void pp2_launch0(const GemmArgs& p, hipStream_t st) {
   static_assert(HI == 2 || TACC, "the 192-row variant exists for the bf16-output epilogue only");
   constexpr int smem = 131072 + 8 * 4096;            // the ring + one 4 KiB transposition buffer per wave = all 160 KiB
-  auto kern = gemm_bf16_pp_kernel<TA, TB, TACC, EPI, HI>;
+  auto kern = gemm_bf16_pp2_kernel<TA, TB, TACC, EPI, HI>;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
   const int nitems = (p.N / 256) * (p.M / (128 + 64 * HI)) * p.split_k;
-  int cus = pp_num_cus() - p.spare_cus;
+  int cus = pp2_num_cus() - p.spare_cus;
   if (cus < 8) cus = 8;
   const int grid = nitems < cus ? nitems : cus;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, p);
@@ -460,49 +435,40 @@ static void pp_launch0(const GemmArgs& p, hipStream_t st) {
 // The epilogue kind is a template parameter; only the combinations the encoder uses are instantiated:
 //   X*W^T (forward): none, GELU, +residual, tanh;  dY*W (input gradient): none, dGELU, +residual;  everything else: none.
 // tile_rows = 192 (the N = 768 shapes, see the header comment): forward none, input gradient none / +residual.
-bool uc2_gemm_pp_supported(int trans_a, int trans_b, int c_f32, int epi, int tile_rows) {
-  if (tile_rows == 192) {
-    if (c_f32 || trans_a) return false;
-    return trans_b ? (epi == EPI_NONE || epi == EPI_ADD) : (epi == EPI_NONE);
-  }
+bool uc2_gemm_pp2_supported(int trans_a, int trans_b, int c_f32, int epi, int tile_rows) {
+  if (tile_rows != 256) return false;
   if (c_f32) return epi == EPI_NONE;
   if (!trans_a && !trans_b) return epi == EPI_NONE || epi == EPI_GELU || epi == EPI_ADD || epi == EPI_TANH;
   if (!trans_a && trans_b) return epi == EPI_NONE || epi == EPI_DGELU || epi == EPI_ADD;
   return epi == EPI_NONE;
 }
 
-void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st, int tile_rows) {
-  if (tile_rows == 192) {
-    if (!trans_b) pp_launch0<false, false, true, EPI_NONE, 1>(p, st);
-    else if (p.epi == EPI_ADD) pp_launch0<false, true, true, EPI_ADD, 1>(p, st);
-    else pp_launch0<false, true, true, EPI_NONE, 1>(p, st);
-    return;
-  }
+void uc2_gemm_pp2_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st, int tile_rows) {
   if (p.c_f32 && p.partial) {                          // the bf16-output kernels double as partial-tile producers
-    if (!trans_a && !trans_b) pp_launch0<false, false, true, EPI_NONE>(p, st);
-    else if (!trans_a && trans_b) pp_launch0<false, true, true, EPI_NONE>(p, st);
-    else if (trans_a && !trans_b) pp_launch0<true, false, true, EPI_NONE>(p, st);
-    else pp_launch0<true, true, true, EPI_NONE>(p, st);
+    if (!trans_a && !trans_b) pp2_launch0<false, false, true, EPI_NONE>(p, st);
+    else if (!trans_a && trans_b) pp2_launch0<false, true, true, EPI_NONE>(p, st);
+    else if (trans_a && !trans_b) pp2_launch0<true, false, true, EPI_NONE>(p, st);
+    else pp2_launch0<true, true, true, EPI_NONE>(p, st);
   } else if (p.c_f32) {
-    if (!trans_a && !trans_b) pp_launch0<false, false, false, EPI_NONE>(p, st);
-    else if (!trans_a && trans_b) pp_launch0<false, true, false, EPI_NONE>(p, st);
-    else if (trans_a && !trans_b) pp_launch0<true, false, false, EPI_NONE>(p, st);
-    else pp_launch0<true, true, false, EPI_NONE>(p, st);
+    if (!trans_a && !trans_b) pp2_launch0<false, false, false, EPI_NONE>(p, st);
+    else if (!trans_a && trans_b) pp2_launch0<false, true, false, EPI_NONE>(p, st);
+    else if (trans_a && !trans_b) pp2_launch0<true, false, false, EPI_NONE>(p, st);
+    else pp2_launch0<true, true, false, EPI_NONE>(p, st);
   } else if (!trans_a && !trans_b) {
-    if (p.epi == EPI_GELU && !p.aux_out) pp_launch0<false, false, true, EPI_GELU_NOAUX>(p, st);
-    else if (p.epi == EPI_GELU && p.aux_deriv) pp_launch0<false, false, true, EPI_GELU_D>(p, st);
-    else if (p.epi == EPI_GELU) pp_launch0<false, false, true, EPI_GELU>(p, st);
-    else if (p.epi == EPI_ADD) pp_launch0<false, false, true, EPI_ADD>(p, st);
-    else if (p.epi == EPI_TANH) pp_launch0<false, false, true, EPI_TANH>(p, st);
-    else pp_launch0<false, false, true, EPI_NONE>(p, st);
+    if (p.epi == EPI_GELU && !p.aux_out) pp2_launch0<false, false, true, EPI_GELU_NOAUX>(p, st);
+    else if (p.epi == EPI_GELU && p.aux_deriv) pp2_launch0<false, false, true, EPI_GELU_D>(p, st);
+    else if (p.epi == EPI_GELU) pp2_launch0<false, false, true, EPI_GELU>(p, st);
+    else if (p.epi == EPI_ADD) pp2_launch0<false, false, true, EPI_ADD>(p, st);
+    else if (p.epi == EPI_TANH) pp2_launch0<false, false, true, EPI_TANH>(p, st);
+    else pp2_launch0<false, false, true, EPI_NONE>(p, st);
   } else if (!trans_a && trans_b) {
-    if (p.epi == EPI_DGELU && p.aux_deriv) pp_launch0<false, true, true, EPI_MUL>(p, st);
-    else if (p.epi == EPI_DGELU) pp_launch0<false, true, true, EPI_DGELU>(p, st);
-    else if (p.epi == EPI_ADD) pp_launch0<false, true, true, EPI_ADD>(p, st);
-    else pp_launch0<false, true, true, EPI_NONE>(p, st);
+    if (p.epi == EPI_DGELU && p.aux_deriv) pp2_launch0<false, true, true, EPI_MUL>(p, st);
+    else if (p.epi == EPI_DGELU) pp2_launch0<false, true, true, EPI_DGELU>(p, st);
+    else if (p.epi == EPI_ADD) pp2_launch0<false, true, true, EPI_ADD>(p, st);
+    else pp2_launch0<false, true, true, EPI_NONE>(p, st);
   } else if (trans_a && !trans_b) {
-    pp_launch0<true, false, true, EPI_NONE>(p, st);
+    pp2_launch0<true, false, true, EPI_NONE>(p, st);
   } else {
-    pp_launch0<true, true, true, EPI_NONE>(p, st);
+    pp2_launch0<true, true, true, EPI_NONE>(p, st);
   }
 }
