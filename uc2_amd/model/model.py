@@ -302,15 +302,16 @@ class VLXLMRModel(VLXLMRPreTrainedModel):
         # additive key mask, fp32 (the parameters are fp32 masters): model/model.py:433-436
         extended_attention_mask = attention_mask.unsqueeze(1).unsqueeze(2).to(dtype=torch.float32)
         extended_attention_mask = (1.0 - extended_attention_mask) * -10000.0
-        if input_ids is None:
-            embedding_output = self._compute_img_embeddings(img_feat, img_pos_feat, img_masks, img_type_ids)
-        elif img_feat is None:
-            embedding_output = self._compute_txt_embeddings(input_ids, position_ids, txt_type_ids)
-        else:
-            embedding_output = self._compute_img_txt_embeddings(input_ids, position_ids, img_feat, img_pos_feat,
-                                                                gather_index, img_masks, txt_type_ids, img_type_ids)
-        encoded_layers = self.encoder(embedding_output, extended_attention_mask,
-                                      output_all_encoded_layers=output_all_encoded_layers)
+        with ops.rng.scope():           # one dropout seed copy for the whole forward; the sites are told apart by ops.rng.site()
+            if input_ids is None:
+                embedding_output = self._compute_img_embeddings(img_feat, img_pos_feat, img_masks, img_type_ids)
+            elif img_feat is None:
+                embedding_output = self._compute_txt_embeddings(input_ids, position_ids, txt_type_ids)
+            else:
+                embedding_output = self._compute_img_txt_embeddings(input_ids, position_ids, img_feat, img_pos_feat,
+                                                                    gather_index, img_masks, txt_type_ids, img_type_ids)
+            encoded_layers = self.encoder(embedding_output, extended_attention_mask,
+                                          output_all_encoded_layers=output_all_encoded_layers)
         if not output_all_encoded_layers:
             encoded_layers = encoded_layers[-1]
         return encoded_layers

@@ -135,6 +135,7 @@ def _require_cuda(t):
 class _Rng:
     def __init__(self):
         self.state = {}
+        self._scope = None
 
     def buf(self, device):
         device = torch.device(device)
@@ -146,10 +147,44 @@ class _Rng:
         return self.state[key]
 
     def snapshot(self, device):
-        """advance the stream and return a private copy for one forward/backward pair"""
+        """advance the stream and return a private copy for one forward/backward pair.  Inside `with rng.scope():` (one
+        model forward) every caller gets the SAME copy -- one add + one clone per forward instead of one pair per
+        BertLayer / LayerNorm (26 tiny launches per forward at 12 layers) -- and tells its sites apart with rng.site()."""
+        sc = self._scope
+        if sc is not None:
+            key = str(torch.device(device))
+            if key not in sc:
+                sc[key] = self._fresh(device)
+            return sc[key]
+        return self._fresh(device)
+
+    def _fresh(self, device):
         b = self.buf(device)
         b.add_(0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFF)
         return b.clone()
+
+    def site(self, imm):
+        """seed offset of one dropout site.  Outside a scope: `imm` itself (every caller has its own seed copy).  Inside: the
+        small site numbers (layer * 16 + k) are spread over 63 bits, so that two sites sharing the forward's seed do not draw
+        masks that are XOR-shifted copies of each other (the kernels hash seed ^ index)."""
+        if self._scope is None:
+            return int(imm)
+        return (int(imm) * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
+
+    class _Scope:
+        def __init__(self, rng):
+            self.rng = rng
+
+        def __enter__(self):
+            self.prev, self.rng._scope = self.rng._scope, {}
+            return self
+
+        def __exit__(self, *exc):
+            self.rng._scope = self.prev
+            return False
+
+    def scope(self):
+        return _Rng._Scope(self)
 
     def manual_seed(self, seed, device="cuda"):
         self.buf(torch.device(device)).fill_(seed & 0x7FFFFFFFFFFF)
@@ -164,7 +199,7 @@ rng = _Rng()
 # Item queue of the persistent ping-pong GEMM (include/uc2_hip.h uc2_gemm_queued): dynamic work distribution from the third
 # item of a workgroup on, for steps that overlap GEMMs with a communication kernel.  One 9-int queue per (device, stream):
 # launches on one stream are serialised and the kernel leaves its queue zeroed.  UC2_GEMM_QUEUE=1 / ops.GEMM_QUEUE = True.
-GEMM_QUEUE = True       # (on with the weight-gradient side stream: two persistent kernels may meet on the CUs; UC2_GEMM_QUEUE=0 turns it off)
+GEMM_QUEUE = False      # (with the weight-gradient side stream on one GPU the queue changed nothing: 61.6-61.7 ms without, 61.8-61.9 with)
 _GEMM_QUEUES = {}
 
 
@@ -561,9 +596,13 @@ def _end_of_backward_join():
     join_side_streams()
 
 
+WGRAD_SIDE_MIN_ROWS = 16384      # below this many tokens the step is close to host-bound and the extra event / stream traffic makes it
+                                 # erratic (104-pair micro-batches: 27.6-45.5 ms per optimizer step with the side stream, 30.8 without)
+
+
 def linear_wgrad(dy2, x2, dw, db):
     """dW[N,K] += dY^T X ; db[N] += colsum(dY)  (fp32 accumulation buffers)"""
-    if not WGRAD_SIDE_STREAM or torch.cuda.is_current_stream_capturing():
+    if not WGRAD_SIDE_STREAM or dy2.shape[0] < WGRAD_SIDE_MIN_ROWS or torch.cuda.is_current_stream_capturing():
         return _linear_wgrad_now(dy2, x2, dw, db)
     dev = dy2.device
     main = torch.cuda.current_stream(dev)
@@ -697,6 +736,7 @@ class BertLayerFn(torch.autograd.Function):
         p_a = cfg["p_attn"] if training else 0.0
         seed = rng.snapshot(x.device) if (p_h > 0 or p_a > 0) else None
         sid = cfg["layer_id"] * 16
+        s_attn, s_ln1, s_ln2 = rng.site(sid + 1), rng.site(sid + 2), rng.site(sid + 3)      # dropout sites of this layer
 
         wqkv = st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype)
         bqkv = st.span(st.data, P["qb"], P["vb"], (3 * H,))
@@ -704,15 +744,15 @@ class BertLayerFn(torch.autograd.Function):
             # forward-only (retrieval scoring, validation, the hard-negative scoring pass): nothing is kept for a
             # backward -- no gelu' stream out of the FFN1 GEMM, no LayerNorm statistics, no log-sum-exp
             qkv = linear_fwd(x2, wqkv, bqkv)
-            ctxv, _ = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, sid + 1, want_lse=False)
+            ctxv, _ = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn, want_lse=False)
             del qkv
             o1 = linear_fwd(ctxv, st.compute(P["ow"], dtype), P["ob"].data)
-            a, _, _ = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, sid + 2, want_stats=False)
+            a, _, _ = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, s_ln1, want_stats=False)
             del o1, ctxv
             u = linear_fwd(a, st.compute(P["iw"], dtype), P["ib"].data, EPI_GELU, None)
             o2 = linear_fwd(u, st.compute(P["fw"], dtype), P["fb"].data)
             del u
-            y, _, _ = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, sid + 3, want_stats=False)
+            y, _, _ = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, s_ln2, want_stats=False)
             return y.view(B, L, H)
         fp8 = bool(cfg.get("fp8")) and dtype == torch.bfloat16 and H % 128 == 0 and P["iw"].shape[0] % 128 == 0
         I_ = P["iw"].shape[0]
@@ -720,24 +760,24 @@ class BertLayerFn(torch.autograd.Function):
         if fp8:
             # e4m3 operands for the four forward GEMMs (per-tensor scales computed on the device), bf16 outputs
             qkv = linear_fwd_fp8(x2, st, P["qw"], P["vw"], (3 * H, H), bqkv)
-            ctxv, lse = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, sid + 1)
+            ctxv, lse = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn)
             o1 = linear_fwd_fp8(ctxv, st, P["ow"], P["ow"], (H, H), P["ob"].data)
-            a, mean1, rstd1 = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, sid + 2)
+            a, mean1, rstd1 = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, s_ln1)
             u = linear_fwd_fp8(a, st, P["iw"], P["iw"], (I_, H), P["ib"].data, EPI_GELU, pre, flags=GEMM_AUX_DERIV)
             o2 = linear_fwd_fp8(u, st, P["fw"], P["fw"], (H, I_), P["fb"].data)
         else:
             qkv = linear_fwd(x2, wqkv, bqkv)
-            ctxv, lse = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, sid + 1)
+            ctxv, lse = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn)
             o1 = linear_fwd(ctxv, st.compute(P["ow"], dtype), P["ob"].data)
-            a, mean1, rstd1 = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, sid + 2)
+            a, mean1, rstd1 = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, s_ln1)
             # `pre` holds gelu'(a W1^T + b1), not the pre-activation itself (UC2_GEMM_AUX_DERIV): one more exp2 beside
             # the forward's Phi(x) there, and the backward's dGELU epilogue becomes a plain multiply
             u = linear_fwd(a, st.compute(P["iw"], dtype), P["ib"].data, EPI_GELU, pre, flags=GEMM_AUX_DERIV)
             o2 = linear_fwd(u, st.compute(P["fw"], dtype), P["fb"].data)
-        y, mean2, rstd2 = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, sid + 3)
+        y, mean2, rstd2 = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, s_ln2)
 
         ctx.save_for_backward(x2, mask2d, qkv, ctxv, lse, o1, mean1, rstd1, a, pre, u, o2, mean2, rstd2, seed)
-        ctx.layer, ctx.cfg, ctx.shape, ctx.p = layer, cfg, (B, L, H, nh, D), (p_h, p_a, sid)
+        ctx.layer, ctx.cfg, ctx.shape, ctx.p = layer, cfg, (B, L, H, nh, D), (p_h, p_a, (s_attn, s_ln1, s_ln2))
         ctx.params, ctx.fp8 = params, fp8
         return y.view(B, L, H)
 
@@ -745,7 +785,7 @@ class BertLayerFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2, mask2d, qkv, ctxv, lse, o1, mean1, rstd1, a, pre, u, o2, mean2, rstd2, seed = ctx.saved_tensors
         B, L, H, nh, D = ctx.shape
-        p_h, p_a, sid = ctx.p
+        p_h, p_a, (s_attn, s_ln1, s_ln2) = ctx.p
         P = dict(zip(_P_NAMES, ctx.params))
         st = store_of(ctx.layer)
         dtype = x2.dtype
@@ -756,7 +796,7 @@ class BertLayerFn(torch.autograd.Function):
         G = st.grad_buf
 
         # LN2 and FFN
-        d_o2, dz2 = ln_bwd(dy2, o2, a, P["g2"].data, mean2, rstd2, G(P["g2"]), G(P["b2"]), p_h, seed, sid + 3,
+        d_o2, dz2 = ln_bwd(dy2, o2, a, P["g2"].data, mean2, rstd2, G(P["g2"]), G(P["b2"]), p_h, seed, s_ln2,
                            dbias=G(P["fb"]))
         fp8 = ctx.fp8
         I_ = P["iw"].shape[0]
@@ -772,7 +812,7 @@ class BertLayerFn(torch.autograd.Function):
         else:
             da = linear_dgrad(d_pre, st.compute(P["iw"], dtype), EPI_ADD, dz2)
         # LN1, output projection, attention, fused QKV
-        d_o1, dz1 = ln_bwd(da, o1, x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, sid + 2,
+        d_o1, dz1 = ln_bwd(da, o1, x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, s_ln1,
                            dbias=G(P["ob"]))
         linear_wgrad(d_o1, ctxv, G(P["ow"]), None)
         dctx = linear_dgrad_fp8(d_o1, st, P["ow"], P["ow"], (H, H)) if fp8 else linear_dgrad(d_o1, st.compute(P["ow"], dtype))
@@ -781,7 +821,7 @@ class BertLayerFn(torch.autograd.Function):
         # d(q|k|v bias) comes out of attn_bwd: column sums of the dQ/dK/dV accumulators, added up per workgroup in LDS and
         # flushed with one global atomic per column and workgroup (the separate column-sum pass re-read dqkv: 97 us)
         # (the fp32-math kernels run the column-sum pass inside uc2_attn_bwd)
-        dqkv = attn_bwd(qkv, mask2d, ctxv, dctx, lse, B, L, nh, D, p_a, seed, sid + 1, dbias=dbqkv)
+        dqkv = attn_bwd(qkv, mask2d, ctxv, dctx, lse, B, L, nh, D, p_a, seed, s_attn, dbias=dbqkv)
         linear_wgrad(dqkv, x2, dwqkv, None)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -995,6 +1035,7 @@ class LayerNormFn(torch.autograd.Function):
             if not r2.is_contiguous():
                 r2 = r2.contiguous()
         seed = rng.snapshot(x.device) if drop_p > 0 else None
+        seed_imm = rng.site(seed_imm)
         b = beta.data if beta_extra is None else (beta.data + beta_extra.data)
         y, mean, rstd = ln_fwd(x2, r2, gamma.data, b, eps, drop_p, seed, seed_imm, drop_after=drop_after)
         ctx.save_for_backward(x2, r2, mean, rstd, seed)
@@ -1432,6 +1473,7 @@ class AttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv2, mask2d, B, L, nh, D, drop_p, seed_imm):
         seed = rng.snapshot(qkv2.device) if drop_p > 0 else None
+        seed_imm = rng.site(seed_imm)
         ctxv, lse = attn_fwd(qkv2, mask2d, B, L, nh, D, drop_p, seed, seed_imm)
         ctx.save_for_backward(qkv2, mask2d, ctxv, lse, seed)
         ctx.cfg = (B, L, nh, D, drop_p, seed_imm)
