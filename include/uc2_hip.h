@@ -133,17 +133,19 @@ int uc2_attn_probs_mean(int dtype, int B, int L, int nh, int D, const void* qkv,
 
 /* general form for the MultiheadAttention API (model/attention.py:12-264): separate q / k / v (token-major rows
  * b*L + i, head h at column h*D, leading dimensions ld*), Lq != Lk allowed, additive key mask [B, Lk] and additive
- * attn_mask [Lq, Lk] (either may be NULL); fp32 math, no dropout.  delta: fp32 scratch [B, nh, Lq]. */
+ * attn_mask [Lq, Lk] (either may be NULL); fp32 math; dropout on the normalised probabilities (the way the reference's only
+ * user calls it, model/nlvr2.py:120-125,163-166) with the counter-based masks of uc2_attn_fwd: keep(q, k) is a function of
+ * (seed, batch, head, q, k), regenerated by the backward.  delta: fp32 scratch [B, nh, Lq]. */
 int uc2_attn_general_fwd(int dtype, int B, int Lq, int Lk, int nh, int D, const void* q, int ldq, const void* k, int ldk,
                          const void* v, int ldv, const float* key_mask, const float* attn_mask, float scale, void* ctx,
-                         int ldc, float* lse, void* stream);
+                         int ldc, float* lse, float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, void* stream);
 int uc2_attn_general_bwd(int dtype, int B, int Lq, int Lk, int nh, int D, const void* q, int ldq, const void* k, int ldk,
                          const void* v, int ldv, const float* key_mask, const float* attn_mask, float scale, const void* ctx,
                          const void* dctx, int ldc, const float* lse, float* delta, void* dq, int lddq, void* dk, int lddk,
-                         void* dv, int lddv, void* stream);
+                         void* dv, int lddv, float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, void* stream);
 int uc2_attn_general_probs_mean(int dtype, int B, int Lq, int Lk, int nh, int D, const void* q, int ldq, const void* k, int ldk,
                                 const float* key_mask, const float* attn_mask, float scale, const float* lse, float* out,
-                                void* stream);
+                                float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, void* stream);      /* (dropped weights, like the reference returns) */
 
 /* ---- embeddings and sequence assembly (model/model.py:280-335, 352-364, 412-425) ---------------------------- */
 int uc2_position_ids(int B, int T, const int64_t* ids, int64_t pad, int64_t* out, void* stream);

@@ -791,6 +791,59 @@ def test_multihead_attention_cross_and_attn_mask_vs_golden():
         check_against_golden(g, "mha_cross/grad/" + n, p.grad, 3e-3)
 
 
+def test_multihead_attention_cross_attention_with_dropout():
+    """the form the reference actually calls (model/nlvr2.py:120-125,163-166): cross-attention (key = value != query) with a key
+    padding mask AND attention dropout in training mode.  Masks are counter-based, so with the seed reset the forward repeats
+    bit for bit: (1) the returned weights are the eval-mode weights, each either dropped or scaled by 1/(1-p), at a keep rate of
+    1-p; (2) the output equals out_proj(dropped weights x projected values); (3) every input gradient matches central differences
+    of the same masked function; (4) p = 0 in training mode equals eval mode."""
+    from uc2_amd.model.attention import MultiheadAttention
+    E, nh, L, N, S, pdrop = 64, 1, 40, 6, 33, 0.25
+    m = MultiheadAttention(E, nh, dropout=pdrop)
+    synth.det_init_(m)
+    m.to(DEV)
+    q, k = synth.det_normal((L, N, E), 90).to(DEV), synth.det_normal((S, N, E), 91).to(DEV)
+    kpm = torch.zeros(N, S, dtype=torch.bool, device=DEV)
+    kpm[1, 20:] = True
+    m.eval()
+    o_eval, w_eval = m(q, k, k, key_padding_mask=kpm)
+
+    def train_fwd(qq, kk):
+        ops.rng.manual_seed(4242, DEV)
+        return m(qq, kk, kk, key_padding_mask=kpm)
+    m.train()
+    o1, w1 = train_fwd(q, k)
+    o2, w2 = train_fwd(q, k)
+    assert torch.equal(o1, o2) and torch.equal(w1, w2)
+    kept = w1 > 0
+    live = w_eval > 1e-12
+    assert torch.allclose(w1[kept], w_eval[kept] / (1 - pdrop), rtol=1e-5, atol=1e-9)
+    rate = float((kept & live).sum()) / float(live.sum())
+    assert abs(rate - (1 - pdrop)) < 0.03, rate
+    # (2) output from the dropped weights: out = out_proj(W_dropped @ (k W_v^T + b_v))
+    Wv, bv = m.in_proj_weight[2 * E:], m.in_proj_bias[2 * E:]
+    vproj = torch.einsum("sne,fe->snf", k, Wv) + bv                              # (S, N, E)
+    ctx = torch.einsum("nls,snf->lnf", w1, vproj)
+    want = torch.einsum("lnf,ef->lne", ctx, m.out_proj.weight) + m.out_proj.bias
+    assert max_rel(o1.detach().cpu(), want.detach().cpu()) < 1e-4
+    # (3) gradients against central differences with the masks held fixed
+    wgt = synth.det_normal((L, N, E), 92).to(DEV)
+    qg, kg = q.clone().requires_grad_(True), k.clone().requires_grad_(True)
+    (train_fwd(qg, kg)[0] * wgt).sum().backward()
+    f = lambda qq, kk: float((train_fwd(qq, kk)[0].detach().double() * wgt.double()).sum())
+    eps = 1e-2
+    for (t, g, idx) in ((q, qg.grad, (3, 1, 7)), (q, qg.grad, (39, 5, 60)), (k, kg.grad, (2, 0, 11)), (k, kg.grad, (30, 4, 5))):
+        tp, tm = t.clone(), t.clone()
+        tp[idx] += eps
+        tm[idx] -= eps
+        num = ((f(tp, k) - f(tm, k)) if t is q else (f(q, tp) - f(q, tm))) / (2 * eps)
+        assert abs(num - float(g[idx])) < 2e-2 * max(1.0, abs(num)), (idx, num, float(g[idx]))
+    # (4) p = 0 in training mode is the eval function
+    m.dropout = 0.0
+    o0, w0 = m(q, k, k, key_padding_mask=kpm)
+    assert torch.equal(o0, o_eval) and torch.equal(w0, w_eval)
+
+
 @pytest.mark.parametrize("task", ["itm", "mrfr", "mrc"])
 def test_device_collate_vs_reference_collates(task):
     """f1: flat pinned buffers -> two kernels -> the padded batch, against the reference's own xlmr_*_collate outputs

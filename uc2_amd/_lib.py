@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UC2_LIB_PATH") or os.path.join(_HERE, "libuc2_hip.so")      # (UC2_LIB_PATH: A/B of two builds on one box)
 _lib = None
-ABI_VERSION = 2          # include/uc2_hip.h; bumped whenever a signature changes
+ABI_VERSION = 3          # include/uc2_hip.h; bumped whenever a signature changes
 
 P, I, F, U64, I64, SZ = c_void_p, c_int, c_float, c_uint64, c_int64, c_size_t
 
@@ -37,9 +37,9 @@ SIGNATURES = {
     "uc2_attn_bwd": (I, [I, I, I, I, I, I, P, P, F, F, P, U64, P, P, P, P, P, P]),
     "uc2_attn_mfma_supported": (I, [I, I]),
     "uc2_attn_probs_mean": (I, [I, I, I, I, I, P, P, F, P, P]),
-    "uc2_attn_general_fwd": (I, [I, I, I, I, I, I, P, I, P, I, P, I, P, P, F, P, I, P, P]),
-    "uc2_attn_general_bwd": (I, [I, I, I, I, I, I, P, I, P, I, P, I, P, P, F, P, P, I, P, P, P, I, P, I, P, I, P]),
-    "uc2_attn_general_probs_mean": (I, [I, I, I, I, I, I, P, I, P, I, P, P, F, P, P, P]),
+    "uc2_attn_general_fwd": (I, [I, I, I, I, I, I, P, I, P, I, P, I, P, P, F, P, I, P, F, P, U64, P]),
+    "uc2_attn_general_bwd": (I, [I, I, I, I, I, I, P, I, P, I, P, I, P, P, F, P, P, I, P, P, P, I, P, I, P, I, F, P, U64, P]),
+    "uc2_attn_general_probs_mean": (I, [I, I, I, I, I, I, P, I, P, I, P, P, F, P, P, F, P, U64, P]),
     "uc2_position_ids": (I, [I, I, P, I64, P, P]),
     "uc2_embed_fwd": (I, [I, I, I, P, P, P, I, P, P, P, P, P]),
     "uc2_embed_bwd": (I, [I, I, I, P, P, P, P, P, P, P, I64, I64, P]),

@@ -6,7 +6,8 @@ packed projection.  That case maps one-to-one onto the fused path of the encoder
 attention kernel with an additive key mask, one output GEMM.  Separate query / key / value inputs
 (cross-attention) and an additive float attn_mask [L, S] run on the general kernels (attention_general.hip): three
 projections over row slices of the packed in_proj_weight, then uc2_attn_general_*.  What stays unimplemented
-(and raises): kdim / vdim != embed_dim, bias_kv, zero_attn, boolean or 3-D attn_mask, dropout on the general path.
+(and raises): kdim / vdim != embed_dim, bias_kv, zero_attn, boolean or 3-D attn_mask.  Attention dropout works on both paths
+(counter-based masks regenerated in the backward; the returned head-averaged weights are the dropped ones, like the reference's).
 """
 import torch
 from torch import nn
@@ -75,8 +76,6 @@ class MultiheadAttention(nn.Module):
 
     def _forward_general(self, query, key, value, key_padding_mask, need_weights, attn_mask):
         """cross-attention / additive attn_mask (model/attention.py:130-264 with the packed in_proj split in thirds)"""
-        if self.training and self.dropout > 0:
-            raise NotImplementedError("attention dropout is implemented on the packed self-attention path only")
         L, N, E = query.shape
         S = key.shape[0]
         if key.shape != value.shape or key.shape[1] != N or key.shape[2] != E:
@@ -98,12 +97,16 @@ class MultiheadAttention(nn.Module):
         if key_padding_mask is not None:
             kmask = torch.zeros((N, S), dtype=torch.float32, device=query.device)
             kmask.masked_fill_(key_padding_mask.to(torch.bool), -1e30)
+        # attention dropout (the reference's NLVR2 head calls this path with attention_probs_dropout_prob, model/nlvr2.py:120-125)
+        p = float(self.dropout) if self.training else 0.0
+        seed = ops.rng.snapshot(q.device) if p > 0 else None
+        site = ops.rng.site(0x4D49)
         ctx, lse = ops.AttentionGeneralFn.apply(q.reshape(N * L, E), k.reshape(N * S, E), v.reshape(N * S, E), kmask, attn_mask,
-                                                N, L, S, self.num_heads, self.head_dim)
+                                                N, L, S, self.num_heads, self.head_dim, p, seed, site)
         out = self.out_proj(ctx.view(N, L, E)).transpose(0, 1)
         weights = None
         if need_weights:
             with torch.no_grad():
                 weights = ops.attn_general_probs_mean(q.detach().reshape(N * L, E), k.detach().reshape(N * S, E), kmask,
-                                                      attn_mask, lse, N, L, S, self.num_heads, self.head_dim)
+                                                      attn_mask, lse, N, L, S, self.num_heads, self.head_dim, p, seed, site)
         return out, weights

@@ -1489,40 +1489,42 @@ class AttentionFn(torch.autograd.Function):
 
 class AttentionGeneralFn(torch.autograd.Function):
     """softmax(scale q k^T + key_mask + attn_mask) v with separate q / k / v [B*L, nh*D] tensors (cross-attention,
-    additive attn_mask): the general form behind MultiheadAttention (model/attention.py:12-264); fp32 math, no dropout"""
+    additive attn_mask): the general form behind MultiheadAttention (model/attention.py:12-264); fp32 math; dropout on the
+    probabilities with counter-based masks (the seed copy is a third, non-differentiable output for need_weights)"""
 
     @staticmethod
-    def forward(ctx, q2, k2, v2, key_mask, attn_mask, B, Lq, Lk, nh, D):
+    def forward(ctx, q2, k2, v2, key_mask, attn_mask, B, Lq, Lk, nh, D, drop_p=0.0, seed=None, seed_imm=0):
+        """seed: the caller's dropout seed copy (rng.snapshot; it also feeds attn_general_probs_mean), seed_imm: its site number"""
         q2, k2, v2 = q2.contiguous(), k2.contiguous(), v2.contiguous()
         H = nh * D
         out = torch.empty((B * Lq, H), dtype=q2.dtype, device=q2.device)
         lse = torch.empty((B, nh, Lq), dtype=torch.float32, device=q2.device)
         call("uc2_attn_general_fwd", dt(q2.dtype), B, Lq, Lk, nh, D, ptr(q2), H, ptr(k2), H, ptr(v2), H, ptr(key_mask),
-             ptr(attn_mask), 1.0 / math.sqrt(D), ptr(out), H, ptr(lse), stream())
-        ctx.save_for_backward(q2, k2, v2, key_mask, attn_mask, out, lse)
-        ctx.cfg = (B, Lq, Lk, nh, D)
+             ptr(attn_mask), 1.0 / math.sqrt(D), ptr(out), H, ptr(lse), float(drop_p), ptr(seed), seed_imm, stream())
+        ctx.save_for_backward(q2, k2, v2, key_mask, attn_mask, out, lse, seed)
+        ctx.cfg = (B, Lq, Lk, nh, D, float(drop_p), seed_imm)
         ctx.mark_non_differentiable(lse)
         return out, lse
 
     @staticmethod
     def backward(ctx, dout, _dlse):
-        q2, k2, v2, key_mask, attn_mask, out, lse = ctx.saved_tensors
-        B, Lq, Lk, nh, D = ctx.cfg
+        q2, k2, v2, key_mask, attn_mask, out, lse, seed = ctx.saved_tensors
+        B, Lq, Lk, nh, D, drop_p, seed_imm = ctx.cfg
         H = nh * D
         dout = dout.contiguous()
         dq, dk, dv = torch.empty_like(q2), torch.empty_like(k2), torch.empty_like(v2)
         delta = torch.empty((B, nh, Lq), dtype=torch.float32, device=q2.device)
         call("uc2_attn_general_bwd", dt(q2.dtype), B, Lq, Lk, nh, D, ptr(q2), H, ptr(k2), H, ptr(v2), H, ptr(key_mask),
              ptr(attn_mask), 1.0 / math.sqrt(D), ptr(out), ptr(dout), H, ptr(lse), ptr(delta), ptr(dq), H, ptr(dk), H,
-             ptr(dv), H, stream())
-        return dq, dk, dv, None, None, None, None, None, None, None
+             ptr(dv), H, drop_p, ptr(seed), seed_imm, stream())
+        return dq, dk, dv, None, None, None, None, None, None, None, None, None, None
 
 
-def attn_general_probs_mean(q2, k2, key_mask, attn_mask, lse, B, Lq, Lk, nh, D):
+def attn_general_probs_mean(q2, k2, key_mask, attn_mask, lse, B, Lq, Lk, nh, D, drop_p=0.0, seed=None, seed_imm=0):
     out = torch.empty((B, Lq, Lk), dtype=torch.float32, device=q2.device)
     H = nh * D
     call("uc2_attn_general_probs_mean", dt(q2.dtype), B, Lq, Lk, nh, D, ptr(q2), H, ptr(k2), H, ptr(key_mask), ptr(attn_mask),
-         1.0 / math.sqrt(D), ptr(lse), ptr(out), stream())
+         1.0 / math.sqrt(D), ptr(lse), ptr(out), float(drop_p), ptr(seed), seed_imm, stream())
     return out
 
 
