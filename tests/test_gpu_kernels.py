@@ -621,6 +621,27 @@ def test_gemm_two_phase_pingpong_equals_pingpong(ta, tb, M, N, K):
     assert torch.equal(o, r)
 
 
+@pytest.mark.parametrize("M,N,K,pad", [(256, 256, 128, 0), (1024, 768, 512, 256), (2560, 768, 4608, 64), (768, 1024, 2048, 0)])
+def test_gemm_pingpong_unsplit_weight_gradient_accumulates_in_place(M, N, K, pad):
+    """C[M,N] fp32 += A^T B with split_k = 1 on the ping-pong kernel (the tied decoder's dE += dlogits^T z, DecoderCEFn.backward:
+    a vocabulary-long output that needs no split): the accumulators leave through the line-wide partial-tile store with the old C
+    read two groups ahead.  Bit-identical to the generic kernel (same per-element summation order, one fp32 add), leading dimension
+    larger than M like the padded vocabulary, twice in a row (C accumulates twice), race screen."""
+    a = rnd((K, M + pad), 1, dtype=torch.bfloat16)[:, :M]
+    b = rnd((K, N), 2, dtype=torch.bfloat16)
+    c0 = rnd((M, N), 3)
+    ref = c0.clone()
+    for _ in range(2):
+        ops.gemm(a, b, M, N, K, ta=True, tb=True, out=ref, accumulate=True, lda=a.stride(0), variant=99)
+    for _ in range(3):
+        out = c0.clone()
+        for _ in range(2):
+            ops.gemm(a, b, M, N, K, ta=True, tb=True, out=out, accumulate=True, lda=a.stride(0), variant=8)
+        assert torch.equal(out, ref)
+    want = c0.double() + 2 * (a.double().t() @ b.double())
+    assert rel_err(out.double(), want) < 1e-5
+
+
 def test_gemm_pingpong_skew_and_deferred_reduce():
     """start skew between phase groups changes timing only; the split-K reduction pass run on its own
     (UC2_GEMM_DEFER_REDUCE + uc2_gemm_splitk_reduce) equals the fused call; without a workspace the same call

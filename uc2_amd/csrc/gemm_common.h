@@ -4,7 +4,8 @@
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_ADD = 3, EPI_TANH = 4,
        EPI_GELU_D = 5, EPI_MUL = 6,       // internal to the ping-pong kernel: EPI_GELU / EPI_DGELU under GemmArgs::aux_deriv
-       EPI_GELU_NOAUX = 7 };              // ... and EPI_GELU without a second output stream (aux_out == NULL)
+       EPI_GELU_NOAUX = 7,                // ... and EPI_GELU without a second output stream (aux_out == NULL)
+       EPI_ACC = 8 };                     // ... fp32 C += tile through the line-wide partial-tile store (unsplit weight gradient)
 
 struct GemmArgs {
   const void* A; const void* B; void* C;

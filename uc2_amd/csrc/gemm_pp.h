@@ -356,29 +356,48 @@ __device__ __forceinline__ void pp_epi_store(const GemmArgs& p, const PpOut& out
 // consecutive columns per register group; through the same LDS transposition -> whole 128-byte lines,
 // 32 stores per wave (compile-time count, full tiles)
 typedef __attribute__((ext_vector_type(4))) float f32x4v;
-template <int HI>
+template <int HI, bool ACCUM = false>
 __device__ __forceinline__ void pp_partial_store(float* __restrict__ dst, int ldn, const f32x16 (&acc)[2][2][2], int mb0, int nb,
                                                  int lane, const TpAddr& ta) {
   const int lr = lane >> 3, lc = lane & 7;
+  // ACCUM: dst += tile (a weight gradient that is not split: the vocabulary-long dE of the tied decoder).  The 16-byte pieces a
+  // lane will store are also the pieces it loads, two groups (8 loads) ahead of their use, so the read of C hides behind the
+  // transposition and the stores of the groups before it.
+  constexpr int NG = 2 * (2 + HI);                     // groups (hh, i, j), in store order
+  auto rowp = [&](int g) __attribute__((always_inline)) {
+    const int hh = g >> 2, i = (g >> 1) & 1, j = g & 1;
+    return dst + (size_t)(mb0 + hh * 64 + i * 32 + lr) * ldn + nb + 32 * j + 4 * lc;
+  };
+  f32x4v cin[2][4];
+  if (ACCUM) {
 #pragma unroll
-  for (int hh = 0; hh < 2; ++hh)
+    for (int g = 0; g < 2; ++g)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (hh == 1 && i >= HI) continue;
+      for (int it = 0; it < 4; ++it) cin[g][it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(rowp(g) + (size_t)(8 * it) * ldn));
+  }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        bf16x8 w[4], t[4];                              // 16 bytes = 4 floats (columns 32j + 8c + 4h .. +3  ->  chunk 2c + h)
+  for (int g = 0; g < NG; ++g) {
+    const int hh = g >> 2, i = (g >> 1) & 1, j = g & 1;
+    bf16x8 w[4], t[4];                                  // 16 bytes = 4 floats (columns 32j + 8c + 4h .. +3  ->  chunk 2c + h)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          w[c] = __builtin_bit_cast(bf16x8, make_float4(acc[hh][i][j][4 * c], acc[hh][i][j][4 * c + 1], acc[hh][i][j][4 * c + 2], acc[hh][i][j][4 * c + 3]));
-        tp_write(ta.rh[0], w[0]); tp_write(ta.rh[1], w[1]); tp_write(ta.rh[2], w[2]); tp_write(ta.rh[3], w[3]);
-        tp_read_o<0>(t[0], ta.line); tp_read_o<1024>(t[1], ta.line); tp_read_o<2048>(t[2], ta.line); tp_read_o<3072>(t[3], ta.line);
-        TP_WAIT4(t[0], t[1], t[2], t[3]);
-        float* row = dst + (size_t)(mb0 + hh * 64 + i * 32 + lr) * ldn + nb + 32 * j + 4 * lc;
+    for (int c = 0; c < 4; ++c)
+      w[c] = __builtin_bit_cast(bf16x8, make_float4(acc[hh][i][j][4 * c], acc[hh][i][j][4 * c + 1], acc[hh][i][j][4 * c + 2], acc[hh][i][j][4 * c + 3]));
+    tp_write(ta.rh[0], w[0]); tp_write(ta.rh[1], w[1]); tp_write(ta.rh[2], w[2]); tp_write(ta.rh[3], w[3]);
+    tp_read_o<0>(t[0], ta.line); tp_read_o<1024>(t[1], ta.line); tp_read_o<2048>(t[2], ta.line); tp_read_o<3072>(t[3], ta.line);
+    TP_WAIT4(t[0], t[1], t[2], t[3]);
+    float* row = rowp(g);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) __builtin_nontemporal_store(__builtin_bit_cast(f32x4v, t[it]), reinterpret_cast<f32x4v*>(row + (size_t)(8 * it) * ldn));
-      }
+    for (int it = 0; it < 4; ++it) {
+      f32x4v v = __builtin_bit_cast(f32x4v, t[it]);
+      if (ACCUM) v += cin[g & 1][it];
+      __builtin_nontemporal_store(v, reinterpret_cast<f32x4v*>(row + (size_t)(8 * it) * ldn));
     }
+    if (ACCUM && g + 2 < NG) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        cin[g & 1][it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(rowp(g + 2) + (size_t)(8 * it) * ldn));
+    }
+  }
 }
 
 template <> __device__ __forceinline__ void wait_vmcnt<40>() { asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); }

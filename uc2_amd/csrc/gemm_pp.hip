@@ -368,13 +368,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     if (!store) {
       ticket_ready(); ticket_publish();
       younger = GKT;
-    } else if (TACC && p.partial) {                     // split-K item of a two-stage reduction (fp32 partial, plain stores)
-      {
+    } else if (TACC && (EPI == EPI_ACC || p.partial)) { // split-K item of a two-stage reduction (fp32 partial, plain stores),
+      {                                                 // or C += tile for an unsplit fp32 weight gradient (EPI_ACC)
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const TpAddr tpa = tp_addr(lds0 + 131072u + (unsigned)w * 4096u, ln);
         ticket_ready();
-        pp_partial_store<HI>(p.partial + (size_t)ez * p.M * p.N, p.N, acc, em0, en0, ln, tpa);
+        if (EPI == EPI_ACC) pp_partial_store<HI, true>(reinterpret_cast<float*>(p.C), p.ldc, acc, em0, en0, ln, tpa);
+        else pp_partial_store<HI>(p.partial + (size_t)ez * p.M * p.N, p.N, acc, em0, en0, ln, tpa);
       }
       ticket_publish();
       younger = GKT + 2 * NST;
@@ -483,6 +484,8 @@ void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t
     else if (!trans_a && trans_b) pp_launch0<false, true, true, EPI_NONE>(p, st);
     else if (trans_a && !trans_b) pp_launch0<true, false, true, EPI_NONE>(p, st);
     else pp_launch0<true, true, true, EPI_NONE>(p, st);
+  } else if (p.c_f32 && p.accumulate && !(p.atomic & 1) && p.split_k == 1 && !p.bias && p.alpha == 1.0f && !p.alpha_dev && trans_a && trans_b) {
+    pp_launch0<true, true, true, EPI_ACC>(p, st);      // dE += dlogits^T z: the accumulators leave as whole lines, C read ahead
   } else if (p.c_f32) {
     if (!trans_a && !trans_b) pp_launch0<false, false, false, EPI_NONE>(p, st);
     else if (!trans_a && trans_b) pp_launch0<false, true, false, EPI_NONE>(p, st);
