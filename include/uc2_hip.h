@@ -82,6 +82,20 @@ int uc2_gemm_queued(int dtype, int trans_a, int trans_b, int M, int N, int K, co
                     void* queue, void* stream);
 int uc2_gemm_splitk_reduce(int M, int N, void* C, int ldc, int split_k, int accumulate, const void* workspace,
                            size_t workspace_bytes, void* stream);
+/* Grouped weight gradients: dW_i[n_out_i, n_in_i] (fp32) += dY_i[rows, n_out_i]^T X_i[rows, n_in_i] for up to four linear
+ * layers that share the token axis -- the four dense layers of one BertLayer (model/layer.py:75-156; autograd issues their
+ * weight gradients one GEMM at a time) -- as ONE launch of the persistent ping-pong kernel over all (tile, k-split) items
+ * plus one reduction launch.  At the reference's 104-pair micro-batch (~10 k tokens, config/uc2_pretrain.json:17-19) a single
+ * weight gradient has 9-36 output tiles and fills half of the 256 CUs for one round; four of them in one launch fill them.
+ * bf16 only; n_out, n_in multiples of 256, rows a multiple of 128; workspace >= uc2_gemm_wgrad_group_workspace bytes of
+ * caller-owned device memory.  Returns -2 (nothing launched) for shapes it does not take: issue uc2_gemm per item then. */
+typedef struct {
+  const void* dy; const void* x; void* dw;
+  int lddy, ldx, lddw, n_out, n_in, split_k;
+} Uc2WgradItem;
+size_t uc2_gemm_wgrad_group_workspace(int n, const Uc2WgradItem* items);
+int uc2_gemm_wgrad_group(int dtype, int n, const Uc2WgradItem* items, int rows, void* workspace, size_t workspace_bytes,
+                         void* stream);
 
 /* ---- fp8 (OCP e4m3) forward / input-gradient GEMMs (BASELINE.json configs[4]; the reference's mixed precision is apex
  *      amp O2 fp16 -- pretrain.py:463-465 -- so this extends the bf16 mode behind the same layer interfaces) ----------

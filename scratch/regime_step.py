@@ -31,6 +31,8 @@ torch.cuda.synchronize()
 import time
 t0 = time.perf_counter()
 for _ in range(nsteps): step()
+th = (time.perf_counter() - t0) / nsteps          # host enqueue time (the loop does not wait for the GPU)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / nsteps
+print("host enqueue %.2f ms per optimizer step" % (th * 1e3))
 print("%s regime: %.2f ms per optimizer step, %.0f pairs/s, mfma %.4f" % (task, dt * 1e3, 312 / dt, 312 / dt * 49.94e9 / 2.5e15))

@@ -642,6 +642,42 @@ def test_gemm_pingpong_unsplit_weight_gradient_accumulates_in_place(M, N, K, pad
     assert rel_err(out.double(), want) < 1e-5
 
 
+@pytest.mark.parametrize("rows", [384, 3072, 9984])
+def test_gemm_grouped_weight_gradients(rows):
+    """uc2_gemm_wgrad_group: the four weight gradients of a BertLayer (dW_i += dY_i^T X_i over the same tokens) as ONE launch of
+    the persistent ping-pong kernel over all (tile, k-split) items + one reduction launch -- against the four separate GEMMs and
+    an fp64 product; repeated launches bit-identical (no atomics); a leading dimension larger than the width (dW inside the fused
+    q|k|v gradient span); shapes the grouped kernel does not take fall back to one GEMM per item."""
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    tr = []
+    for i, (no, ni) in enumerate(shapes):
+        dy = rnd((rows, no), 10 + i, dtype=torch.bfloat16)
+        x = rnd((rows, ni), 20 + i, dtype=torch.bfloat16)
+        dw = rnd((no, ni + (256 if i == 3 else 0)), 30 + i)[:, :ni]
+        tr.append((dy, x, dw))
+    sep = [dw.clone() for _, _, dw in tr]
+    for (dy, x, _), r in zip(tr, sep):
+        ops._linear_wgrad_now(dy, x, r, None)
+    outs = []
+    for _ in range(3):
+        got = [(dy, x, dw.clone()) for dy, x, dw in tr]          # (clone keeps the strides of the span view)
+        assert got[3][2].stride(0) == tr[3][2].stride(0) or got[3][2].is_contiguous()
+        ops.wgrad_group(got)
+        outs.append([g for _, _, g in got])
+    for k in range(4):
+        assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[0][k], outs[2][k])
+        want = tr[k][2].double() + tr[k][0].double().t() @ tr[k][1].double()
+        assert rel_err(outs[0][k].double(), want) < 2e-6
+        assert rel_err(outs[0][k], sep[k]) < 2e-6
+    # a width that is not a multiple of 256: the same call goes through the per-item path
+    dy = rnd((rows, 768), 40, dtype=torch.bfloat16)
+    x = rnd((rows, 200), 41, dtype=torch.bfloat16)
+    dw = rnd((768, 200), 42)
+    ref = dw.double() + dy.double().t() @ x.double()
+    ops.wgrad_group([(dy, x, dw)])
+    assert rel_err(dw.double(), ref) < 2e-5
+
+
 def test_gemm_pingpong_skew_and_deferred_reduce():
     """start skew between phase groups changes timing only; the split-K reduction pass run on its own
     (UC2_GEMM_DEFER_REDUCE + uc2_gemm_splitk_reduce) equals the fused call; without a workspace the same call

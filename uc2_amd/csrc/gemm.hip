@@ -303,6 +303,91 @@ extern "C" int uc2_gemm_splitk_reduce(int M, int N, void* C, int ldc, int split_
   return 0;
 }
 
+// ---- grouped weight gradients: ONE launch of the persistent ping-pong kernel over the split-K items of up to four
+//      dW_i[n_out_i, n_in_i] += dY_i^T X_i that share the contraction (`rows` tokens), then one reduction launch.
+//      At ~10 k tokens (the reference's 104-pair micro-batch) a layer's four weight gradients are 27 + 9 + 36 + 36 output
+//      tiles: launched one by one, each runs a single round of 117-144 items on 256 CUs (50 % of the chip idle, 215 us
+//      for the four); as one launch of 216 items, 136 us.
+struct Uc2WgradItem {             // mirrors include/uc2_hip.h
+  const void* dy; const void* x; void* dw;
+  int lddy, ldx, lddw, n_out, n_in, split_k;
+};
+struct ReduceGroup { int n; size_t end4[UC2_GEMM_MAX_GROUP]; const float* ws[UC2_GEMM_MAX_GROUP]; float* C[UC2_GEMM_MAX_GROUP];
+                     int M[UC2_GEMM_MAX_GROUP], N[UC2_GEMM_MAX_GROUP], ldc[UC2_GEMM_MAX_GROUP], split[UC2_GEMM_MAX_GROUP]; };
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(ReduceGroup r) {
+  const size_t total = r.end4[r.n - 1];
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int g = 0;
+#pragma unroll
+    for (int k = 1; k < UC2_GEMM_MAX_GROUP; ++k) if (k < r.n && i >= r.end4[k - 1]) g = k;
+    const size_t li = i - (g ? r.end4[g - 1] : 0);
+    const size_t mn = (size_t)r.M[g] * r.N[g];
+    const float* ws = r.ws[g];
+    float4 a = reinterpret_cast<const float4*>(ws)[li];
+    for (int z = 1; z < r.split[g]; ++z) {
+      const float4 b = reinterpret_cast<const float4*>(ws + (size_t)z * mn)[li];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const size_t e = li * 4, m = e / r.N[g], n = e - m * r.N[g];
+    float4* c = reinterpret_cast<float4*>(r.C[g] + m * r.ldc[g] + n);
+    const float4 o = *c;
+    a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+    *c = a;
+  }
+}
+void uc2_gemm_pp_group_launch(const GemmArgs& p, hipStream_t st);       // gemm_pp.hip
+
+extern "C" size_t uc2_gemm_wgrad_group_workspace(int n, const Uc2WgradItem* items) {
+  size_t b = 0;
+  for (int i = 0; i < n; ++i) b += (size_t)items[i].split_k * items[i].n_out * items[i].n_in * sizeof(float);
+  return b;
+}
+// returns 0, an error code, or -2 when the shapes are not ones the grouped kernel takes (the caller then issues uc2_gemm per item)
+extern "C" int uc2_gemm_wgrad_group(int dtype, int n, const Uc2WgradItem* items, int rows, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  UC2_CHECK_ARG(n >= 1 && items);
+  if (dtype != 1 || n > UC2_GEMM_MAX_GROUP || rows < 128 || (rows & 63)) return -2;
+  UC2_CHECK_ARG(workspace && uc2_gemm_wgrad_group_workspace(n, items) <= workspace_bytes && ((uintptr_t)workspace & 15) == 0);
+  GemmArgs p{};
+  ReduceGroup r{};
+  p.epi = EPI_NONE; p.c_f32 = 1; p.accumulate = 1; p.split_k = 1; p.alpha = 1.0f; p.ngroup = n;
+  const int ktiles = rows / 64;
+  float* ws = reinterpret_cast<float*>(workspace);
+  int item0 = 0;
+  size_t end4 = 0;
+  for (int i = 0; i < n; ++i) {
+    const Uc2WgradItem& it = items[i];
+    UC2_CHECK_ARG(it.dy && it.x && it.dw && it.split_k >= 1);
+    const int per = ((ktiles + it.split_k - 1) / it.split_k + 1) & ~1;
+    if ((it.n_out & 255) || (it.n_in & 255) || (it.lddy & 7) || (it.ldx & 7) || (it.lddw & 3) || ((uintptr_t)it.dy & 15) ||
+        ((uintptr_t)it.x & 15) || ((uintptr_t)it.dw & 15) || per < 2 || (ktiles & 1) || (it.split_k - 1) * per >= ktiles ||
+        ((ktiles - (it.split_k - 1) * per) & 1) ||
+        (size_t)rows * it.lddy * 2 >= (1ull << 32) || (size_t)rows * it.ldx * 2 >= (1ull << 32))
+      return -2;                                          // (32-bit operand offsets, even k-tile counts per item, whole 256 x 256 tiles)
+    GemmProb& q = p.grp[i];
+    q.A = it.dy; q.B = it.x; q.partial = ws; q.M = it.n_out; q.N = it.n_in; q.lda = it.lddy; q.ldb = it.ldx;
+    q.nbx = it.n_in / 256; q.mt = it.n_out / 256; q.per = per; q.ktiles = ktiles; q.item0 = item0;
+    { int cg = q.nbx; if (cg > 6) { cg = 1; for (int d = 6; d >= 2; --d) if (q.nbx % d == 0) { cg = d; break; } if (cg == 1) cg = 6; } q.col_group = cg; }
+    item0 += q.nbx * q.mt * it.split_k;
+    const size_t mn = (size_t)it.n_out * it.n_in;
+    end4 += mn / 4;
+    r.end4[i] = end4; r.ws[i] = ws; r.C[i] = reinterpret_cast<float*>(it.dw); r.M[i] = it.n_out; r.N[i] = it.n_in; r.ldc[i] = it.lddw;
+    r.split[i] = it.split_k;
+    ws += mn * it.split_k;
+  }
+  p.grp_items = item0;
+  r.n = n;
+  // (fields of the single-problem path the kernel still reads before its first item: keep them consistent with problem 0)
+  p.A = p.grp[0].A; p.B = p.grp[0].B; p.M = p.grp[0].M; p.N = p.grp[0].N; p.K = rows; p.lda = p.grp[0].lda; p.ldb = p.grp[0].ldb;
+  p.col_group = p.grp[0].col_group;
+  hipStream_t st = (hipStream_t)stream;
+  uc2_gemm_pp_group_launch(p, st);
+  const int blocks = (int)((end4 + 255) / 256 < 2048 ? (end4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(blocks), dim3(256), 0, st, r);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
 static int gemm_impl(int dtype, int trans_a, int trans_b, int M, int N, int K,
                      const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_is_f32,
                      const float* bias, int epilogue, const void* aux_in, void* aux_out, int ldaux,
@@ -319,7 +404,7 @@ static int gemm_impl(int dtype, int trans_a, int trans_b, int M, int N, int K,
   if (M == 0 || N == 0) return 0;
   if (K == 0 && accumulate) return 0;                 // empty contraction (a weight gradient over zero rows): C += 0
   UC2_CHECK_ARG(C && (K == 0 || (A && B)));
-  GemmArgs p;
+  GemmArgs p{};
   p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux ? ldaux : ldc;
   p.epi = epilogue; p.c_f32 = (dtype == 0) ? 1 : c_is_f32; p.accumulate = accumulate;

@@ -5,7 +5,18 @@
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_ADD = 3, EPI_TANH = 4,
        EPI_GELU_D = 5, EPI_MUL = 6,       // internal to the ping-pong kernel: EPI_GELU / EPI_DGELU under GemmArgs::aux_deriv
        EPI_GELU_NOAUX = 7,                // ... and EPI_GELU without a second output stream (aux_out == NULL)
-       EPI_ACC = 8 };                     // ... fp32 C += tile through the line-wide partial-tile store (unsplit weight gradient)
+       EPI_ACC = 8,                       // ... fp32 C += tile through the line-wide partial-tile store (unsplit weight gradient)
+       EPI_GROUP = 9 };                   // ... one launch over the split-K items of up to four weight gradients (GemmArgs::grp)
+
+// One problem of a grouped weight-gradient launch (uc2_gemm_wgrad_group): dW[M,N] += A^T B over `ktiles` 64-row k-tiles,
+// A = dY [rows][M] and B = X [rows][N] both k-strided; items item0 .. item0 + ntile * split - 1 of the launch, tile-major
+// inside a split; fp32 partial tiles [split][M][N] at `partial`.
+struct GemmProb {
+  const void* A; const void* B; float* partial;
+  int M, N, lda, ldb;
+  int nbx, mt, col_group, per, ktiles, item0;
+};
+#define UC2_GEMM_MAX_GROUP 4
 
 struct GemmArgs {
   const void* A; const void* B; void* C;
@@ -28,6 +39,8 @@ struct GemmArgs {
   int aux_deriv;         // UC2_GEMM_AUX_DERIV: EPI_GELU stores gelu'(pre) (not pre) to aux_out, EPI_DGELU multiplies by aux_in as is
   int spare_cus;         // persistent kernels: CUs left without a workgroup (for a kernel running beside this one on another stream)
   int* queue;            // ping-pong kernel: caller-owned item queue (9 zeroed ints: next-item counter per XCD + exit count), or null = static partition
+  int ngroup, grp_items; // EPI_GROUP: problems and total work items of the launch
+  GemmProb grp[UC2_GEMM_MAX_GROUP];
 };
 
 // ------------------------------------------------------------------------------------------

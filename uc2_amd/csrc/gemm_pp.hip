@@ -48,16 +48,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   constexpr int GA1 = HI == 2 ? 2 : 1;                      // LDS-DMA instructions per wave for unit A1
   constexpr int GKT = 6 + GA1;                             // ... per k-tile
   constexpr int NST = (2 + HI) * 4;                        // bf16 stores per wave in the direct epilogue
+  constexpr bool GRP = EPI == EPI_GROUP;                  // grouped launch: operands, shapes and the partial-tile destination are per item
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const bf16* __restrict__ A = reinterpret_cast<const bf16*>(p.A);
-  const bf16* __restrict__ B = reinterpret_cast<const bf16*>(p.B);
+  const bf16* A = reinterpret_cast<const bf16*>(p.A);
+  const bf16* B = reinterpret_cast<const bf16*>(p.B);
   const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), wr = w >> 2, wc = w & 3;
 
   // ---- work items: (tile, k-split), tile-major inside a split.  Workgroups land on XCD blockIdx % 8; each XCD
   //      owns a contiguous range of items (neighbouring tiles share an A row panel in that XCD's L2) and its
   //      workgroups stride through it together.
   const int nbx = p.N / 256, ntile = nbx * (p.M / RT);
-  const int nitems = ntile * p.split_k;
+  const int nitems = GRP ? p.grp_items : ntile * p.split_k;
   const int ktiles = p.K / 64, per = ((ktiles + p.split_k - 1) / p.split_k + 1) & ~1;     // k-tiles per split: even
   int item, item_end, item_step;
   {
@@ -99,8 +100,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     for (int i = 0; i < g * p.skew; ++i) __builtin_amdgcn_s_sleep(127);
   }
 
-  const unsigned stepa = (TA ? 64u * (unsigned)p.lda : 64u) * 2u;      // bytes per k-tile
-  const unsigned stepb = (TB ? 64u * (unsigned)p.ldb : 64u) * 2u;
+  unsigned stepa = (TA ? 64u * (unsigned)p.lda : 64u) * 2u;            // bytes per k-tile (grouped launch: set per item)
+  unsigned stepb = (TB ? 64u * (unsigned)p.ldb : 64u) * 2u;
+  float* pdst = nullptr; float* pdstx = nullptr;                       // grouped launch: partial tile of the item computed / staged
+  int pld = 0, pldx = 0;
   const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((lds_void_p)smem);
   unsigned fa[2], fa1[2], fb;                                    // fragment addresses (buffer 0; the other is + 65536)
   fa[0] = lds0 + pp_frag_off<TA>(wr * 64, lane);                 // unit A0: 64 rows per wave row
@@ -114,6 +117,39 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   unsigned src[4][2];           // staging sources as 32-bit byte offsets from A / B (SGPR base + VGPR offset addressing:
                                 // half the registers of 64-bit pointers); unit type J (0 A0, 1 B0, 2 B1, 3 A1), wave-instructions w, w + 8
   auto setup = [&](int it) __attribute__((always_inline)) {
+    if (GRP) {
+      // which problem: items are numbered problem by problem (item0 ascending); everything below is wave-uniform
+      int g = 0;
+#pragma unroll
+      for (int i = 1; i < UC2_GEMM_MAX_GROUP; ++i) if (i < p.ngroup && it >= p.grp[i].item0) g = i;
+      const GemmProb& q = p.grp[g];
+      const int lit = it - q.item0, ntl = q.nbx * q.mt;
+      const int z = lit / ntl, tile = lit - z * ntl;
+      zx = z;
+      {
+        const int cg = q.col_group, per_group = q.mt * cg;
+        const int gg = tile / per_group, r = tile - gg * per_group;
+        const int cw = min(cg, q.nbx - gg * cg);
+        const int tm = r / cw, tc = r - tm * cw;
+        m0x = tm * RT; n0x = (gg * cg + tc) * 256;
+      }
+      const int tbeg = z * q.per;
+      ntx = min(q.ktiles, tbeg + q.per) - tbeg;
+      const int kbeg = tbeg * 64;
+      A = reinterpret_cast<const bf16*>(q.A); B = reinterpret_cast<const bf16*>(q.B);
+      stepa = 128u * (unsigned)q.lda; stepb = 128u * (unsigned)q.ldb;
+      pdstx = q.partial + (size_t)z * q.M * q.N; pldx = q.N;
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        src[0][qq] = (unsigned)((const char*)pp_src<TA, 0, HI>(A, q.lda, q.M, m0x, kbeg, w + 8 * qq, ln) - (const char*)A);
+        src[1][qq] = (unsigned)((const char*)pp_src<TB, 1, HI>(B, q.ldb, q.N, n0x, kbeg, w + 8 * qq, ln) - (const char*)B);
+        src[2][qq] = (unsigned)((const char*)pp_src<TB, 2, HI>(B, q.ldb, q.N, n0x, kbeg, w + 8 * qq, ln) - (const char*)B);
+        src[3][qq] = (unsigned)((const char*)pp_src<TA, 3, HI>(A, q.lda, q.M, m0x, kbeg, w + 8 * qq, ln) - (const char*)A);
+      }
+      return;
+    }
     const int z = it / ntile, tile = it - z * ntile;
     zx = z;
     {
@@ -270,6 +306,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
 #define PP_STAMP(I) do { if (dbg && nitem_done == 2) { unsigned long long t64_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t64_) :: "memory"); ts[I] = (unsigned)t64_; } } while (0)
   setup(item);
   m0 = m0x; n0 = n0x; nt = ntx; zsplit = zx;
+  if (GRP) { pdst = pdstx; pld = pldx; }
   PP_PROLOGUE();
   int younger = GKT;                                   // VMEM operations issued after the first two units of the current item
   for (;;) {
@@ -350,8 +387,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     // only the transposition buffers behind the ring.
     PP_STAMP(1);
     const int em0 = m0 + wr * RW, en0 = n0 + wc * 64, ez = zsplit;
+    float* const edst = pdst; const int eld = pld;
     item = nxt;
-    if (more) { m0 = m0x; n0 = n0x; nt = ntx; zsplit = zx; }
+    if (more) { m0 = m0x; n0 = n0x; nt = ntx; zsplit = zx; if (GRP) { pdst = pdstx; pld = pldx; } }
     // (queue) the ticket fetched at the start of this item -> index of the item after the next one; the use makes hipcc wait
     // for it here, after the epilogue arithmetic and before the stores; wave 0 writes it once its transposition buffer is free
     int ticket_item = 0;
@@ -368,13 +406,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     if (!store) {
       ticket_ready(); ticket_publish();
       younger = GKT;
-    } else if (TACC && (EPI == EPI_ACC || p.partial)) { // split-K item of a two-stage reduction (fp32 partial, plain stores),
+    } else if (TACC && (EPI == EPI_ACC || GRP || p.partial)) { // split-K item of a two-stage reduction (fp32 partial, plain stores),
       {                                                 // or C += tile for an unsplit fp32 weight gradient (EPI_ACC)
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const TpAddr tpa = tp_addr(lds0 + 131072u + (unsigned)w * 4096u, ln);
         ticket_ready();
         if (EPI == EPI_ACC) pp_partial_store<HI, true>(reinterpret_cast<float*>(p.C), p.ldc, acc, em0, en0, ln, tpa);
+        else if (GRP) pp_partial_store<HI>(edst, eld, acc, em0, en0, ln, tpa);
         else pp_partial_store<HI>(p.partial + (size_t)ez * p.M * p.N, p.N, acc, em0, en0, ln, tpa);
       }
       ticket_publish();
@@ -451,7 +490,7 @@ static void pp_launch0(const GemmArgs& p, hipStream_t st) {
   auto kern = gemm_bf16_pp_kernel<TA, TB, TACC, EPI, HI>;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
-  const int nitems = (p.N / 256) * (p.M / (128 + 64 * HI)) * p.split_k;
+  const int nitems = EPI == EPI_GROUP ? p.grp_items : (p.N / 256) * (p.M / (128 + 64 * HI)) * p.split_k;
   int cus = pp_num_cus() - p.spare_cus;
   if (cus < 8) cus = 8;
   const int grid = nitems < cus ? nitems : cus;
@@ -471,6 +510,9 @@ bool uc2_gemm_pp_supported(int trans_a, int trans_b, int c_f32, int epi, int til
   if (!trans_a && trans_b) return epi == EPI_NONE || epi == EPI_DGELU || epi == EPI_ADD;
   return epi == EPI_NONE;
 }
+
+// one launch over the split-K items of p.ngroup weight gradients (p.grp, uc2_gemm_wgrad_group in gemm.hip)
+void uc2_gemm_pp_group_launch(const GemmArgs& p, hipStream_t st) { pp_launch0<true, true, true, EPI_GROUP>(p, st); }
 
 void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st, int tile_rows) {
   if (tile_rows == 192) {

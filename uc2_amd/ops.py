@@ -3,7 +3,9 @@
 Every function here enqueues HIP kernels from libuc2_hip.so on torch's current stream.
 torch is used only for device memory (torch.empty), streams and autograd graph edges.
 """
+import ctypes
 import math
+import os
 
 import torch
 
@@ -621,6 +623,71 @@ def linear_wgrad(dy2, x2, dw, db):
             join_side_streams()
 
 
+# Below WGRAD_SIDE_MIN_ROWS tokens a layer's four weight gradients are too small to fill the chip one by one (9-36 output tiles
+# each at ~10 k tokens = a single round on half of the 256 CUs): BertLayerFn.backward hands them to ONE launch of the persistent
+# ping-pong kernel (uc2_gemm_wgrad_group) at the end of the layer's backward.  104-pair micro-batch: 215 -> 136 us per layer.
+WGRAD_GROUP = os.environ.get("UC2_WGRAD_GROUP", "1") != "0"
+
+
+class _WgradItem(ctypes.Structure):             # include/uc2_hip.h: Uc2WgradItem
+    _fields_ = [("dy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("lddy", ctypes.c_int),
+                ("ldx", ctypes.c_int), ("lddw", ctypes.c_int), ("n_out", ctypes.c_int), ("n_in", ctypes.c_int),
+                ("split_k", ctypes.c_int)]
+
+
+_CUS = {}
+
+
+def _num_cus(device):
+    key = (device.type, device.index)
+    if key not in _CUS:
+        _CUS[key] = torch.cuda.get_device_properties(device).multi_processor_count
+    return _CUS[key]
+
+
+def _group_split(tiles, ktiles, cus):
+    """common split-K factor of a grouped weight-gradient launch: fewest rounds of equal items, counting ~8 k-tile times per
+    round for the partial-tile epilogue, the next item's first fetch and the reduction's share (measured at 108 tiles x 156
+    k-tiles: split 2 = 136 us, 3 = 170, 4 = 166, 6 = 183; one k-tile = 1.65 us)"""
+    best, best_t = 1, None
+    for s in range(1, 17):
+        per = ((ktiles + s - 1) // s + 1) & ~1
+        if per < 2 or (s - 1) * per >= ktiles or ((ktiles - (s - 1) * per) & 1):
+            continue
+        rounds = (tiles * s + cus - 1) // cus
+        t = rounds * (per + 8) + 0.5 * s
+        if best_t is None or t < best_t:
+            best, best_t = s, t
+    return best
+
+
+def wgrad_group(triples):
+    """dW_i += dY_i^T X_i for every (dY_i, X_i, dW_i) of `triples` (at most four, same token count), one launch + one reduction;
+    falls back to one GEMM per item where the grouped kernel does not apply"""
+    dy0 = triples[0][0]
+    rows = dy0.shape[0]
+    ok = (WGRAD_GROUP and dy0.dtype == torch.bfloat16 and 1 <= len(triples) <= 4 and rows % 128 == 0
+          and all(dy.shape[0] == rows and x.shape[0] == rows and dy.shape[1] % 256 == 0 and x.shape[1] % 256 == 0
+                  and dy.is_contiguous() and x.is_contiguous() and dw.dtype == torch.float32 for dy, x, dw in triples))
+    if ok:
+        tiles = sum((dy.shape[1] // 256) * (x.shape[1] // 256) for dy, x, _ in triples)
+        split = _group_split(tiles, rows // 64, _num_cus(dy0.device))
+        arr = (_WgradItem * len(triples))()
+        for i, (dy, x, dw) in enumerate(triples):
+            arr[i] = _WgradItem(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), dy.stride(0), x.stride(0), dw.stride(0),
+                                dy.shape[1], x.shape[1], split)
+        lib = _lib.load()
+        need = lib.uc2_gemm_wgrad_group_workspace(len(triples), arr)
+        ws = _splitk_workspace(dy0.device, need)             # (None: it would have to grow inside a stream capture)
+        rc = -2 if ws is None else lib.uc2_gemm_wgrad_group(dt(dy0.dtype), len(triples), arr, rows, ptr(ws), ws.numel(), stream())
+        if rc == 0:
+            return
+        if rc != -2:
+            _lib.check(rc)
+    for dy, x, dw in triples:
+        _linear_wgrad_now(dy, x, dw, None)
+
+
 def colsum_accum(x2, out, rowmask=None):
     """out[n] += sum over (masked) rows of x2[:, n]; out is fp32"""
     M, N = x2.shape
@@ -800,13 +867,16 @@ class BertLayerFn(torch.autograd.Function):
                            dbias=G(P["fb"]))
         fp8 = ctx.fp8
         I_ = P["iw"].shape[0]
-        linear_wgrad(d_o2, u, G(P["fw"]), None)
+        # small token counts: the four weight gradients go out as ONE grouped launch at the end (wgrad_group)
+        grouped = [] if (WGRAD_GROUP and dtype == torch.bfloat16 and M < WGRAD_SIDE_MIN_ROWS and M % 128 == 0) else None
+        wgrad = (lambda dyv, xv, dwv: grouped.append((dyv, xv, dwv))) if grouped is not None else (lambda dyv, xv, dwv: linear_wgrad(dyv, xv, dwv, None))
+        wgrad(d_o2, u, G(P["fw"]))
         if fp8:
             d_pre = linear_dgrad_fp8(d_o2, st, P["fw"], P["fw"], (H, I_), EPI_DGELU, pre, colsum_out=G(P["ib"]), flags=GEMM_AUX_DERIV)
         else:
             d_pre = linear_dgrad(d_o2, st.compute(P["fw"], dtype), EPI_DGELU, pre, colsum_out=G(P["ib"]),
                                  flags=GEMM_AUX_DERIV)                                         # + d(intermediate bias)
-        linear_wgrad(d_pre, a, G(P["iw"]), None)
+        wgrad(d_pre, a, G(P["iw"]))
         if fp8:
             da = linear_dgrad_fp8(d_pre, st, P["iw"], P["iw"], (I_, H), EPI_ADD, dz2)
         else:
@@ -814,7 +884,7 @@ class BertLayerFn(torch.autograd.Function):
         # LN1, output projection, attention, fused QKV
         d_o1, dz1 = ln_bwd(da, o1, x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, s_ln1,
                            dbias=G(P["ob"]))
-        linear_wgrad(d_o1, ctxv, G(P["ow"]), None)
+        wgrad(d_o1, ctxv, G(P["ow"]))
         dctx = linear_dgrad_fp8(d_o1, st, P["ow"], P["ow"], (H, H)) if fp8 else linear_dgrad(d_o1, st.compute(P["ow"], dtype))
         dwqkv = st.grad_span(P["qw"], P["vw"], (3 * H, H))
         dbqkv = st.grad_span(P["qb"], P["vb"], (3 * H,))
@@ -822,13 +892,15 @@ class BertLayerFn(torch.autograd.Function):
         # flushed with one global atomic per column and workgroup (the separate column-sum pass re-read dqkv: 97 us)
         # (the fp32-math kernels run the column-sum pass inside uc2_attn_bwd)
         dqkv = attn_bwd(qkv, mask2d, ctxv, dctx, lse, B, L, nh, D, p_a, seed, s_attn, dbias=dbqkv)
-        linear_wgrad(dqkv, x2, dwqkv, None)
+        wgrad(dqkv, x2, dwqkv)
         dx = None
         if ctx.needs_input_grad[0]:
             if fp8:
                 dx = linear_dgrad_fp8(dqkv, st, P["qw"], P["vw"], (3 * H, H), EPI_ADD, dz1).view(B, L, H)
             else:
                 dx = linear_dgrad(dqkv, st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype), EPI_ADD, dz1).view(B, L, H)
+        if grouped:
+            wgrad_group(grouped)
         hook = ctx.cfg.get("grad_ready_hook")
         if hook is not None:
             join_side_streams()                  # this layer's weight gradients must be complete before its all-reduce
