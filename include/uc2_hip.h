@@ -174,6 +174,13 @@ int uc2_gather_rows_fwd(int dtype, int B, int S, int L, int H, const void* src, 
                         void* stream);
 int uc2_gather_rows_bwd(int dtype, int B, int S, int L, int H, const void* dout, const int64_t* index, void* dsrc,
                         void* stream);
+/* the same over the concatenation [src1 [B,S1,H] | src2 [B,S2,H]] along dim 1 (torch.cat([txt_emb, img_emb], 1) followed by
+ * the gather, model/model.py:412-425) without building it: forward reads both sources in place, backward writes dsrc1 and
+ * dsrc2 as separate contiguous tensors */
+int uc2_gather_rows2_fwd(int dtype, int B, int S1, int S2, int L, int H, const void* src1, const void* src2,
+                         const int64_t* index, void* out, void* stream);
+int uc2_gather_rows2_bwd(int dtype, int B, int S1, int S2, int L, int H, const void* dout, const int64_t* index,
+                         void* dsrc1, void* dsrc2, void* stream);
 
 /* ---- batch assembly on the device (collates data/itm.py:205-232, data/mrm.py:73-119, data/mlm.py:761-801; helpers
  *      data/data.py:360-384 pad_tensors / get_gather_index, data/mrm.py:36-39 _mask_img_feat; loader data/loader.py:85-140):

@@ -327,6 +327,19 @@ def test_gather_select_embed():
     out = ops.GatherRowsFn.apply(y, idx)
     out.backward(g)
     assert torch.equal(out, ref.detach()) and rel_err(y.grad, x.grad) < 1e-6
+    # the same gather over cat([a, b], 1) without the concatenated tensor (model/model.py:412-425): repeated and unused indices
+    for dtype in (torch.float32, torch.bfloat16):
+        S1, S2 = 9, 5
+        a0, b0 = rnd((B, S1, H), 6, dtype=dtype), rnd((B, S2, H), 7, dtype=dtype)
+        a1, b1 = a0.float().clone().requires_grad_(True), b0.float().clone().requires_grad_(True)
+        ref = torch.gather(torch.cat([a1, b1], 1), 1, idx.unsqueeze(-1).expand(-1, -1, H))
+        ref.backward(g)
+        a2, b2 = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        out = ops.GatherCatRowsFn.apply(a2, b2, idx)
+        out.backward(g.to(dtype))
+        assert torch.equal(out.float(), ref.detach())
+        assert rel_err(a2.grad.float(), a1.grad) < tol(dtype, 1e-6, 4e-3) and rel_err(b2.grad.float(), b1.grad) < tol(dtype, 1e-6, 4e-3)
+        assert a2.grad.is_contiguous() and b2.grad.is_contiguous()
     hid = rnd((40, H), 4)
     rows = torch.tensor([0, 3, 7, 39], device=DEV)
     y = hid.clone().requires_grad_(True)

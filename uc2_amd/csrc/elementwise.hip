@@ -116,12 +116,17 @@ extern "C" int uc2_embed_bwd(int dtype, int rows, int H, const int64_t* ids, con
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void gather_fwd_kernel(int B, int S, int L, int H, const T* __restrict__ src,
-                                                         const int64_t* __restrict__ index, T* __restrict__ out) {
+                                                         const int64_t* __restrict__ index, T* __restrict__ out,
+                                                         const T* __restrict__ src2 = nullptr, int S1 = 0) {
+  // (src2 != NULL: the source is the concatenation [src (S1 rows) | src2 (S - S1 rows)] along dim 1 -- text and image
+  //  embeddings, model/model.py:412-425 -- read in place, the concatenated tensor never exists)
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= B * L) return;
   const int b = r / L;
-  const T* s = src + ((size_t)b * S + index[r]) * H;
+  const int64_t si = index[r];
+  const T* s = (src2 && si >= S1) ? src2 + ((size_t)b * (S - S1) + (si - S1)) * H
+                                  : src + ((size_t)b * (src2 ? S1 : S) + si) * H;
   for (int c = lane * 4; c < H; c += 256) {
     float v[4];
     Vec4<T>::load(s + c, v);
@@ -130,7 +135,8 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(int B, int S, int L, in
 }
 template <typename T>
 __global__ __launch_bounds__(256) void gather_bwd_kernel(int B, int S, int L, int H, const T* __restrict__ dout,
-                                                         const int64_t* __restrict__ index, T* __restrict__ dsrc) {
+                                                         const int64_t* __restrict__ index, T* __restrict__ dsrc,
+                                                         T* __restrict__ dsrc2 = nullptr, int S1 = 0) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);          // r = b*S + s
   if (r >= B * S) return;
@@ -164,7 +170,11 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(int B, int S, int L, in
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = cbase + i * 256 + lane * 4;
-      if (c < H) Vec4<T>::store(dsrc + (size_t)r * H + c, acc[i]);
+      if (c < H) {
+        T* d = (dsrc2 && s >= S1) ? dsrc2 + ((size_t)b * (S - S1) + (s - S1)) * H
+                                  : dsrc + ((size_t)b * (dsrc2 ? S1 : S) + s) * H;
+        Vec4<T>::store(d + c, acc[i]);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
     }
@@ -191,6 +201,33 @@ extern "C" int uc2_gather_rows_bwd(int dtype, int B, int S, int L, int H, const 
   dim3 grid((B * S + 3) / 4);
   if (dtype == 0) hipLaunchKernelGGL(gather_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, B, S, L, H, (const float*)dout, index, (float*)dsrc);
   else hipLaunchKernelGGL(gather_bwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, B, S, L, H, (const bf16*)dout, index, (bf16*)dsrc);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+// the same over the concatenation [src1 [B,S1,H] | src2 [B,S2,H]] along dim 1 without building it: forward reads
+// the two sources in place, backward writes the two gradients as separate contiguous tensors
+extern "C" int uc2_gather_rows2_fwd(int dtype, int B, int S1, int S2, int L, int H, const void* src1, const void* src2,
+                                    const int64_t* index, void* out, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  UC2_CHECK_ARG((H % 4) == 0 && S1 >= 0 && S2 >= 0);
+  if (B * L <= 0) return 0;
+  UC2_CHECK_ARG(src1 && src2 && index && out);
+  dim3 grid((B * L + 3) / 4);
+  if (dtype == 0) hipLaunchKernelGGL(gather_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, B, S1 + S2, L, H, (const float*)src1, index, (float*)out, (const float*)src2, S1);
+  else hipLaunchKernelGGL(gather_fwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, B, S1 + S2, L, H, (const bf16*)src1, index, (bf16*)out, (const bf16*)src2, S1);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int uc2_gather_rows2_bwd(int dtype, int B, int S1, int S2, int L, int H, const void* dout, const int64_t* index,
+                                    void* dsrc1, void* dsrc2, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  UC2_CHECK_ARG((H % 4) == 0 && S1 >= 0 && S2 >= 0);
+  if (B * (S1 + S2) <= 0) return 0;
+  UC2_CHECK_ARG(dout && index && dsrc1 && dsrc2);
+  dim3 grid((B * (S1 + S2) + 3) / 4);
+  if (dtype == 0) hipLaunchKernelGGL(gather_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, B, S1 + S2, L, H, (const float*)dout, index, (float*)dsrc1, (float*)dsrc2, S1);
+  else hipLaunchKernelGGL(gather_bwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, B, S1 + S2, L, H, (const bf16*)dout, index, (bf16*)dsrc1, (bf16*)dsrc2, S1);
   UC2_LAUNCH_CHECK();
   return 0;
 }

@@ -292,6 +292,8 @@ class VLXLMRModel(VLXLMRPreTrainedModel):
                                     img_masks=None, txt_type_ids=None, img_type_ids=None):
         txt_emb = self._compute_txt_embeddings(input_ids, position_ids, txt_type_ids)
         img_emb = self._compute_img_embeddings(img_feat, img_pos_feat, img_masks, img_type_ids)
+        if txt_emb.dtype == img_emb.dtype and txt_emb.shape[0] == img_emb.shape[0]:
+            return ops.GatherCatRowsFn.apply(txt_emb, img_emb, gather_index)       # the concatenation is never built
         return ops.GatherRowsFn.apply(torch.cat([txt_emb, img_emb], dim=1), gather_index)
 
     def forward(self, input_ids, position_ids, img_feat, img_pos_feat, attention_mask, gather_index=None,

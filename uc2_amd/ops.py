@@ -1198,6 +1198,35 @@ class GatherRowsFn(torch.autograd.Function):
         return dsrc, None
 
 
+class GatherCatRowsFn(torch.autograd.Function):
+    """torch.gather(torch.cat([a, b], 1), 1, index[..., None].expand(H)) (model/model.py:412-425) without the concatenated tensor:
+    the gather reads the text and image embeddings in place; the backward writes their two gradients as separate tensors"""
+
+    @staticmethod
+    def forward(ctx, a, b, index):
+        B, S1, H = a.shape
+        S2 = b.shape[1]
+        L = index.shape[1]
+        a, b = a.contiguous(), b.contiguous()
+        idx = index.contiguous()
+        out = torch.empty((B, L, H), dtype=a.dtype, device=a.device)
+        call("uc2_gather_rows2_fwd", dt(a.dtype), B, S1, S2, L, H, ptr(a), ptr(b), ptr(idx), ptr(out), stream())
+        ctx.save_for_backward(idx)
+        ctx.S = (S1, S2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        B, L, H = dout.shape
+        S1, S2 = ctx.S
+        dout = dout.contiguous()
+        da = torch.empty((B, S1, H), dtype=dout.dtype, device=dout.device)
+        db = torch.empty((B, S2, H), dtype=dout.dtype, device=dout.device)
+        call("uc2_gather_rows2_bwd", dt(dout.dtype), B, S1, S2, L, H, ptr(dout), ptr(idx), ptr(da), ptr(db), stream())
+        return da, db, None
+
+
 class SelectRowsFn(torch.autograd.Function):
     """hidden[mask] for a boolean mask over rows (model/model.py:653-657); rows = flat row indices"""
 
