@@ -128,7 +128,15 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """raw hipStream_t of torch's current stream on the current device (every kernel launch asks: the two C accessors cost
+    ~0.5 us, torch.cuda.current_stream().cuda_stream ~10 us of Python)"""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 

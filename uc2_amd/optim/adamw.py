@@ -99,10 +99,22 @@ class AdamW(Optimizer):
 
     def _chunk_table(self, plan, want_p16):
         """device table of (p, g, m, v, p16, n, group, param) records; g = the gradient (arena view)"""
-        key_parts, rows = [], []
+        # the table depends only on where the arenas live (and on the gradient tensors of parameters outside a store): compare
+        # those first -- rebuilding the ~2 600 rows just to hash them cost 3-5 ms of host time per step
+        key_parts = [bool(want_p16)]
+        for st in plan["stores"]:
+            st._ensure_grad()
+            key_parts.append((id(st), st.data.data_ptr(), st.grad.data_ptr(),
+                              st.shadow.data_ptr() if st.shadow is not None else 0))
+        for (p, gi, pi, m, v, st) in plan["recs"]:
+            if st is None:
+                key_parts.append((p.data_ptr(), p.grad.data_ptr() if p.grad is not None else 0))
+        key = tuple(key_parts)
+        if plan["table_key"] == key:
+            return plan["table"], plan["n_chunks"]
+        rows = []
         for (p, gi, pi, m, v, st) in plan["recs"]:
             if st is not None:
-                st._ensure_grad()
                 g = st.view(st.grad, p)
                 p16 = st.view(st.shadow, p) if (want_p16 and st.shadow is not None) else None
             else:
@@ -110,14 +122,10 @@ class AdamW(Optimizer):
                 p16 = None
             gp = g.data_ptr() if g is not None else 0
             pp = 0 if p16 is None else p16.data_ptr()
-            key_parts.append((p.data_ptr(), gp, pp))
             n = p.numel()
             for off in range(0, n, _CHUNK):
                 rows.append((p.data_ptr() + 4 * off, gp + 4 * off if gp else 0, m.data_ptr() + 4 * off,
                              v.data_ptr() + 4 * off, pp + 2 * off if pp else 0, min(_CHUNK, n - off), gi, pi))
-        key = hash(tuple(key_parts))
-        if plan["table_key"] == key:
-            return plan["table"], plan["n_chunks"]
         rec = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("p16", "<u8"),
                         ("n", "<u4"), ("group", "<u2"), ("param", "<u2")])
         assert rec.itemsize == _lib.load().uc2_adamw_chunk_bytes()
