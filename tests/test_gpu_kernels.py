@@ -426,6 +426,69 @@ def test_gemm_pingpong_epilogues(epi, M, N, K):
         assert rel_err(pre.float(), ref_pre.float()) < 3e-3
 
 
+@pytest.mark.parametrize("kind", ["none", "gelu", "gelu_d", "gelu_noaux", "add", "tanh", "dgelu", "mul", "add_nt"])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1024, 768, 512), (4096, 2304, 768)])
+def test_gemm_pingpong_16x16x32_epilogues(kind, M, N, K):
+    """variant 12 (gemm_pp16.hip: the ping-pong schedule on v_mfma_f32_16x16x32_bf16) against variant 8 and an fp32 product, every
+    fused epilogue kind with its second output stream / aux tile / column sums; NaN-filled outputs, two launches (race screen).
+    The two MFMA shapes accumulate a k-tile in a different order (2 x 32 against 4 x 16), so outputs may differ by a bf16 ulp."""
+    nt = kind in ("dgelu", "mul", "add_nt")
+    a = rnd((M, K), 1, dtype=torch.bfloat16)
+    b = rnd((K, N) if nt else (N, K), 2, 0.05, dtype=torch.bfloat16)
+    bias = None if nt else rnd((N,), 3)
+    aux = rnd((M, N), 4, dtype=torch.bfloat16)
+    code = {"none": ops.EPI_NONE, "gelu": ops.EPI_GELU, "gelu_d": ops.EPI_GELU, "gelu_noaux": ops.EPI_GELU, "add": ops.EPI_ADD,
+            "tanh": ops.EPI_TANH, "dgelu": ops.EPI_DGELU, "mul": ops.EPI_DGELU, "add_nt": ops.EPI_ADD}[kind]
+    flags = ops.GEMM_AUX_DERIV if kind in ("gelu_d", "mul") else 0
+
+    def run(variant):
+        second = None
+        if kind in ("gelu", "gelu_d"):
+            second = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        elif kind in ("dgelu", "mul"):
+            second = torch.zeros(N, dtype=torch.float32, device=DEV)           # column sums of the result
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.gemm(a, b, M, N, K, tb=nt, bias=bias, epi=code, aux_in=aux if kind in ("add", "dgelu", "mul", "add_nt") else None,
+                 aux_out=second, out=out, variant=variant, flags=flags)
+        return out, second
+    ref, ref2 = run(8)
+    for _ in range(2):
+        out, second = run(12)
+        assert torch.isfinite(out.float()).all()
+        assert rel_err(out.float(), ref.float()) < 2e-3
+        if second is not None:
+            assert rel_err(second.float(), ref2.float()) < 2e-3
+    if kind == "none":
+        want = a.float() @ (b.float() if nt else b.float().t()) + (0 if bias is None else bias)
+        assert rel_err(out.float(), want) < 4e-3
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_pingpong_16x16x32_layouts_and_fp32_outputs(ta, tb):
+    """variant 12 with every operand layout (k-contiguous and k-strided LDS images, the latter with its second swizzle bit), split-K
+    partial tiles + reduction, the in-place accumulation of an unsplit weight gradient; shapes it does not take run as variant 8"""
+    M, N, K = 768, 512, 1024
+    a = rnd((K, M) if ta else (M, K), 1, dtype=torch.bfloat16)
+    b = rnd((K, N) if tb else (N, K), 2, dtype=torch.bfloat16)
+    bias = rnd((N,), 3)
+    r8 = ops.gemm(a, b, M, N, K, ta=ta, tb=tb, bias=bias, variant=8)
+    r12 = ops.gemm(a, b, M, N, K, ta=ta, tb=tb, bias=bias, variant=12)
+    assert rel_err(r12.float(), r8.float()) < 2e-3
+    want = (a.float().t() if ta else a.float()) @ (b.float() if tb else b.float().t()) + bias
+    assert rel_err(r12.float(), want) < 4e-3
+    c0 = rnd((M, N), 4)
+    for sk in (1, 2, 4):
+        o8 = ops.gemm(a, b, M, N, K, ta=ta, tb=tb, out=c0.clone(), accumulate=True, split_k=sk, variant=8)
+        o12 = ops.gemm(a, b, M, N, K, ta=ta, tb=tb, out=c0.clone(), accumulate=True, split_k=sk, variant=12)
+        o12b = ops.gemm(a, b, M, N, K, ta=ta, tb=tb, out=c0.clone(), accumulate=True, split_k=sk, variant=12)
+        assert rel_err(o12, o8) < 1e-5 and torch.equal(o12, o12b)
+    # 192 rows: not a multiple of the 256-row tile -> the library's fallback, still correct
+    a2 = rnd((K, 192) if ta else (192, K), 5, dtype=torch.bfloat16)
+    f12 = ops.gemm(a2, b, 192, N, K, ta=ta, tb=tb, bias=bias, variant=12)
+    f99 = ops.gemm(a2, b, 192, N, K, ta=ta, tb=tb, bias=bias, variant=GENERIC)
+    assert rel_err(f12.float(), f99.float()) < 3e-3
+
+
 def test_gemm_pingpong_persistent():
     """more work items than CUs: every workgroup walks several tiles (next tile's staging overlaps the stores)"""
     M, N, K = 16384, 2304, 768            # 576 tiles
