@@ -7,6 +7,20 @@
 #pragma once
 #include "gemm_pp.h"
 
+// chunk-slot swizzle of the k-strided LDS image as a function of the k row (experiment knob: 1 = variant 8's swizzle, 2 = bit 4)
+#ifndef UC2_PP16_SWZ
+#define UC2_PP16_SWZ 0
+#endif
+#if UC2_PP16_SWZ == 1
+#define PP16_SWZ(krow) (((krow) & 3) << 2)
+#elif UC2_PP16_SWZ == 2
+#define PP16_SWZ(krow) ((((krow) & 3) << 2) | ((((krow) >> 4) & 1) << 1))
+#elif UC2_PP16_SWZ == 3
+#define PP16_SWZ(krow) ((((krow) & 3) << 2) | ((((krow) >> 3) & 1) << 1) | (((krow) >> 4) & 1))
+#else
+#define PP16_SWZ(krow) ((((krow) & 3) << 2) | ((((krow) >> 3) & 1) << 1))
+#endif
+
 // per-lane staging source: as pp_src, but the k-strided image gets a second swizzle bit (bit 3 of the k row): the
 // transposing read of a 16x16x32 operand takes two 4 x 16 blocks 8 k-rows apart in the same columns per 32 lanes, which land
 // on the same banks with the (krow & 3) swizzle alone
@@ -16,7 +30,7 @@ __device__ __forceinline__ const bf16* pp16_src(const bf16* __restrict__ X, int 
     return pp_src<false, J, HI>(X, ld, rows, r0, kbeg, wi, l);
   } else {
     const int krow = wi * 4 + (l >> 4), cp = l & 15;
-    const int c = cp ^ (((krow & 3) << 2) | (((krow >> 3) & 1) << 1));
+    const int c = cp ^ PP16_SWZ(krow);
     const int col = min(r0 + pp_map<J, HI>(c * 8), rows - 8);
     return X + (size_t)(kbeg + krow) * ld + col;
   }
@@ -34,7 +48,7 @@ template <bool TR> __device__ __forceinline__ unsigned pp16_frag_off(int rbase, 
     const int q = i >> 2, pp = i & 3;
     const int krow = 8 * g + q;
     const int chunk = (rbase >> 3) + (pp >> 1);
-    return krow * 256 + ((chunk ^ ((q << 2) | ((g & 1) << 1))) << 4) + (pp & 1) * 8;
+    return krow * 256 + ((chunk ^ PP16_SWZ(krow)) << 4) + (pp & 1) * 8;
   }
 }
 template <bool TR, int BLK, int KS> __device__ __forceinline__ void pp16_read(bf16x8& dst, unsigned addr) {
