@@ -39,6 +39,7 @@ __device__ __forceinline__ const bf16* pp16_src(const bf16* __restrict__ X, int 
 // byte offset (inside a unit) of the lane's part of fragment (block 0, k-step 0) for rows / columns rbase .. of the unit;
 //   k-contiguous image: fragment (blk, ks) at (off ^ (ks << 6)) + blk * 2048
 //   k-strided image   : fragment (blk, ks) at (off ^ (blk << 5)) + ks * 8192, second half of the k octet + 1024
+//                       (pp16_read takes the block's base off ^ (blk << 5); the kernel keeps the four in registers)
 template <bool TR> __device__ __forceinline__ unsigned pp16_frag_off(int rbase, int lane) {
   const int g = lane >> 4, i = lane & 15;
   if (!TR) {
@@ -56,7 +57,7 @@ template <bool TR, int BLK, int KS> __device__ __forceinline__ void pp16_read(bf
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr ^ (unsigned)(KS << 6)), "n"(BLK * 2048));
   } else {
     short4v lo, hi;
-    const unsigned a2 = addr ^ (unsigned)(BLK << 5);
+    const unsigned a2 = addr;                          // (the caller passes the block's own base: base ^ (BLK << 5), precomputed)
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a2), "n"(KS * 8192));
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a2), "n"(KS * 8192 + 1024));
     bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);

@@ -79,10 +79,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
   float* pdst = nullptr; float* pdstx = nullptr;                       // grouped launch: partial tile of the item computed / staged
   int pld = 0, pldx = 0;
   const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((lds_void_p)smem);
-  unsigned fa[2], fa1[2], fb;                                    // fragment addresses (buffer 0; the other is + 65536)
+  unsigned fa[4], fb[2];                                         // fragment addresses per block (buffer 0; the other is + 65536)
   fa[0] = lds0 + pp16_frag_off<TA>(wr * 64, lane);               // units A0 / A1: 64 rows per wave row, four 16-row blocks
-  fa[1] = fa[0]; fa1[0] = fa[0]; fa1[1] = fa[0];
-  fb = lds0 + pp16_frag_off<TB>(wc * 32, lane);                  // units B0 / B1: 32 columns per wave column, two blocks
+  fb[0] = lds0 + pp16_frag_off<TB>(wc * 32, lane);               // units B0 / B1: 32 columns per wave column, two blocks
+#pragma unroll
+  for (int i = 1; i < 4; ++i) fa[i] = TA ? (fa[0] ^ (unsigned)(i << 5)) : fa[0];     // (k-contiguous image: the block is an immediate offset)
+  fb[1] = TB ? (fb[0] ^ 32u) : fb[0];
 
   int m0, n0, nt, zsplit;       // the item being computed
   int m0x, n0x, ntx, zx;        // the item being staged: the same one, until the tail of its main loop starts fetching the next
@@ -177,15 +179,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
 #define PP_READ_A(BASEOFF)                                                                                     \
   do {                                                                                                         \
     pp16_read<TA, 0, 0>(a[0][0], fa[0] + (BASEOFF)); pp16_read<TA, 0, 1>(a[0][1], fa[0] + (BASEOFF));          \
-    pp16_read<TA, 1, 0>(a[1][0], fa[0] + (BASEOFF)); pp16_read<TA, 1, 1>(a[1][1], fa[0] + (BASEOFF));          \
-    pp16_read<TA, 2, 0>(a[2][0], fa[0] + (BASEOFF)); pp16_read<TA, 2, 1>(a[2][1], fa[0] + (BASEOFF));          \
-    pp16_read<TA, 3, 0>(a[3][0], fa[0] + (BASEOFF)); pp16_read<TA, 3, 1>(a[3][1], fa[0] + (BASEOFF));          \
+    pp16_read<TA, 1, 0>(a[1][0], fa[1] + (BASEOFF)); pp16_read<TA, 1, 1>(a[1][1], fa[1] + (BASEOFF));          \
+    pp16_read<TA, 2, 0>(a[2][0], fa[2] + (BASEOFF)); pp16_read<TA, 2, 1>(a[2][1], fa[2] + (BASEOFF));          \
+    pp16_read<TA, 3, 0>(a[3][0], fa[3] + (BASEOFF)); pp16_read<TA, 3, 1>(a[3][1], fa[3] + (BASEOFF));          \
   } while (0)
 #define PP_READ_A1(BASEOFF) PP_READ_A(BASEOFF)
 #define PP_READ_B(BREG, BASEOFF)                                                                               \
   do {                                                                                                         \
-    pp16_read<TB, 0, 0>(BREG[0], fb + (BASEOFF)); pp16_read<TB, 0, 1>(BREG[1], fb + (BASEOFF));                \
-    pp16_read<TB, 1, 0>(BREG[2], fb + (BASEOFF)); pp16_read<TB, 1, 1>(BREG[3], fb + (BASEOFF));                \
+    pp16_read<TB, 0, 0>(BREG[0], fb[0] + (BASEOFF)); pp16_read<TB, 0, 1>(BREG[1], fb[0] + (BASEOFF));          \
+    pp16_read<TB, 1, 0>(BREG[2], fb[1] + (BASEOFF)); pp16_read<TB, 1, 1>(BREG[3], fb[1] + (BASEOFF));          \
   } while (0)
   // end of an L section: retire the units the next phase reads, publish, then wait for this phase's own reads
   // ALLOW = units (the oldest of the window f+3 .. f+6) that may stay in flight; P = phase: with HI = 1 the A1 unit
