@@ -230,6 +230,12 @@ int uc2_dtanh(int dtype, size_t n, const void* y, const void* dy, void* dx, void
 int uc2_gelu(int dtype, size_t n, const void* x, void* y, void* stream);       /* model/layer.py:31-37, stand-alone */
 int uc2_dgelu(int dtype, size_t n, const void* pre, const void* dy, void* dx, void* stream);
 int uc2_cast(int from_dtype, int to_dtype, size_t n, const void* in, void* out, void* stream);
+/* Batched bf16 transposes in one launch: for every item, dst_base[offset ..] as [cols][rows] = transpose of src_base[offset ..]
+ * as [rows][cols] (offsets in elements, rows and cols multiples of 64).  Used to keep k-contiguous copies W^T of the layer
+ * weights (nn.Linear.weight [out, in], model/layer.py:76-156) beside their bf16 compute copies, refreshed once per optimizer
+ * step, so that the input-gradient GEMMs dX = dY W read both operands k-contiguously. */
+typedef struct { size_t offset; int rows, cols; } Uc2TransposeItem;
+int uc2_transpose_batch(int n, const Uc2TransposeItem* items, const void* src_base, void* dst_base, void* stream);
 
 /* ---- optimal-transport regulariser of the ITM head (model/ot.py:8-82; hooked at model/model.py:701-729) -----------
  *   seq [B, L, H] compact encoder output; scatter [B, L] = position of each row in the padded [txt(T) | img(R)] layout;

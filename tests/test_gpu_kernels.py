@@ -463,6 +463,50 @@ def test_gemm_pingpong_16x16x32_epilogues(kind, M, N, K):
         assert rel_err(out.float(), want) < 4e-3
 
 
+@pytest.mark.parametrize("kind", ["none", "add", "dgelu", "mul"])
+def test_gemm_input_gradient_with_transposed_weight_copy(kind):
+    """dX = epi(dY W) with W read from a k-contiguous copy W^T (both operands k-contiguous, variant 12) equals the form that reads
+    W [out, in] through the transposing LDS read (variant 8), for every epilogue of the layer backward, column sums included"""
+    M, N, K = 2048, 3072, 768
+    dy = rnd((M, N), 1, dtype=torch.bfloat16)
+    w = rnd((N, K), 2, 0.03, dtype=torch.bfloat16)
+    wt = w.t().contiguous()
+    aux = rnd((M, K), 3, dtype=torch.bfloat16)
+    code = {"none": ops.EPI_NONE, "add": ops.EPI_ADD, "dgelu": ops.EPI_DGELU, "mul": ops.EPI_DGELU}[kind]
+    flags = ops.GEMM_AUX_DERIV if kind == "mul" else 0
+    c_ref = torch.zeros(K, device=DEV) if code == ops.EPI_DGELU else None
+    c_got = torch.zeros(K, device=DEV) if code == ops.EPI_DGELU else None
+    a_in = None if kind == "none" else aux
+    ref = ops.gemm(dy, w, M, K, N, tb=True, epi=code, aux_in=a_in, aux_out=c_ref, variant=8, flags=flags)
+    got = ops.gemm(dy, wt, M, K, N, tb=False, epi=code, aux_in=a_in, aux_out=c_got, variant=12, flags=flags)
+    assert rel_err(got.float(), ref.float()) < 2e-3
+    if c_ref is not None:
+        assert rel_err(c_got, c_ref) < 2e-3
+    # through ops.linear_dgrad (takes the k-contiguous form only where the plan for it is variant 12)
+    out = ops.linear_dgrad(dy, w, code, a_in, colsum_out=(torch.zeros(K, device=DEV) if code == ops.EPI_DGELU else None), flags=flags, wt=wt)
+    assert rel_err(out.float(), ref.float()) < 3e-3
+
+
+def test_store_keeps_transposed_weight_copies_fresh():
+    """ParamStore.compute_t: bf16 W^T at the parameter's offset of a second arena, one batched transpose launch per weight version
+    (uc2_transpose_batch); follows optimizer-style updates (mark_dirty) and spans of adjacent parameters (q|k|v)"""
+    from uc2_amd.store import set_compute_dtype, store_of
+    net = torch.nn.Sequential(torch.nn.Linear(768, 3072), torch.nn.Linear(3072, 768), torch.nn.Linear(768, 768),
+                              torch.nn.Linear(768, 200)).to(DEV)
+    set_compute_dtype(net, torch.bfloat16)
+    st = store_of(net)
+    st.sync_shadow()
+    for m in list(net)[:3]:
+        assert torch.equal(st.compute_t(m.weight), st.compute(m.weight, torch.bfloat16).t().contiguous())
+    assert st.compute_t(net[3].weight) is None                      # 200 rows: not whole 64 x 64 tiles -> the caller keeps W
+    with torch.no_grad():
+        net[0].weight.mul_(2.0)
+        net[2].weight.add_(1.0)
+    st.mark_dirty()
+    for m in list(net)[:3]:
+        assert torch.equal(st.compute_t(m.weight), st.compute(m.weight, torch.bfloat16).t().contiguous())
+
+
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
 def test_gemm_pingpong_16x16x32_layouts_and_fp32_outputs(ta, tb):
     """variant 12 with every operand layout (k-contiguous and k-strided LDS images, the latter with its second swizzle bit), split-K

@@ -47,6 +47,7 @@ SIGNATURES = {
     "uc2_embed_bwd": (I, [I, I, I, P, P, P, P, P, P, P, I64, I64, P]),
     "uc2_gather_rows_fwd": (I, [I, I, I, I, I, P, P, P, P]),
     "uc2_gather_rows_bwd": (I, [I, I, I, I, I, P, P, P, P]),
+    "uc2_transpose_batch": (I, [I, P, P, P, P]),
     "uc2_gather_rows2_fwd": (I, [I, I, I, I, I, I, P, P, P, P, P]),
     "uc2_gather_rows2_bwd": (I, [I, I, I, I, I, I, P, P, P, P, P]),
     "uc2_collate_regions": (I, [I, I, I, I, P, P, P, P, P]),

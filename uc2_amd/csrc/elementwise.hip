@@ -871,3 +871,59 @@ extern "C" int uc2_cast(int from_dtype, int to_dtype, size_t n, const void* in, 
   UC2_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------
+// Batched bf16 transposes: dst[off_i .. ] viewed as [cols_i][rows_i] = transpose of src[off_i ..] viewed as [rows_i][cols_i], for
+// up to UC2_TR_MAX matrices in ONE launch.  Keeps k-contiguous copies W^T of the layer weights beside the bf16 shadow arena, so
+// that the input-gradient GEMMs dX = dY W read both operands k-contiguously (the ping-pong kernel on the 16x16x32 MFMA is 4-10 %
+// faster on that layout than with W read through the transposing LDS read); refreshed once per optimizer step: 170 MB each way.
+// ---------------------------------------------------------------------------------------
+#define UC2_TR_MAX 64
+struct TrBatch { int n; int tile0[UC2_TR_MAX + 1]; int rows[UC2_TR_MAX]; int cols[UC2_TR_MAX]; unsigned long long off[UC2_TR_MAX]; };
+__global__ __launch_bounds__(256) void transpose_batch_kernel(TrBatch b, const bf16* __restrict__ src, bf16* __restrict__ dst) {
+  __shared__ bf16 tile[64][64 + 4];
+  int i = 0;
+  for (int k = 1; k < UC2_TR_MAX; ++k) if (k < b.n && (int)blockIdx.x >= b.tile0[k]) i = k;     // (uniform)
+  const int t = blockIdx.x - b.tile0[i];
+  const int tc = b.cols[i] / 64, tr_ = t / tc, tcx = t - tr_ * tc;
+  const bf16* s = src + b.off[i] + (size_t)(tr_ * 64) * b.cols[i] + tcx * 64;
+  bf16* d = dst + b.off[i] + (size_t)(tcx * 64) * b.rows[i] + tr_ * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;          // 16 x 16 threads, 4 x 4 elements each
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = ty + 16 * r;
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(s + (size_t)row * b.cols[i] + tx * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[row][tx * 4 + e] = v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int col = ty + 16 * r;                                     // source column = destination row
+    bf16x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = tile[tx * 4 + e][col];
+    *reinterpret_cast<bf16x4*>(d + (size_t)col * b.rows[i] + tx * 4) = v;
+  }
+}
+struct Uc2TransposeItem { size_t offset; int rows, cols; };        // mirrors include/uc2_hip.h
+extern "C" int uc2_transpose_batch(int n, const Uc2TransposeItem* items, const void* src_base, void* dst_base, void* stream) {
+  UC2_CHECK_ARG(n >= 0 && (n == 0 || items));
+  if (n == 0) return 0;
+  UC2_CHECK_ARG(src_base && dst_base && src_base != dst_base);
+  for (int i0 = 0; i0 < n; i0 += UC2_TR_MAX) {
+    TrBatch b{};
+    b.n = n - i0 < UC2_TR_MAX ? n - i0 : UC2_TR_MAX;
+    int tiles = 0;
+    for (int k = 0; k < b.n; ++k) {
+      const Uc2TransposeItem& it = items[i0 + k];
+      UC2_CHECK_ARG(it.rows > 0 && it.cols > 0 && (it.rows % 64) == 0 && (it.cols % 64) == 0 && (it.offset % 4) == 0);
+      b.tile0[k] = tiles; b.rows[k] = it.rows; b.cols[k] = it.cols; b.off[k] = it.offset;
+      tiles += (it.rows / 64) * (it.cols / 64);
+    }
+    b.tile0[b.n] = tiles;
+    hipLaunchKernelGGL(transpose_batch_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, b, (const bf16*)src_base, (bf16*)dst_base);
+  }
+  UC2_LAUNCH_CHECK();
+  return 0;
+}

@@ -428,7 +428,8 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
       const unsigned long long ea = 2ull * (trans_a ? p.K : p.M) * p.lda, eb = 2ull * (trans_b ? p.K : p.N) * p.ldb;
       if (ea >= (1ull << 32) || eb >= (1ull << 32)) return 0;
     }
-    if (!uc2_gemm_pp_supported(trans_a, trans_b, p.c_f32, p.epi, rows)) return 0;
+    if (!uc2_gemm_pp_supported(trans_a, trans_b, p.c_f32, p.epi, rows) &&
+        !(want_pp16 && !p.c_f32 && uc2_gemm_pp16_supported(p, trans_a, trans_b))) return 0;
     if (!p.c_f32 && (p.accumulate || (p.ldc & 7) || (p.ldaux & 7) || ((uintptr_t)p.C & 15) ||
                      ((uintptr_t)p.aux_in & 15) || ((uintptr_t)p.aux_out & 15) || ((uintptr_t)p.bias & 15)))
       return 0;

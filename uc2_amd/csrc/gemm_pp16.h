@@ -39,7 +39,8 @@ __device__ __forceinline__ const bf16* pp16_src(const bf16* __restrict__ X, int 
 // byte offset (inside a unit) of the lane's part of fragment (block 0, k-step 0) for rows / columns rbase .. of the unit;
 //   k-contiguous image: fragment (blk, ks) at (off ^ (ks << 6)) + blk * 2048
 //   k-strided image   : fragment (blk, ks) at (off ^ (blk << 5)) + ks * 8192, second half of the k octet + 1024
-//                       (pp16_read takes the block's base off ^ (blk << 5); the kernel keeps the four in registers)
+//   (pp16_read takes the k-step's base off ^ (ks << 6) resp. the block's base off ^ (blk << 5); the kernel keeps them in
+//    registers: every VALU instruction in an L section competes with the partner wave's MFMA issue)
 template <bool TR> __device__ __forceinline__ unsigned pp16_frag_off(int rbase, int lane) {
   const int g = lane >> 4, i = lane & 15;
   if (!TR) {
@@ -52,14 +53,16 @@ template <bool TR> __device__ __forceinline__ unsigned pp16_frag_off(int rbase, 
     return krow * 256 + ((chunk ^ PP16_SWZ(krow)) << 4) + (pp & 1) * 8;
   }
 }
-template <bool TR, int BLK, int KS> __device__ __forceinline__ void pp16_read(bf16x8& dst, unsigned addr) {
+template <bool TR, int BLK, int KS, int OFF> __device__ __forceinline__ void pp16_read(bf16x8& dst, unsigned addr) {
+  // addr: the k-step's (k-contiguous image) resp. the block's (k-strided image) base in the k-tile's buffer; OFF: the unit's
+  // offset in the buffer.  No address arithmetic here: every VALU instruction of an L section competes with the partner
+  // wave's MFMA issue (16 MFMAs per C section hold the SIMD's vector issue for half of it).
   if (!TR) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr ^ (unsigned)(KS << 6)), "n"(BLK * 2048));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(BLK * 2048 + OFF));
   } else {
     short4v lo, hi;
-    const unsigned a2 = addr;                          // (the caller passes the block's own base: base ^ (BLK << 5), precomputed)
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a2), "n"(KS * 8192));
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a2), "n"(KS * 8192 + 1024));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(KS * 8192 + OFF));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(KS * 8192 + 1024 + OFF));
     bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
     dst = bf16x8{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
   }

@@ -79,12 +79,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
   float* pdst = nullptr; float* pdstx = nullptr;                       // grouped launch: partial tile of the item computed / staged
   int pld = 0, pldx = 0;
   const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((lds_void_p)smem);
-  unsigned fa[4], fb[2];                                         // fragment addresses per block (buffer 0; the other is + 65536)
-  fa[0] = lds0 + pp16_frag_off<TA>(wr * 64, lane);               // units A0 / A1: 64 rows per wave row, four 16-row blocks
-  fb[0] = lds0 + pp16_frag_off<TB>(wc * 32, lane);               // units B0 / B1: 32 columns per wave column, two blocks
+  unsigned fa[2][4], fb[2][2];                                   // fragment bases [k-tile buffer][block or k-step]
+  fa[0][0] = lds0 + pp16_frag_off<TA>(wr * 64, lane);            // units A0 / A1: 64 rows per wave row, four 16-row blocks
+  fb[0][0] = lds0 + pp16_frag_off<TB>(wc * 32, lane);            // units B0 / B1: 32 columns per wave column, two blocks
+  // k-strided image: one base per block (the k-step is an immediate offset); k-contiguous image: one base per k-step (the block
+  // is an immediate offset) -- fa[b] resp. fa[ks]
+  // -- fa[buf][b] resp. fa[buf][ks]; the unit is an immediate offset too, so a fragment read needs no address arithmetic
 #pragma unroll
-  for (int i = 1; i < 4; ++i) fa[i] = TA ? (fa[0] ^ (unsigned)(i << 5)) : fa[0];     // (k-contiguous image: the block is an immediate offset)
-  fb[1] = TB ? (fb[0] ^ 32u) : fb[0];
+  for (int i = 1; i < 4; ++i) fa[0][i] = TA ? (fa[0][0] ^ (unsigned)(i << 5)) : (i == 1 ? (fa[0][0] ^ 64u) : fa[0][0]);
+  fb[0][1] = TB ? (fb[0][0] ^ 32u) : (fb[0][0] ^ 64u);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa[1][i] = fa[0][i] + 65536u;
+  fb[1][0] = fb[0][0] + 65536u; fb[1][1] = fb[0][1] + 65536u;
 
   int m0, n0, nt, zsplit;       // the item being computed
   int m0x, n0x, ntx, zx;        // the item being staged: the same one, until the tail of its main loop starts fetching the next
@@ -176,18 +182,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
         _Pragma("unroll") for (int nbl = 0; nbl < 2; ++nbl)                                                    \
           acc[H][mb][2 * (JB) + nbl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BREG[2 * nbl + ks], a[mb][ks], acc[H][mb][2 * (JB) + nbl], 0, 0, 0); \
   } while (0)
-#define PP_READ_A(BASEOFF)                                                                                     \
+#define PP16_FA(BUF, B_, KS_) (TA ? fa[BUF][B_] : fa[BUF][KS_])
+#define PP16_FB(BUF, B_, KS_) (TB ? fb[BUF][B_] : fb[BUF][KS_])
+#define PP_READ_A(BUF, UNIT)                                                                                   \
   do {                                                                                                         \
-    pp16_read<TA, 0, 0>(a[0][0], fa[0] + (BASEOFF)); pp16_read<TA, 0, 1>(a[0][1], fa[0] + (BASEOFF));          \
-    pp16_read<TA, 1, 0>(a[1][0], fa[1] + (BASEOFF)); pp16_read<TA, 1, 1>(a[1][1], fa[1] + (BASEOFF));          \
-    pp16_read<TA, 2, 0>(a[2][0], fa[2] + (BASEOFF)); pp16_read<TA, 2, 1>(a[2][1], fa[2] + (BASEOFF));          \
-    pp16_read<TA, 3, 0>(a[3][0], fa[3] + (BASEOFF)); pp16_read<TA, 3, 1>(a[3][1], fa[3] + (BASEOFF));          \
+    pp16_read<TA, 0, 0, (UNIT) * PP_UNIT>(a[0][0], PP16_FA(BUF, 0, 0)); pp16_read<TA, 0, 1, (UNIT) * PP_UNIT>(a[0][1], PP16_FA(BUF, 0, 1)); \
+    pp16_read<TA, 1, 0, (UNIT) * PP_UNIT>(a[1][0], PP16_FA(BUF, 1, 0)); pp16_read<TA, 1, 1, (UNIT) * PP_UNIT>(a[1][1], PP16_FA(BUF, 1, 1)); \
+    pp16_read<TA, 2, 0, (UNIT) * PP_UNIT>(a[2][0], PP16_FA(BUF, 2, 0)); pp16_read<TA, 2, 1, (UNIT) * PP_UNIT>(a[2][1], PP16_FA(BUF, 2, 1)); \
+    pp16_read<TA, 3, 0, (UNIT) * PP_UNIT>(a[3][0], PP16_FA(BUF, 3, 0)); pp16_read<TA, 3, 1, (UNIT) * PP_UNIT>(a[3][1], PP16_FA(BUF, 3, 1)); \
   } while (0)
-#define PP_READ_A1(BASEOFF) PP_READ_A(BASEOFF)
-#define PP_READ_B(BREG, BASEOFF)                                                                               \
+#define PP_READ_B(BREG, BUF, UNIT)                                                                             \
   do {                                                                                                         \
-    pp16_read<TB, 0, 0>(BREG[0], fb[0] + (BASEOFF)); pp16_read<TB, 0, 1>(BREG[1], fb[0] + (BASEOFF));          \
-    pp16_read<TB, 1, 0>(BREG[2], fb[1] + (BASEOFF)); pp16_read<TB, 1, 1>(BREG[3], fb[1] + (BASEOFF));          \
+    pp16_read<TB, 0, 0, (UNIT) * PP_UNIT>(BREG[0], PP16_FB(BUF, 0, 0)); pp16_read<TB, 0, 1, (UNIT) * PP_UNIT>(BREG[1], PP16_FB(BUF, 0, 1)); \
+    pp16_read<TB, 1, 0, (UNIT) * PP_UNIT>(BREG[2], PP16_FB(BUF, 1, 0)); pp16_read<TB, 1, 1, (UNIT) * PP_UNIT>(BREG[3], PP16_FB(BUF, 1, 1)); \
   } while (0)
   // end of an L section: retire the units the next phase reads, publish, then wait for this phase's own reads
   // ALLOW = units (the oldest of the window f+3 .. f+6) that may stay in flight; P = phase: with HI = 1 the A1 unit
@@ -219,9 +226,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
     bf16x8 (&b0)[4] = SW ? by : bx;
     bf16x8 (&b1)[4] = SW ? bx : by;
     const int nunits = 4 * nt;
-    unsigned cb = (kt & 1) * 65536u;                   // this k-tile's buffer
-    asm volatile("" : "+s"(cb));                       // opaque: the fragment addresses (base ^ step, + buffer, + unit) are recomputed per
-                                                       // read (1-2 VALU) instead of living in ~40 loop-invariant registers
+    constexpr int CB = SW ? 1 : 0;                     // this k-tile's buffer (the k-tile parity is the template argument)
     const int nb = (kt & 1) ^ 1;                       // buffer of k-tile kt+1 (kt+2 shares this tile's)
     const int f0 = 4 * kt;                             // first phase; phase f issues unit f+6, may leave min(4, nunits-3-f) units in flight
     // Fragment reads are spread 8 / 4 / 8 / 4 over the phases: B0 of k-tile kt+1 is read in phase 3 of k-tile kt, into
@@ -229,13 +234,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
     // register sets swap roles every k-tile.  The unit order of the stream is therefore B0, A0, B1, A1: every phase
     // consumes exactly the unit the previous phase's wait retired.
     // ---- phase 0
-    if (!dg_nord || kt == 0) PP_READ_A(cb + 0 * PP_UNIT);
+    if (!dg_nord || kt == 0) PP_READ_A(CB, 0);
     if ((!TAIL || f0 + 6 < nunits || more) && !dg_nodma) PP_ISSUE(2, nb);
     PP_SYNC_L((TAIL && !more) ? nunits - 3 - f0 : 4, 0);
     PP_MFMA(0, 0, b0);
     PP_SYNC_C();
     // ---- phase 1
-    if (!dg_nord || kt == 0) PP_READ_B(b1, cb + 2 * PP_UNIT);
+    if (!dg_nord || kt == 0) PP_READ_B(b1, CB, 2);
     if ((!TAIL || f0 + 7 < nunits || more) && !dg_nodma) PP_ISSUE(3, nb);
     PP_SYNC_L((TAIL && !more) ? nunits - 4 - f0 : 4, 1);
     PP_MFMA(0, 1, b1);
@@ -246,13 +251,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
     // into the ring positions a prologue would use (nt is even).  The next item then starts with its operands in LDS
     // instead of issuing 96 KiB of LDS-DMA and waiting for it with the matrix pipe idle.
     if (TAIL && !SW && more) setup(nxt);
-    if (!dg_nord || kt == 0) PP_READ_A1(cb + 3 * PP_UNIT);
+    if (!dg_nord || kt == 0) PP_READ_A(CB, 3);
     if ((!TAIL || f0 + 8 < nunits || more) && !dg_nodma) PP_ISSUE(1, nb ^ 1);
     PP_SYNC_L((TAIL && !more) ? nunits - 5 - f0 : 4, 2);
     PP_MFMA(1, 1, b1);
     PP_SYNC_C();
     // ---- phase 3
-    if ((!TAIL || kt + 1 < nt) && (!dg_nord || kt == 0)) PP_READ_B(b1, (cb ^ 65536u) + 1 * PP_UNIT);
+    if ((!TAIL || kt + 1 < nt) && (!dg_nord || kt == 0)) PP_READ_B(b1, CB ^ 1, 1);
     if ((!TAIL || f0 + 9 < nunits || more) && !dg_nodma) PP_ISSUE(0, nb ^ 1);
     PP_SYNC_L((TAIL && !more) ? nunits - 6 - f0 : 4, 3);
     PP_MFMA(1, 0, b0);
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
     more = nxt < item_end;
     if (!(p.atomic & 0x4000)) {                        // (diagnostic 0x4000: epilogue only)
       using F = std::false_type; using T = std::true_type;
-      PP_READ_B(bx, 1 * PP_UNIT);                      // B0 of k-tile 0 (later k-tiles get theirs one phase ahead)
+      PP_READ_B(bx, 0, 1);                             // B0 of k-tile 0 (later k-tiles get theirs one phase ahead)
       int kt = 0;
       for (; kt + 2 < nt; kt += 2) { body(F{}, F{}, kt); body(F{}, T{}, kt + 1); }     // nt is even (host-checked)
       body(T{}, F{}, kt);
@@ -428,7 +433,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
 #undef PP_PROLOGUE
 #undef PP_MFMA
 #undef PP_READ_A
-#undef PP_READ_A1
 #undef PP_READ_B
 #undef PP_SYNC_L
 #undef PP_SYNC_C
@@ -465,12 +469,10 @@ bool uc2_gemm_pp16_supported(const GemmArgs& p, int trans_a, int trans_b) {
     if (p.partial) return true;
     return p.accumulate && !(p.atomic & 1) && p.split_k == 1 && trans_a && trans_b;
   }
-  if (!trans_a && !trans_b) return p.epi == EPI_NONE || p.epi == EPI_GELU || p.epi == EPI_ADD || p.epi == EPI_TANH;
+  if (!trans_a && !trans_b) return p.epi == EPI_NONE || p.epi == EPI_GELU || p.epi == EPI_ADD || p.epi == EPI_TANH || p.epi == EPI_DGELU;
   if (!trans_a && trans_b) return p.epi == EPI_NONE || p.epi == EPI_DGELU || p.epi == EPI_ADD;
   return p.epi == EPI_NONE;
 }
-
-void uc2_gemm_pp16_group_launch(const GemmArgs& p, hipStream_t st) { pp16_launch0<true, true, EPI_GROUP>(p, st); }
 
 void uc2_gemm_pp16_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st) {
   if (p.c_f32 && p.partial) {
@@ -486,6 +488,8 @@ void uc2_gemm_pp16_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream
     else if (p.epi == EPI_GELU) pp16_launch0<false, false, EPI_GELU>(p, st);
     else if (p.epi == EPI_ADD) pp16_launch0<false, false, EPI_ADD>(p, st);
     else if (p.epi == EPI_TANH) pp16_launch0<false, false, EPI_TANH>(p, st);
+    else if (p.epi == EPI_DGELU && p.aux_deriv) pp16_launch0<false, false, EPI_MUL>(p, st);     // dX = dY W with a k-contiguous W^T
+    else if (p.epi == EPI_DGELU) pp16_launch0<false, false, EPI_DGELU>(p, st);
     else pp16_launch0<false, false, EPI_NONE>(p, st);
   } else if (!trans_a && trans_b) {
     if (p.epi == EPI_DGELU && p.aux_deriv) pp16_launch0<false, true, EPI_MUL>(p, st);

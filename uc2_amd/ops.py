@@ -549,13 +549,21 @@ def linear_fwd(x2, w, bias, epi=EPI_NONE, aux_out=None, flags=0):
     return _gemm_planned(x2, w, M, N, K, False, False, bias=bias, epi=epi, aux_out=aux_out, flags=flags)
 
 
-def linear_dgrad(dy2, w, epi=EPI_NONE, aux_in=None, colsum_out=None, flags=0):
+DGRAD_TRANSPOSED_W = os.environ.get("UC2_DGRAD_WT", "1") != "0"     # bf16: dX = dY W reads a k-contiguous copy W^T (store.compute_t)
+
+
+def linear_dgrad(dy2, w, epi=EPI_NONE, aux_in=None, colsum_out=None, flags=0, wt=None):
     """dX[M,K] = epi(dY[M,N] @ W[N,K])  (W in nn.Linear layout).  With EPI_DGELU, colsum_out (fp32 [K]) += column sums
-    of dX = the bias gradient of the layer below (fused into the GEMM epilogue where the kernel supports it)."""
+    of dX = the bias gradient of the layer below (fused into the GEMM epilogue where the kernel supports it).
+    wt: optional k-contiguous copy W^T [K, N] (ParamStore.compute_t): the GEMM then reads both operands k-contiguously, which
+    the ping-pong kernel on the 16x16x32 MFMA does 4-10 % faster than the transposing LDS read of W."""
     M, N = dy2.shape
     K = w.shape[1]
     if colsum_out is not None and epi != EPI_DGELU:
         raise _lib.Uc2Error("colsum_out needs EPI_DGELU")
+    if wt is not None and gemm_plan(dy2.dtype, False, False, M, K, N)[0] == 12:
+        # (only where the plan for the k-contiguous form is the 16x16x32 kernel, which has every epilogue of this path for it)
+        return _gemm_planned(dy2, wt, M, K, N, False, False, epi=epi, aux_in=aux_in, aux_out=colsum_out, flags=flags)
     return _gemm_planned(dy2, w, M, K, N, False, True, epi=epi, aux_in=aux_in, aux_out=colsum_out, flags=flags)
 
 
@@ -871,6 +879,9 @@ class BertLayerFn(torch.autograd.Function):
                            dbias=G(P["fb"]))
         fp8 = ctx.fp8
         I_ = P["iw"].shape[0]
+        # k-contiguous copies W^T for the input-gradient GEMMs (bf16; refreshed once per optimizer step, one launch for all)
+        use_wt = DGRAD_TRANSPOSED_W and dtype == torch.bfloat16 and not fp8 and M >= 256
+        WT = (lambda pf, pl=None, shp=None: st.compute_t(pf, pl, shp)) if use_wt else (lambda *a_: None)
         # small token counts: the four weight gradients go out as ONE grouped launch at the end (wgrad_group)
         grouped = [] if (WGRAD_GROUP and dtype == torch.bfloat16 and M < WGRAD_SIDE_MIN_ROWS and M % 128 == 0) else None
         wgrad = (lambda dyv, xv, dwv: grouped.append((dyv, xv, dwv))) if grouped is not None else (lambda dyv, xv, dwv: linear_wgrad(dyv, xv, dwv, None))
@@ -879,17 +890,17 @@ class BertLayerFn(torch.autograd.Function):
             d_pre = linear_dgrad_fp8(d_o2, st, P["fw"], P["fw"], (H, I_), EPI_DGELU, pre, colsum_out=G(P["ib"]), flags=GEMM_AUX_DERIV)
         else:
             d_pre = linear_dgrad(d_o2, st.compute(P["fw"], dtype), EPI_DGELU, pre, colsum_out=G(P["ib"]),
-                                 flags=GEMM_AUX_DERIV)                                         # + d(intermediate bias)
+                                 flags=GEMM_AUX_DERIV, wt=WT(P["fw"]))                         # + d(intermediate bias)
         wgrad(d_pre, a, G(P["iw"]))
         if fp8:
             da = linear_dgrad_fp8(d_pre, st, P["iw"], P["iw"], (I_, H), EPI_ADD, dz2)
         else:
-            da = linear_dgrad(d_pre, st.compute(P["iw"], dtype), EPI_ADD, dz2)
+            da = linear_dgrad(d_pre, st.compute(P["iw"], dtype), EPI_ADD, dz2, wt=WT(P["iw"]))
         # LN1, output projection, attention, fused QKV
         d_o1, dz1 = ln_bwd(da, o1, x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, s_ln1,
                            dbias=G(P["ob"]))
         wgrad(d_o1, ctxv, G(P["ow"]))
-        dctx = linear_dgrad_fp8(d_o1, st, P["ow"], P["ow"], (H, H)) if fp8 else linear_dgrad(d_o1, st.compute(P["ow"], dtype))
+        dctx = linear_dgrad_fp8(d_o1, st, P["ow"], P["ow"], (H, H)) if fp8 else linear_dgrad(d_o1, st.compute(P["ow"], dtype), wt=WT(P["ow"]))
         dwqkv = st.grad_span(P["qw"], P["vw"], (3 * H, H))
         dbqkv = st.grad_span(P["qb"], P["vb"], (3 * H,))
         # d(q|k|v bias) comes out of attn_bwd: column sums of the dQ/dK/dV accumulators, added up per workgroup in LDS and
@@ -902,7 +913,8 @@ class BertLayerFn(torch.autograd.Function):
             if fp8:
                 dx = linear_dgrad_fp8(dqkv, st, P["qw"], P["vw"], (3 * H, H), EPI_ADD, dz1).view(B, L, H)
             else:
-                dx = linear_dgrad(dqkv, st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype), EPI_ADD, dz1).view(B, L, H)
+                dx = linear_dgrad(dqkv, st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype), EPI_ADD, dz1,
+                                  wt=WT(P["qw"], P["vw"], (3 * H, H))).view(B, L, H)
         if grouped:
             wgrad_group(grouped)
         hook = ctx.cfg.get("grad_ready_hook")

@@ -188,6 +188,33 @@ class ParamStore:
     def compute_span(self, p_first, p_last, shape, dtype):
         return self.span(self.data if dtype == torch.float32 else self.shadow, p_first, p_last, shape)
 
+    # ---- k-contiguous copies W^T of the layer weights (bf16), for the input-gradient GEMMs dX = dY W ----
+    def compute_t(self, p_first, p_last=None, shape=None):
+        """bf16 [cols, rows] transpose of the 2-D parameter p_first (or of the adjacent parameters p_first..p_last viewed as
+        `shape`, e.g. q|k|v -> [3H, H]), kept at the same offset of a second bf16 arena and refreshed with ONE batched launch
+        whenever the weights changed (once per optimizer step).  None if the shape is not made of whole 64 x 64 tiles."""
+        import ctypes
+        rows, cols = (tuple(shape) if shape is not None else tuple(p_first.shape))
+        if rows % 64 or cols % 64:
+            return None
+        self.sync_shadow()
+        if getattr(self, "shadow_t", None) is None:
+            self.shadow_t = torch.empty(self.total, dtype=torch.bfloat16, device=self.device)
+            self._t_items, self._t_version = {}, -1
+        o = self.offsets[id(p_first)]
+        new = o not in self._t_items
+        if new:
+            self._t_items[o] = (rows, cols)
+        if self._t_version != self.version or new:
+            todo = list(self._t_items.items()) if self._t_version != self.version else [(o, (rows, cols))]
+
+            class _Item(ctypes.Structure):
+                _fields_ = [("offset", ctypes.c_size_t), ("rows", ctypes.c_int), ("cols", ctypes.c_int)]
+            arr = (_Item * len(todo))(*[_Item(oo, r, c) for oo, (r, c) in todo])
+            _lib.call("uc2_transpose_batch", len(todo), arr, _lib.ptr(self.shadow), _lib.ptr(self.shadow_t), _lib.stream())
+            self._t_version = self.version
+        return self.shadow_t[o:o + rows * cols].view(cols, rows)
+
 
 def store_of(module):
     """the store that owns `module`'s parameters, built (or rebuilt after .to()/.cuda()) on demand"""
