@@ -329,8 +329,7 @@ def _plan_fits(plan, key):
         return False
     return K % 64 == 0
 _FWD_CANDIDATES = ((99, 1), (0, 1), (1, 1), (2, 1), (6, 1), (7, 1), (8, 1), (12, 1))     # (kernel variant, split_k); 99 = generic kernel, 8 = ping-pong, 12 = ping-pong on the 16x16x32 MFMA
-# (variant 10, the rolling epilogue, is no longer a candidate: never better than 8 inside the step; weight gradients stay on 8: the
-#  16x16x32 kernel is 3-28 % slower when both operands are k-strided)
+# (variant 10, the rolling epilogue, is no longer a candidate: never better than 8 inside the step)
 _WGRAD_SPLITS = (2, 3, 4, 6, 8, 12, 16)
 
 
@@ -418,7 +417,9 @@ def gemm_plan(dtype, ta, tb, M, N, K, wgrad=False):
         valid = [s for s in range(1, 129) if s * 256 <= K and _plan_fits((8, s), key)]
         for target in (cus, 2 * cus, cus // 2):
             if valid:
-                cands.append((8, min(valid, key=lambda s: (abs(tiles * s - target), s))))
+                sp_t = min(valid, key=lambda s: (abs(tiles * s - target), s))
+                cands.append((8, sp_t))
+                cands.append((12, sp_t))              # the same schedule on the 16x16x32 MFMA (within a few % of 8 either way here)
         cands = list(dict.fromkeys(cands))
     best, best_t = default, None
     timer_was, GEMM_TIMER = GEMM_TIMER, None          # tuning launches are not part of anybody's timed region
