@@ -22,6 +22,7 @@
 #include "common.h"
 
 #define AM_MAXW 5       // up to 160 positions
+#define AM_LOG2E 1.4426950408889634f
 #ifndef AM_BWD_PREFETCH
 #define AM_BWD_PREFETCH 0    // backward: fetch the next head into registers during the compute (costs ~80 VGPRs)
 #endif
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
     load_tile_regs<D, NCH>(rk, base + H, ld, L, tid, NW * 64);
     load_tile_regs<D, NCH>(rv, base + 2 * H, ld, L, tid, NW * 64);
     for (int k = tid; k < Lp; k += NW * 64) {
-      Ms[k] = (k < L) ? (mask ? mask[(size_t)b * L + k] : 0.f) : -1e30f;
+      Ms[k] = (k < L) ? (mask ? mask[(size_t)b * L + k] * AM_LOG2E : 0.f) : -1e30f;        // base-2 domain: p = exp2(s c2 + m' - max')
       Hk[k] = attn_line_hash(seed, bh, k, UC2_ATTN_SALT_K);
     }
     store_tile_regs<D, NCH>(Ks, rk, tid, NW * 64);
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
   __syncthreads();
 
   f32x16 sc[NW];
+  const float c2 = scale * AM_LOG2E;                   // scores are kept times log2(e): one v_exp_f32 per element, no multiply before it
   float mx = -INFINITY;
 #pragma unroll
   for (int kb = 0; kb < NW; ++kb) {
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
       const float m4[4] = {mv.x, mv.y, mv.z, mv.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float v = sc[kb][4 * g + e] * scale + m4[e];
+        const float v = fmaf(sc[kb][4 * g + e], c2, m4[e]);
         sc[kb][4 * g + e] = v;
         mx = fmaxf(mx, v);
       }
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int i = 4 * g + e;
-        const float p = __expf(sc[kb][i] - mx);
+        const float p = __builtin_amdgcn_exp2f(sc[kb][i] - mx);
         sum += p;
         sc[kb][i] = kp[e] ? (thresh ? p * keep_scale : p) : 0.f;
       }
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
                                                     0, 0, 0);
     store_acc_block(out + 32 * db, o, inv, h, q < L);
   }
-  if (lse && q < L && h == 0) lse[(size_t)bh * L + q] = mx + __logf(sum);
+  if (lse && q < L && h == 0) lse[(size_t)bh * L + q] = (mx + __builtin_amdgcn_logf(sum)) * 0.69314718056f;     // natural-log lse
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -311,11 +313,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
 #pragma unroll
     for (int o = 1; o < CPR; o <<= 1) dl += __shfl_xor(dl, o);
     const int cidx = tid + i * NTHR, row = cidx / CPR;
-    if (cidx - row * CPR == 0) Ds[row] = dl;
+    if (cidx - row * CPR == 0) Ds[row] = dl * scale;       // delta, pre-multiplied by the softmax scale
   }
   if (tid < Lp) {
-    Ms[tid] = (tid < L) ? rmask : -1e30f;
-    Ls[tid] = (tid < L) ? rlse : 0.f;
+    Ms[tid] = (tid < L) ? rmask * AM_LOG2E : -1e30f;          // base-2 domain, like the forward
+    Ls[tid] = (tid < L) ? rlse * AM_LOG2E : 0.f;
     Hq[tid] = attn_line_hash(seed, bh, tid, UC2_ATTN_SALT_Q);
     Hk[tid] = attn_line_hash(seed, bh, tid, UC2_ATTN_SALT_K);
   }
@@ -333,6 +335,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
     for (int s = 0; s < KS; ++s) kf[s] = ld_row(Ks, RS, r0, 2 * s + h);
     const float mk = Ms[r0];
     const uint32_t hk2 = Hk[r0];
+    const float c2 = scale * AM_LOG2E, ks_scale = keep_scale * scale;
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -358,15 +361,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int i = 4 * g + e;
-          const float p = __expf(sa[i] * scale + mk - l4[e]);
-          float pd = p, dp = pa[i];
+          // per element: fma, sub, exp2; two selects for the dropout multipliers (1/(1-p) and scale/(1-p)); mul, fma, mul
+          const float p = __builtin_amdgcn_exp2f(fmaf(sa[i], c2, mk) - l4[e]);
+          float m1 = 1.0f, m2 = scale;
           if (thresh) {
             const bool keep = attn_keep(hqv[e], hk2, thresh);
-            pd = keep ? p * keep_scale : 0.f;
-            dp = keep ? dp * keep_scale : 0.f;
+            m1 = keep ? keep_scale : 0.f;
+            m2 = keep ? ks_scale : 0.f;
           }
-          pa[i] = pd;                                // dropped P
-          const float dsv = p * (dp - d4[e]) * scale;
+          const float dsv = p * fmaf(pa[i], m2, -d4[e]);      // dS = P (dP_dropped - delta) scale, delta pre-scaled
+          pa[i] = thresh ? p * m1 : p;               // dropped P
           sa[i] = dsv;                               // dS
           ds4[e] = (bf16)dsv;
         }
