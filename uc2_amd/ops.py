@@ -881,7 +881,9 @@ class BertLayerFn(torch.autograd.Function):
         fp8 = ctx.fp8
         I_ = P["iw"].shape[0]
         # k-contiguous copies W^T for the input-gradient GEMMs (bf16; refreshed once per optimizer step, one launch for all)
-        use_wt = DGRAD_TRANSPOSED_W and dtype == torch.bfloat16 and not fp8 and M >= 256
+        # (from ~16 k tokens: at the reference's 104-pair micro-batch the k-contiguous form is no faster on the ring kernels and
+        #  8 % slower for the gelu'-multiply GEMM, scratch/nn_dgrad_small.py; at 38 400 rows it is 2-4 % faster, at 98 304 4-10 %)
+        use_wt = DGRAD_TRANSPOSED_W and dtype == torch.bfloat16 and not fp8 and M >= WGRAD_SIDE_MIN_ROWS
         WT = (lambda pf, pl=None, shp=None: st.compute_t(pf, pl, shp)) if use_wt else (lambda *a_: None)
         # small token counts: the four weight gradients go out as ONE grouped launch at the end (wgrad_group)
         grouped = [] if (WGRAD_GROUP and dtype == torch.bfloat16 and M < WGRAD_SIDE_MIN_ROWS and M % 128 == 0) else None
