@@ -106,6 +106,48 @@ def test_bert_layer_dropout_runs_and_is_reproducible():
     assert torch.equal(layer(x, ext), layer(x, ext))
 
 
+def test_bert_layer_backward_paths_at_bench_token_counts():
+    """One base-geometry BertLayer at 176 x 96 = 16 896 tokens (>= ops.WGRAD_SIDE_MIN_ROWS): the backward the bench step runs --
+    input gradients on the k-contiguous weight copies W^T (ParamStore.compute_t), weight gradients on the side stream -- against the
+    same layer with W read k-strided and everything on one stream, and against the grouped weight-gradient launch forced on at
+    this size.  Same dropout masks (same seed), bf16: dx and every parameter gradient agree to bf16 rounding of the GEMM outputs."""
+    cfg = make_cfg(O.BASE, drop=0.1)
+    layer = BertLayer(cfg)
+    synth.det_init_(layer)
+    layer.to(DEV).train()
+    set_compute_dtype(layer, torch.bfloat16)
+    B, L, H = 176, 96, 768
+    x0 = (synth.det_normal((B, L, H), 3) * 0.5).to(DEV).to(torch.bfloat16)
+    ext = torch.zeros(B, 1, 1, L, device=DEV)
+    dy = (synth.det_normal((B, L, H), 4) * 0.1).to(DEV).to(torch.bfloat16)
+
+    def run(wt, side, group_rows):
+        saved = (ops.DGRAD_TRANSPOSED_W, ops.WGRAD_SIDE_STREAM, ops.WGRAD_SIDE_MIN_ROWS)
+        ops.DGRAD_TRANSPOSED_W, ops.WGRAD_SIDE_STREAM = wt, side
+        if group_rows is not None:
+            ops.WGRAD_SIDE_MIN_ROWS = group_rows          # (the grouped launch and W^T are both gated by this threshold)
+        try:
+            layer.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            ops.rng.manual_seed(5)
+            y = layer(x, ext)
+            y.backward(dy)
+            ops.join_side_streams()
+            torch.cuda.synchronize()
+            return y.detach().clone(), x.grad.clone(), OrderedDict((n, p.grad.detach().clone()) for n, p in layer.named_parameters())
+        finally:
+            ops.DGRAD_TRANSPOSED_W, ops.WGRAD_SIDE_STREAM, ops.WGRAD_SIDE_MIN_ROWS = saved
+    y_ref, dx_ref, g_ref = run(False, False, None)                  # W k-strided, one stream, one GEMM per weight gradient
+    for (wt, side, rows) in ((True, True, None), (False, False, 1 << 30)):          # bench path; grouped weight gradients
+        y, dx, g = run(wt, side, rows)
+        assert torch.equal(y, y_ref)
+        assert rel_err(dx.float(), dx_ref.float()) < 4e-3
+        for n in g_ref:
+            if n.endswith("key.bias"):
+                continue                                            # (mathematically zero: rounding noise on both sides)
+            assert rel_err(g[n], g_ref[n]) < 4e-3, n
+
+
 def test_embedding_dropout_sits_after_layernorm():
     """training mode, p > 0: the reference computes dropout(LayerNorm(emb)) (model/model.py:331-333,361-363), so every
     embedding output element is 0 or eval_output / (1 - p)"""
