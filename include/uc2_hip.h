@@ -53,9 +53,9 @@ int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, const voi
  *   variant    UC2_GEMM_AUTO = the library's default kernel for the shape; UC2_GEMM_GENERIC = the register-staged
  *              kernel (any shape/alignment); 0..12 = one specific kernel (0-2 LDS-DMA rings, 6/7 wave-specialised
  *              rings, 8 = persistent ping-pong 256x256 on v_mfma_f32_32x32x16_bf16, 9 = the same with 192-row tiles, 12 = the same
- *              schedule on v_mfma_f32_16x16x32_bf16 (less energy per flop: +4..8 % on X W^T and dY W; slower when both operands are
- *              k-strided); experiments: 10 = ping-pong whose epilogue rolls into the next tile's main loop, 11 = two phases per
- *              k-tile; calls 10-12 do not cover run as 8).  A variant that does not
+ *              schedule on v_mfma_f32_16x16x32_bf16 (less energy per flop: +4..8 % on X W^T and dY W; calls 12 does not cover run as 8);
+ *              10 and 11 were round-3 experiment kernels -- rolling epilogue, two phases per k-tile: scratch/kernels/ -- and are
+ *              argument errors now, like every other number not listed).  A variant that does not
  *              support the shape falls back to the generic kernel.  uc2_amd/ops.py::gemm_plan picks it per shape.
  *   workspace  optional caller-owned device memory (>= split_k*M*N*4 bytes, 16-byte aligned) for split-K weight
  *              gradients: partial tiles are stored plainly and reduced in a second pass instead of fp32 atomics

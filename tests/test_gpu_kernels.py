@@ -458,9 +458,34 @@ def test_gemm_pingpong_16x16x32_epilogues(kind, M, N, K):
         assert rel_err(out.float(), ref.float()) < 2e-3
         if second is not None:
             assert rel_err(second.float(), ref2.float()) < 2e-3
+    # every kind against plain fp32 torch on the same bf16 operands (not only against variant 8): the epilogue's second stream,
+    # the aux tile and the column sums included
+    pre = (a.float() @ (b.float() if nt else b.float().t()) + (0 if bias is None else bias))
     if kind == "none":
-        want = a.float() @ (b.float() if nt else b.float().t()) + (0 if bias is None else bias)
-        assert rel_err(out.float(), want) < 4e-3
+        want, want2 = pre, None
+    elif kind in ("gelu", "gelu_noaux"):
+        want, want2 = torch.nn.functional.gelu(pre), (pre if kind == "gelu" else None)           # second stream: the pre-activation
+    elif kind == "gelu_d":
+        p_ = pre.clone().requires_grad_(True)
+        want = torch.nn.functional.gelu(p_)
+        want.sum().backward()
+        want, want2 = want.detach(), p_.grad                                                       # second stream: gelu'(pre)
+    elif kind in ("add", "add_nt"):
+        want, want2 = pre + aux.float(), None
+    elif kind == "tanh":
+        want, want2 = torch.tanh(pre), None
+    elif kind == "dgelu":
+        x_ = aux.float().requires_grad_(True)
+        torch.nn.functional.gelu(x_).sum().backward()
+        want = pre * x_.grad
+        want2 = want.sum(0)
+    else:                                                                                          # mul: aux holds gelu'(pre) already
+        want = pre * aux.float()
+        want2 = want.sum(0)
+    assert rel_err(out.float(), want) < 4e-3, kind
+    if want2 is not None:
+        # (column sums: fp32 sums of the UNROUNDED results in the kernel, of fp32 products here)
+        assert rel_err(second.float(), want2) < 4e-3, kind
 
 
 @pytest.mark.parametrize("kind", ["none", "add", "dgelu", "mul"])
@@ -583,7 +608,7 @@ def test_gemm_item_queue_gives_the_same_result_and_is_left_zeroed(ta, tb, M, N, 
     assert torch.equal(got, ref)
 
 
-@pytest.mark.parametrize("variant", [8, 7, 99])
+@pytest.mark.parametrize("variant", [12, 8, 7, 99])
 def test_gemm_gelu_saves_derivative_for_the_backward(variant):
     """UC2_GEMM_AUX_DERIV: the GELU epilogue stores gelu'(pre) (not pre) and the DGELU epilogue multiplies by it as
     is -- same results as the (pre, gelu'(pre)-in-the-backward) pair, in every kernel family"""
@@ -657,42 +682,10 @@ def test_gemm_pingpong_192_row_tiles(tb, epi, M, N, K):
     assert rel_err(o1.float(), ref.float()) < 3e-3
 
 
-@pytest.mark.parametrize("tb,epi,bias", [(False, "none", True), (False, "gelu", True), (False, "tanh", True), (True, "none", False)])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (4096, 768, 768), (16384, 2304, 512), (9472, 768, 3072)])
-def test_gemm_rolling_epilogue_equals_pingpong(tb, epi, bias, M, N, K):
-    """variant 10 (gemm_roll.hip: the epilogue of a tile rides in the L sections around the item boundary, the k-tile stream never
-    stops): bit-identical to the ping-pong kernel (same MFMA order, same rounding), on one tile, a few items per workgroup and
-    many; three launches into NaN-filled outputs (race screen: every element written, identically, every time)"""
-    a = rnd((M, K), 1, dtype=torch.bfloat16)
-    b = rnd((K, N) if tb else (N, K), 2, 0.05, dtype=torch.bfloat16)
-    bv = rnd((N,), 3) if bias else None
-    code = {"none": ops.EPI_NONE, "gelu": ops.EPI_GELU, "tanh": ops.EPI_TANH}[epi]
-    ref = ops.gemm(a, b, M, N, K, tb=tb, bias=bv, epi=code, variant=8)
-    gen = ops.gemm(a, b, M, N, K, tb=tb, bias=bv, epi=code, variant=GENERIC)
-    assert rel_err(ref.float(), gen.float()) < 3e-3
-    for _ in range(3):
-        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
-        ops.gemm(a, b, M, N, K, tb=tb, bias=bv, epi=code, out=out, variant=10)
-        assert torch.equal(out, ref)
-
-
-def test_gemm_rolling_variant_falls_back_to_pingpong_where_it_does_not_apply():
-    """variant 10 only takes bf16-output forward (bias) / input-gradient (no bias) GEMMs without aux streams and with >= 4
-    k-tiles; every other call that names it runs on variant 8 and gives variant 8's result"""
-    M, N, K = 512, 512, 128                                  # 2 k-tiles
-    a, b, bv = rnd((M, K), 1, dtype=torch.bfloat16), rnd((N, K), 2, 0.05, dtype=torch.bfloat16), rnd((N,), 3)
-    assert torch.equal(ops.gemm(a, b, M, N, K, bias=bv, variant=10), ops.gemm(a, b, M, N, K, bias=bv, variant=8))
-    K = 512
-    a, b = rnd((M, K), 1, dtype=torch.bfloat16), rnd((K, N), 2, 0.05, dtype=torch.bfloat16)
-    aux = rnd((M, N), 4, dtype=torch.bfloat16)
-    r10 = ops.gemm(a, b, M, N, K, tb=True, epi=ops.EPI_ADD, aux_in=aux, variant=10)
-    assert torch.equal(r10, ops.gemm(a, b, M, N, K, tb=True, epi=ops.EPI_ADD, aux_in=aux, variant=8))
-
-
-@pytest.mark.parametrize("variant", [8, 11])
+@pytest.mark.parametrize("variant", [8, 12])
 @pytest.mark.parametrize("epi", ["none", "gelu", "gelu_d", "add", "tanh", "dgelu", "mul"])
 def test_gemm_pingpong_epilogues_with_second_streams(epi, variant):
-    """every fused epilogue of the ping-pong kernels (variant 8: four phases per k-tile, 11: two) incl. the second output stream
+    """every fused epilogue of the ping-pong kernels (variant 8: 32x32x16 MFMA, 12: 16x16x32) incl. the second output stream
     (pre-activation or gelu') and the bias-gradient column sums, against the generic kernel; two launches agree bit for bit.
     (The epilogue moves 8-byte pieces straight from the accumulator layout into the transposition buffer, pp_epi_compute_q.)"""
     M, N, K = 2048, 768, 512
@@ -719,26 +712,6 @@ def test_gemm_pingpong_epilogues_with_second_streams(epi, variant):
     if s1 is not None:
         assert rel_err(s1.float(), s_ref.float()) < (3e-3 if s1.dtype == torch.bfloat16 else 2e-3)
         assert torch.equal(s1, s2) if s1.dtype == torch.bfloat16 else rel_err(s1, s2) < 1e-5
-
-
-@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 512, 1024), (2048, 768, 768), (4096, 2304, 256)])
-def test_gemm_two_phase_pingpong_equals_pingpong(ta, tb, M, N, K):
-    """variant 11 (gemm_pp2.hip: two phases of 16 MFMAs per k-tile) computes every output element in the same order as variant 8:
-    bit-identical bf16 results, fp32 split-K accumulation included; NaN-filled outputs, three launches (race screen)"""
-    a = rnd((K, M) if ta else (M, K), 1, dtype=torch.bfloat16)
-    b = rnd((K, N) if tb else (N, K), 2, dtype=torch.bfloat16)
-    bias = rnd((N,), 3)
-    ref = ops.gemm(a, b, M, N, K, ta=ta, tb=tb, bias=bias, variant=8)
-    for _ in range(3):
-        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
-        ops.gemm(a, b, M, N, K, ta=ta, tb=tb, bias=bias, out=out, variant=11)
-        assert torch.equal(out, ref)
-    acc0 = rnd((M, N), 4)
-    sk = 2 if K >= 256 else 1
-    r = ops.gemm(a, b, M, N, K, ta=ta, tb=tb, out=acc0.clone(), accumulate=True, split_k=sk, variant=8)
-    o = ops.gemm(a, b, M, N, K, ta=ta, tb=tb, out=acc0.clone(), accumulate=True, split_k=sk, variant=11)
-    assert torch.equal(o, r)
 
 
 @pytest.mark.parametrize("M,N,K,pad", [(256, 256, 128, 0), (1024, 768, 512, 256), (2560, 768, 4608, 64), (768, 1024, 2048, 0)])

@@ -394,7 +394,7 @@ static int gemm_impl(int dtype, int trans_a, int trans_b, int M, int N, int K,
                      int accumulate, int split_k, int variant, void* workspace, size_t workspace_bytes, int flags,
                      void* queue, void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
-  UC2_CHECK_ARG(variant == -2 || variant == 99 || (variant >= 0 && variant <= 12));
+  UC2_CHECK_ARG(variant == -2 || variant == 99 || (variant >= 0 && variant <= 9) || variant == 12);
   UC2_CHECK_ARG(M >= 0 && N >= 0 && K >= 0);
   UC2_CHECK_ARG(epilogue >= EPI_NONE && epilogue <= EPI_TANH);
   UC2_CHECK_ARG(!((epilogue == EPI_DGELU || epilogue == EPI_ADD) && aux_in == nullptr));

@@ -361,9 +361,6 @@ bool uc2_gemm_pp_supported(int trans_a, int trans_b, int c_f32, int epi, int til
 void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st, int tile_rows);
 bool uc2_gemm_pp16_supported(const GemmArgs& p, int trans_a, int trans_b);                       // gemm_pp16.hip
 void uc2_gemm_pp16_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st);
-void uc2_gemm_pp2_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st, int tile_rows);                // gemm_pp2.hip
-bool uc2_gemm_roll_supported(const GemmArgs& p, int trans_a, int trans_b);                        // gemm_roll.hip
-void uc2_gemm_roll_launch(const GemmArgs& p, int trans_b, hipStream_t st);
 void uc2_splitk_reduce(const GemmArgs& p, hipStream_t st);                                        // gemm.hip
 
 // ------------------------------------------------------------------------------------------------------
@@ -413,10 +410,10 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
   if (trans_b ? ((p.N & 7) != 0 || p.N < 8) : (p.N < 1)) return 0;
   int variant = p.variant;                           // per call (uc2_gemm's `variant` argument), never process state
   if (variant == 99) return 0;                       // caller asked for the generic kernel
-  const bool want_roll = variant == 10;              // rolling-epilogue ping-pong kernel (gemm_roll.hip); else the plain one
-  const bool want_pp2 = variant == 11;               // ping-pong kernel with two phases per k-tile (gemm_pp2.hip)
+  // (variants 10 = rolling epilogue and 11 = two phases per k-tile were measured in round 3, never selected by a plan, and
+  //  live under scratch/kernels/ with their result table in DESIGN.md; uc2_gemm rejects the numbers)
   const bool want_pp16 = variant == 12;              // ping-pong kernel on the 16x16x32 MFMA (gemm_pp16.hip)
-  if (want_roll || want_pp2 || want_pp16) variant = 8;
+  if (want_pp16) variant = 8;
   if (variant == 8 || variant == 9) {
     // ping-pong kernel: whole 256x256 (variant 9: 192x256) tiles, >= 2 k-tiles per split, and (bf16 output) an epilogue
     // made of whole 16-byte accesses; anything else runs on the ring kernels above / the generic kernel
@@ -440,18 +437,17 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
   // skew is off unless the call asks for it: back-to-back launches of the double-store GELU GEMM gained 16 % from
   // de-phasing, inside the training step no kernel moved
   if (variant == 9) { uc2_gemm_pp_launch(pd, trans_a, trans_b, st, 192); return 2; }
-  if (want_roll && uc2_gemm_roll_supported(pd, trans_a, trans_b)) { uc2_gemm_roll_launch(pd, trans_b, st); return 2; }
   if (variant == 8) {
     const size_t need = (size_t)p.split_k * p.M * p.N * sizeof(float);
     if (p.c_f32 && p.split_k > 1 && p.ws && need <= p.ws_bytes && (p.N & 3) == 0 && (p.ldc & 3) == 0 &&
         ((uintptr_t)p.C & 15) == 0 && ((uintptr_t)p.ws & 15) == 0) {
       pd.partial = p.ws;                             // two-stage: plain partial stores, then one reduction pass
       if (want_pp16 && uc2_gemm_pp16_supported(pd, trans_a, trans_b)) uc2_gemm_pp16_launch(pd, trans_a, trans_b, st);
-      else if (want_pp2) uc2_gemm_pp2_launch(pd, trans_a, trans_b, st, 256); else uc2_gemm_pp_launch(pd, trans_a, trans_b, st, 256);
+      else uc2_gemm_pp_launch(pd, trans_a, trans_b, st, 256);
       if (!p.defer) uc2_splitk_reduce(pd, st);
     } else {
       if (want_pp16 && uc2_gemm_pp16_supported(pd, trans_a, trans_b)) uc2_gemm_pp16_launch(pd, trans_a, trans_b, st);
-      else if (want_pp2) uc2_gemm_pp2_launch(pd, trans_a, trans_b, st, 256); else uc2_gemm_pp_launch(pd, trans_a, trans_b, st, 256);
+      else uc2_gemm_pp_launch(pd, trans_a, trans_b, st, 256);
     }
     return 2;                                         // (2: the kernel also produced the EPI_DGELU column sums)
   }

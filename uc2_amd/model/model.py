@@ -411,22 +411,44 @@ class VLXLMRForPretraining(VLXLMRPreTrainedModel):
             raise ValueError('invalid task')
 
     # ------------------------------------------------------------------ heads
-    @staticmethod
-    def _masked_rows(mask, n_hint=None):
+    # Count hints ('n_txt_labels' / 'n_img_mask_tgt' in the batch) are the caller's promise about device data the host never reads
+    # back.  A wrong one must not corrupt memory: padding entries of the fixed-size index list are -1, uc2_select_rows gathers them
+    # as zero rows / skips them when scattering, their labels become ignore_index; and every mismatch (either direction: a hint
+    # that is too small drops masked positions from the loss) is counted on the device in HINT_MISMATCH, which whoever syncs anyway
+    # (a logging step, the loader, bench.py) reads with hint_mismatches().  UC2_CHECK_HINTS=1 asserts at once (one sync per call).
+    HINT_MISMATCH = {}
+
+    @classmethod
+    def hint_mismatches(cls):
+        """number of forward calls so far whose count hint disagreed with the mask on the device (one host sync)"""
+        return int(sum(int(t.item()) for t in cls.HINT_MISMATCH.values()))
+
+    @classmethod
+    def _masked_rows(cls, mask, n_hint=None):
         """flat indices of the set entries of `mask`, in order.  Their number decides the shape of everything downstream, so
         finding it on the device costs a host sync (torch.nonzero; the reference's boolean indexing syncs the same way,
         model/model.py:653-657).  When the batch carries the count (`n_hint`, known to whoever built the labels on the host:
-        uc2_amd/data/loader.py::assemble, bench.py) the index list is built without one."""
+        uc2_amd/data/loader.py::assemble, bench.py) the index list is built without one; entries beyond the real count are -1."""
         flat = mask.reshape(-1)
         if n_hint is None:
             return torch.nonzero(flat, as_tuple=False).view(-1)
         n = int(n_hint)
+        cnt = flat.sum()
         if os.environ.get("UC2_CHECK_HINTS"):
-            assert int(flat.sum().item()) == n, "batch count hint %d != %d masked entries" % (n, int(flat.sum().item()))
+            assert int(cnt.item()) == n, "batch count hint %d != %d masked entries" % (n, int(cnt.item()))
+        key = str(flat.device)
+        acc = cls.HINT_MISMATCH.get(key)
+        if acc is None:
+            acc = cls.HINT_MISMATCH[key] = torch.zeros((), dtype=torch.int64, device=flat.device)
+        acc.add_((cnt != n).to(torch.int64))
         try:
-            return torch.nonzero_static(flat, size=n).view(-1)
+            return torch.nonzero_static(flat, size=n, fill_value=-1).view(-1)
         except (NotImplementedError, RuntimeError):         # no device kernel in this torch build: stable sort, still no sync
-            return torch.argsort(~flat.bool(), stable=True)[:n]
+            order = torch.argsort(~flat.bool(), stable=True)
+            if n > order.numel():
+                order = torch.cat([order, order.new_full((n - order.numel(),), -1)])
+            order = order[:n]
+            return torch.where(torch.arange(n, device=flat.device) < cnt, order, order.new_full((), -1))
 
     def _compute_masked_hidden(self, hidden, mask, n_hint=None, rows=None):
         """model/model.py:653-657: rows of `hidden` where mask is set (row compaction kernel)"""
@@ -438,7 +460,10 @@ class VLXLMRForPretraining(VLXLMRPreTrainedModel):
     def _masked_labels(self, hidden, txt_labels, n_hint):
         """(hidden[txt_labels != -1], txt_labels[txt_labels != -1]) with one index list for both (model/model.py:583-596)"""
         rows = self._masked_rows(txt_labels != -1, n_hint)
-        return self._compute_masked_hidden(hidden, None, rows=rows), txt_labels.reshape(-1).index_select(0, rows)
+        labels = txt_labels.reshape(-1).index_select(0, rows.clamp_min(0))
+        if n_hint is not None:
+            labels = torch.where(rows < 0, labels.new_full((), -100), labels)      # padding entries: ignore_index of the MLM loss
+        return self._compute_masked_hidden(hidden, None, rows=rows), labels
 
     def _pad_layer_unpad(self, input_, layer):
         return layer(input_)

@@ -39,12 +39,8 @@ class GemmTimer:
         tacc = b(not atomic)
         if variant == 12:
             return "gemm_bf16_pp16_kernel<%s, %s, true, %d, 2>" % (b(ta), b(tb), epi)
-        if variant == 11:
-            return "gemm_bf16_pp2_kernel<%s, %s, %s, %d, 2>" % (b(ta), b(tb), b(not atomic), epi)
         if variant in (8, 9):
             return "gemm_bf16_pp_kernel<%s, %s, %s, %d, %d>" % (b(ta), b(tb), b(not atomic), epi, 2 if variant == 8 else 1)
-        if variant == 10:
-            return "gemm_bf16_roll_kernel<%s, %d, %s>" % (b(tb), epi, b(not tb))
         if variant == 99:
             return "gemm_bf16_kernel<%s, %s, %s>" % (b(ta), b(tb), tacc)
         if variant in (6, 7):
@@ -242,7 +238,7 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
         else:
             variant = GEMM_AUTO
     ws = None
-    if variant in (8, 11, 12) and c_f32 and split_k > 1:
+    if variant in (8, 12) and c_f32 and split_k > 1:
         ws = _splitk_workspace(a.device, split_k * M * N * 4)
     two_stage = ws is not None
     timer = GEMM_TIMER
@@ -266,7 +262,7 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
         e1.record()
         if defer:
             call("uc2_gemm_splitk_reduce", M, N, ptr(out), ldc, split_k, int(accumulate), ptr(ws), ws.numel(), stream())
-        if variant in (8, 9, 10, 11, 12):  # ping-pong kernels: transposed accumulators unless fp32 atomics; the epilogue kind is a template argument
+        if variant in (8, 9, 12):  # ping-pong kernels: transposed accumulators unless fp32 atomics; the epilogue kind is a template argument
             epi_t = int(epi) + 4 if (flags & GEMM_AUX_DERIV and epi in (EPI_GELU, EPI_DGELU)) else int(epi)   # EPI_GELU_D = 5, EPI_MUL = 6
             key = (bool(ta), bool(tb), variant, bool(c_f32 and not two_stage), epi_t)
         else:
@@ -320,7 +316,7 @@ def _plan_fits(plan, key):
     """can the kernel of `plan` run the shape `key` (else the library would silently take its generic kernel)"""
     v, sp = plan
     ta, tb, M, N, K, wgrad = key
-    if v in (8, 9, 10, 11, 12):
+    if v in (8, 9, 12):
         rows = 192 if v == 9 else 256
         kt = K // 64
         per = ((kt + sp - 1) // sp + 1) & ~1
@@ -329,7 +325,6 @@ def _plan_fits(plan, key):
         return False
     return K % 64 == 0
 _FWD_CANDIDATES = ((99, 1), (0, 1), (1, 1), (2, 1), (6, 1), (7, 1), (8, 1), (12, 1))     # (kernel variant, split_k); 99 = generic kernel, 8 = ping-pong, 12 = ping-pong on the 16x16x32 MFMA
-# (variant 10, the rolling epilogue, is no longer a candidate: never better than 8 inside the step)
 _WGRAD_SPLITS = (2, 3, 4, 6, 8, 12, 16)
 
 
@@ -444,7 +439,7 @@ def _gemm_planned(a, b, M, N, K, ta, tb, wgrad=False, **kw):
     """one GEMM with its tuned (variant, split_k) plan, passed to the library with the call"""
     v, sp = gemm_plan(a.dtype, ta, tb, M, N, K, wgrad)
     flags = kw.pop("flags", 0)
-    if PP_SKEW and v in (8, 9, 10, 11, 12):
+    if PP_SKEW and v in (8, 9, 12):
         flags |= (PP_SKEW.get(kw.get("epi", EPI_NONE), 0) & 15) << 4
     return gemm(a, b, M, N, K, ta=ta, tb=tb, split_k=sp, variant=v, flags=flags, **kw)
 
