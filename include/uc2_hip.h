@@ -142,6 +142,13 @@ int uc2_attn_fwd(int dtype, int impl, int B, int L, int nh, int D, const void* q
 int uc2_attn_bwd(int dtype, int impl, int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
                  float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx, const void* dctx,
                  const float* lse, void* dqkv, float* dbias_qkv, void* stream);
+/* uc2_attn_bwd with a caller-owned work queue for the MFMA kernel: `queue` = 2 ints of device memory, zeroed once (the kernel
+ * leaves them zeroed), one per stream.  Workgroups take chunks of heads from an atomic counter instead of one fixed share each,
+ * so a launch that shares the chip with an overlapped all-reduce does not wait a second round for the workgroups placed late.
+ * Results identical to uc2_attn_bwd (dbias_qkv up to fp32 summation order); NULL = uc2_attn_bwd; the fp32-math kernels ignore it. */
+int uc2_attn_bwd_queued(int dtype, int impl, int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
+                        float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx, const void* dctx,
+                        const float* lse, void* dqkv, float* dbias_qkv, int* queue, void* stream);
 int uc2_attn_mfma_supported(int L, int D);
 /* head-averaged attention probabilities out[B, L, L] (MultiheadAttention need_weights, model/attention.py:255-260) */
 int uc2_attn_probs_mean(int dtype, int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
@@ -269,7 +276,7 @@ int uc2_scale(size_t n, float* x, const float* scale_dev, float scale_imm, void*
 
 /* ---- data-parallel communication on RCCL over xGMI (utils/distributed.py:15-42 all_reduce_and_rescale_tensors,
  *      :99-147 broadcast_tensors; hvd.init / rank / size at pretrain.py:384-388) -------------------------------
- *   One communicator per process (one process per GPU).  The library owns a side HIP stream and two events and
+ *   One communicator per process (one process per GPU).  The library owns a side HIP stream and three events and
  *   nothing else; librccl is opened lazily by uc2_comm_unique_id / uc2_comm_init.  A bucket's collective is ordered
  *   after `compute_stream` (its gradients are final), runs on the side stream while backward continues, and
  *   uc2_comm_wait(stream) orders `stream` behind everything issued so far (device-side wait; no call blocks the host
@@ -283,9 +290,15 @@ int uc2_comm_rank(void);
 int uc2_comm_world(void);                                           /* ranks RCCL itself counted (ncclCommCount) at init; 0 = no communicator */
 int uc2_comm_version(char* out, int bytes);                         /* "major.minor.patch" of the loaded librccl (hvd.init has no counterpart; for run records) */
 int uc2_comm_allreduce_bucket(void* buf, size_t count, int dtype, int average, void* compute_stream);
+/* the same, ordered after `compute_stream` AND `other_stream` (may be NULL): the caller's weight-gradient side stream.  A
+ * layer's bucket is final when the main stream (dX chain, bias / LayerNorm gradients) and that stream (the dW GEMMs) have both
+ * reached this point; the collective waits for the two events itself, the main stream is not joined behind the dW GEMMs
+ * (pretrain.py:556-566 reduces after the whole backward; Horovod has no counterpart). */
+int uc2_comm_allreduce_bucket_after(void* buf, size_t count, int dtype, int average, void* compute_stream, void* other_stream);
 int uc2_comm_broadcast(void* buf, size_t count, int dtype, int root, void* compute_stream);
 int uc2_comm_wait(void* stream);
 int uc2_comm_destroy(void);
+int uc2_comm_abort(void);                                           /* teardown on an error path: ncclCommAbort (does not wait for peers), then the handles */
 
 #ifdef __cplusplus
 }

@@ -268,6 +268,31 @@ def case_base(mm, out):
     run_pretrain_case(mm, BASE, 4, 60, 36, ["itm", "mlm"], "base4", out, False)
 
 
+def case_base_tasks(mm, out):
+    """round 4: the MRM / VMLM / TLM tasks of the pretrain mix (BASELINE.json configs[2]; config/uc2_pretrain.json:72-102) at the
+    BASE geometry (12L / 768H, vocabulary 250 002), B = 4, variable lengths -- the round-1..3 fixtures pin them at the tiny
+    config only.  Outputs as in run_pretrain_case; `tlm` takes position_ids from the batch (model/model.py:498-499)."""
+    cfg = ref_config(mm, BASE)
+    model = mm.VLXLMRForPretraining(cfg, img_dim=2048, img_label_dim=1601)
+    synth.det_init_(model)
+    model.train()
+    for task in ("vmlm", "tlm", "mrfr", "mrc", "mrc-kl"):
+        b = strip(synth.make_batch(BASE["vocab_size"], 4, 60, 36, task=task, seed=1, variable_len=True))
+        key = "base4var/%s" % task
+        if task == "tlm":
+            out[key + "/position_ids"] = b["position_ids"].numpy()
+        model.zero_grad()
+        loss = model(b, task, compute_loss=True)
+        scores = model(b, task, compute_loss=False)
+        if task in ("vmlm", "tlm"):
+            out[key + "/argmax"] = scores.argmax(-1).numpy()
+        put(out, key + "/scores", scores)
+        put(out, key + "/loss", loss, full=loss.numel() <= 70000 and task not in ("mrfr", "mrc-kl"))
+        loss.mean().backward()
+        grads_to(out, key, model)
+        print("  %s: loss.mean=%.6f" % (key, loss.mean().item()))
+
+
 LARGE = dict(vocab_size=250002, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
              intermediate_size=4096)
 
@@ -453,7 +478,7 @@ def case_collate(out):
 
 
 def main():
-    which = sys.argv[1:] or ["tiny", "gather", "adamw", "mha", "base", "more", "large", "retrieval", "collate"]
+    which = sys.argv[1:] or ["tiny", "gather", "adamw", "mha", "base", "base_tasks", "more", "large", "retrieval", "collate"]
     install_shims()
     sys.path.insert(0, REF)
     mm = importlib.import_module("model.model")
@@ -473,6 +498,8 @@ def main():
             case_mha(out)
         elif w == "base":
             case_base(mm, out)
+        elif w == "base_tasks":
+            case_base_tasks(mm, out)
         elif w == "large":
             case_large(mm, out)
         elif w == "more":

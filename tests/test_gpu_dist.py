@@ -13,25 +13,47 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_self_launches_two_ranks_and_replicas_stay_in_sync():
+@pytest.mark.parametrize("ranks,batch", [(2, 64), (4, 16), (8, 16)])
+def test_bench_self_launches_ranks_and_replicas_stay_in_sync(ranks, batch):
+    """2, 4 and 8 ranks on the one GPU of the test box (gloo data plane): the first 8-GPU run of the driver must not also be the
+    first 8-rank run of the step.  --batch 16 (1 536 tokens) takes the small-batch route (grouped weight gradients, no side
+    stream), --batch 64 the default kernels; the per-layer hooks, the tail reduction, the mean, clip and AdamW run on every rank
+    and the replicas must end bit-identical."""
     import torch
     if torch.cuda.is_initialized():
         # rank processes must be started from a process that has not initialised the GPU (fork + exec of a
         # GPU-initialised process is refused on this pool); this file sorts before the other GPU tests for that reason
         pytest.skip("the GPU is already initialised in this pytest process")
     env = dict(os.environ, UC2_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", UC2_AUTOTUNE="0",
-               UC2_HANG_TRACE="300")          # a stuck rank dumps its stacks and exits instead of running into the timeout
+               UC2_HANG_TRACE="400")          # a stuck rank dumps its stacks and exits instead of running into the timeout
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--batch", "64", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
-                       timeout=420)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1",
+                        "--batch", str(batch), "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["config"]["replicas_in_sync"] is True
-    assert d["config"]["global_batch"] == 128 and d["value"] > 0
-    assert d["config"]["gemm_item_queue"] is True      # N > 1: GEMM work items come from the queue (two processes share this GPU)
+    assert d["n_gpus"] == ranks and d["config"]["replicas_in_sync"] is True
+    assert d["config"]["global_batch"] == ranks * batch and d["value"] > 0
+    assert d["config"]["gemm_item_queue"] is True      # N > 1: GEMM / attention work items come from the queues (the processes share this GPU)
+
+
+def test_bench_two_ranks_side_stream_route_stays_in_sync():
+    """2 ranks at 176 pairs each (16 896 tokens >= ops.WGRAD_SIDE_MIN_ROWS): the route the 8-GPU bench takes -- weight gradients on
+    the side stream, each layer's all-reduce ordered behind BOTH streams (ops.pending_side_stream; the main stream is not joined),
+    W^T input gradients, attention backward on its work queue -- with the replicas bit-identical afterwards"""
+    import torch
+    if torch.cuda.is_initialized():
+        pytest.skip("the GPU is already initialised in this pytest process")
+    env = dict(os.environ, UC2_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", UC2_AUTOTUNE="0", UC2_HANG_TRACE="400")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "176", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["replicas_in_sync"] is True and d["config"]["global_batch"] == 352
 
 
 def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible():

@@ -648,6 +648,35 @@ def test_gemm_dgelu_fused_colsum(variant):
     assert rel_err(got, want) < 2e-3
 
 
+def test_attention_bwd_work_queue_matches_static_partition():
+    """uc2_attn_bwd_queued (N > 1: chunks of heads from an atomic counter, so that a launch sharing the chip with an all-reduce
+    kernel does not wait a second round for workgroups placed late) against the static partition at the bench size (12 288
+    heads): dqkv bit-identical, the fused bias gradient equal up to the fp32 order of the per-workgroup sums; the kernel leaves
+    the queue zeroed; three launches (race screen)"""
+    B, L, nh, D = 1024, 96, 12, 64
+    H = nh * D
+    qkv = rnd((B * L, 3 * H), 1, 0.7, dtype=torch.bfloat16)
+    mask = torch.zeros(B, L, device=DEV)
+    mask[::7, L - 9:] = -10000.0
+    dctx = rnd((B * L, H), 2, dtype=torch.bfloat16)
+    seed = torch.full((1,), 1234, dtype=torch.int64, device=DEV)
+    ctx, lse = ops.attn_fwd(qkv, mask, B, L, nh, D, 0.1, seed, 5, impl=2)
+    ref_db = torch.zeros(3 * H, device=DEV)
+    ref = ops.attn_bwd(qkv, mask, ctx, dctx, lse, B, L, nh, D, 0.1, seed, 5, impl=2, dbias=ref_db)
+    was = ops.GEMM_QUEUE
+    try:
+        ops.GEMM_QUEUE = True
+        for _ in range(3):
+            db = torch.zeros(3 * H, device=DEV)
+            got = ops.attn_bwd(qkv, mask, ctx, dctx, lse, B, L, nh, D, 0.1, seed, 5, impl=2, dbias=db)
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref)
+            assert rel_err(db, ref_db) < 1e-5
+            assert int(ops._gemm_queue(qkv.device).abs().sum()) == 0
+    finally:
+        ops.GEMM_QUEUE = was
+
+
 @pytest.mark.parametrize("impl,dtype", [(2, torch.bfloat16), (1, torch.bfloat16), (1, torch.float32)])
 @pytest.mark.parametrize("B,L,nh,D", [(3, 96, 12, 64), (2, 70, 4, 32)])
 def test_attention_bwd_fused_bias_grad(impl, dtype, B, L, nh, D):

@@ -310,3 +310,34 @@ def test_pretrain_base_geometry():
                      "roberta.encoder.layer.11.output.dense.weight",
                      "roberta.img_embeddings.img_linear.weight"):
             check_against_golden(g, "%s/grad/%s" % (key, name), grads[name], 5e-4)
+
+
+@pytest.mark.slow
+def test_pretrain_base_geometry_mix_tasks():
+    """round 4: the MRM / VMLM / TLM tasks of the pretrain mix (BASELINE.json configs[2]) at the BASE geometry, B = 4, variable
+    lengths, against the reference's own outputs (tests/golden/golden_base_tasks.npz, make_golden.py::case_base_tasks)"""
+    g = golden("base_tasks")
+    cfg = cfg_of(O.BASE)
+    W = make_weights(specs.pretrain_shapes(cfg))
+    for task in ("vmlm", "tlm", "mrfr", "mrc", "mrc-kl"):
+        batch = synth.make_batch(cfg.vocab_size, 4, 60, 36, task=task, seed=1, variable_len=True)
+        key = "base4var/%s" % task
+        if task == "tlm":
+            assert np.array_equal(batch["position_ids"].numpy(), g[key + "/position_ids"])
+        b = strip(batch)
+        with torch.no_grad():
+            scores = O.pretrain_forward(W, cfg, b, task, compute_loss=False)
+
+        def loss_fn(Wg):
+            l = O.pretrain_forward(Wg, cfg, b, task, compute_loss=True)
+            loss_fn.loss = l.detach()
+            return l.mean()
+        names = {"roberta.encoder.layer.0.attention.self.query.weight", "roberta.encoder.layer.11.output.dense.weight",
+                 "roberta.img_embeddings.img_linear.weight", "roberta.embeddings.LayerNorm.weight"}
+        _, grads = O.grads_of(loss_fn, W, names=names)
+        check_against_golden(g, key + "/scores", scores, 1e-4)
+        check_against_golden(g, key + "/loss", loss_fn.loss, 1e-4)
+        if key + "/argmax" in g.files:
+            assert np.array_equal(scores.argmax(-1).numpy(), g[key + "/argmax"])
+        for name in sorted(names):
+            check_against_golden(g, "%s/grad/%s" % (key, name), grads[name], 5e-4)

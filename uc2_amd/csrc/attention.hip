@@ -315,7 +315,7 @@ extern "C" int uc2_attn_fwd_mfma(int B, int L, int nh, int D, const void* qkv, c
                                  void* stream);
 extern "C" int uc2_attn_bwd_mfma(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
                                  float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx,
-                                 const void* dctx, const float* lse, void* dqkv, float* dbias, void* stream);
+                                 const void* dctx, const float* lse, void* dqkv, float* dbias, int* queue, void* stream);
 extern "C" int uc2_colsum_accum(int dtype, int M, int N, const void* X, int ldx, const uint8_t* rowmask, float* out, void* stream);
 extern "C" int uc2_attn_mfma_supported(int L, int D);
 
@@ -330,19 +330,25 @@ extern "C" int uc2_attn_fwd(int dtype, int impl, int B, int L, int nh, int D, co
   }
   return uc2_attn_fwd_simple(dtype, B, L, nh, D, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, lse, stream);
 }
-extern "C" int uc2_attn_bwd(int dtype, int impl, int B, int L, int nh, int D, const void* qkv, const float* mask,
-                            float scale, float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx,
-                            const void* dctx, const float* lse, void* dqkv, float* dbias_qkv, void* stream) {
+extern "C" int uc2_attn_bwd_queued(int dtype, int impl, int B, int L, int nh, int D, const void* qkv, const float* mask,
+                                   float scale, float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx,
+                                   const void* dctx, const float* lse, void* dqkv, float* dbias_qkv, int* queue, void* stream) {
   UC2_CHECK_ARG(impl >= 0 && impl <= 2);
   const bool mfma = (impl == 2) || (impl == 0 && dtype == 1 && uc2_attn_mfma_supported(L, D));
   if (mfma) {
     UC2_CHECK_ARG(dtype == 1 && uc2_attn_mfma_supported(L, D));
-    return uc2_attn_bwd_mfma(B, L, nh, D, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv, dbias_qkv, stream);
+    return uc2_attn_bwd_mfma(B, L, nh, D, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv, dbias_qkv, queue, stream);
   }
   const int rc = uc2_attn_bwd_simple(dtype, B, L, nh, D, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv,
                                      stream);
   if (rc != 0 || !dbias_qkv || B == 0) return rc;          // fp32-math kernels: the column sums are one more pass
   return uc2_colsum_accum(dtype, B * L, 3 * nh * D, dqkv, 3 * nh * D, nullptr, dbias_qkv, stream);
+}
+extern "C" int uc2_attn_bwd(int dtype, int impl, int B, int L, int nh, int D, const void* qkv, const float* mask,
+                            float scale, float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx,
+                            const void* dctx, const float* lse, void* dqkv, float* dbias_qkv, void* stream) {
+  return uc2_attn_bwd_queued(dtype, impl, B, L, nh, D, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv,
+                             dbias_qkv, nullptr, stream);
 }
 
 // ---- head-averaged attention probabilities (MultiheadAttention need_weights=True, reference

@@ -253,7 +253,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
                                                                 uint64_t seed_imm, const bf16* __restrict__ ctx,
                                                                 const bf16* __restrict__ dctx,
                                                                 const float* __restrict__ lse,
-                                                                bf16* __restrict__ dqkv, float* __restrict__ dbias, int nbh, int hpw) {
+                                                                bf16* __restrict__ dqkv, float* __restrict__ dbias, int nbh, int hpw,
+                                                                int* __restrict__ queue) {
   constexpr int KS = D / 16, DB = D / 32, RS = D * 2 + 16, Lp = NW * 32;
   constexpr int RSD = Lp * 2 + 16;                     // dS^T image: [key][query] bf16
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -266,7 +267,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
   float* Ds = Ls + Lp;
   uint32_t* Hq = reinterpret_cast<uint32_t*>(Ds + Lp);          // per-query / per-key dropout hashes
   uint32_t* Hk = Hq + Lp;
-  float* Cs = reinterpret_cast<float*>(Hk + Lp);       // [3H] column sums of dQ | dK | dV over this workgroup's heads (dbias only)
+  int* Tk = reinterpret_cast<int*>(Hk + Lp);           // [4] (queue) index of the workgroup's next chunk of heads
+  float* Cs = reinterpret_cast<float*>(Tk + 4);        // [3H] column sums of dQ | dK | dV over this workgroup's heads (dbias only)
   const int H = nh * D, ld = 3 * H;
   const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
   const int tid = threadIdx.x;
@@ -276,8 +278,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
   if (dbias) {                                         // (the head loop's first barrier orders this before any accumulation)
     for (int i = tid; i < 3 * H; i += NTHR) Cs[i] = 0.f;
   }
-  const int bh_end = min(nbh, (int)(blockIdx.x + 1) * hpw);
-  int bh = blockIdx.x * hpw;
+  // Chunks of `hpw` consecutive heads.  Static partition (queue == nullptr): one chunk per workgroup, the grid is one resident
+  // round.  With a caller-owned queue (two zeroed ints; uc2_attn_bwd_queued) a workgroup's first chunk is blockIdx.x and every
+  // later one comes from an atomic counter: when another kernel (an overlapped all-reduce) holds CUs, the workgroups that do run
+  // take over the work of those that are placed late instead of the kernel waiting a second round for them.  The ticket is
+  // fetched at the start of a chunk and read at its end; the last workgroup to leave zeroes the queue.
+  const int nchunk = (nbh + hpw - 1) / hpw;
+  int chunk = blockIdx.x;
+  int ticket = 0;
+  for (;;) {
+  if (chunk >= nchunk) break;
+  if (queue && tid == 0) ticket = __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int bh_end = min(nbh, (chunk + 1) * hpw);
+  int bh = chunk * hpw;
   // ---- fetch of one head into registers: Q, K, dO, O tiles (NCH chunks each), this lane's V fragments, mask / lse of row tid
   bf16x8 rq[NCH], rk[NCH], rg[NCH], ro[NCH], rvf[KS];
   float rmask = 0.f, rlse = 0.f;
@@ -418,6 +431,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
   }
   __syncthreads();                                     // every wave is done with this head's LDS tiles
   }
+  if (!queue) break;
+  if (tid == 0) Tk[0] = (int)gridDim.x + ticket;       // (the next write to Tk[0] is at least one head = several barriers away)
+  __syncthreads();
+  chunk = Tk[0];
+  }
+  if (queue && tid == 0) {
+    const int old = __hip_atomic_fetch_add(queue + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (int)gridDim.x - 1) { atomicExch(queue, 0); atomicExch(queue + 1, 0); }
+  }
   // d(q|k|v bias): the workgroup's heads were summed in LDS (ds_add_f32); one global atomic per column and workgroup
   // (2 x CUs workgroups) instead of one per column, wave and head
   if (dbias) {
@@ -443,9 +465,9 @@ static int launch_fwd(int B, int L, int nh, const void* qkv, const float* mask, 
 template <int D, int NW>
 static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, float scale, float drop_p,
                       const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx, const void* dctx,
-                      const float* lse, void* dqkv, float* dbias, hipStream_t st) {
+                      const float* lse, void* dqkv, float* dbias, int* queue, hipStream_t st) {
   constexpr int RS = D * 2 + 16, Lp = NW * 32, RSD = Lp * 2 + 16;
-  const size_t smem = 3 * Lp * RS + Lp * RSD + 5 * Lp * sizeof(float) + (dbias ? 3 * (size_t)nh * D * sizeof(float) : 0);
+  const size_t smem = 3 * Lp * RS + Lp * RSD + 5 * Lp * sizeof(float) + 16 + (dbias ? 3 * (size_t)nh * D * sizeof(float) : 0);
   auto kern = attn_bwd_mfma_kernel<D, NW>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -463,10 +485,18 @@ static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, 
     cus_cached = cus;
   }
   const int slots = 2 * cus_cached;
-  const int hpw = nbh > slots ? (nbh + slots - 1) / slots : 1;
-  hipLaunchKernelGGL(kern, dim3((nbh + hpw - 1) / hpw), dim3(NW * 64), smem, st, L, nh, (const bf16*)qkv, mask, scale,
+  int hpw = nbh > slots ? (nbh + slots - 1) / slots : 1;
+  int grid = (nbh + hpw - 1) / hpw;
+  if (queue && hpw > 4) {                              // dynamic chunks of a sixth of a static share (at least 4 heads), one resident round
+    hpw = hpw >= 24 ? hpw / 6 : 4;
+    const int nchunk = (nbh + hpw - 1) / hpw;
+    grid = nchunk < slots ? nchunk : slots;
+  } else {
+    queue = nullptr;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, L, nh, (const bf16*)qkv, mask, scale,
                      drop_thresh(drop_p), 1.0f / (1.0f - drop_p), seed_ptr, seed_imm, (const bf16*)ctx,
-                     (const bf16*)dctx, lse, (bf16*)dqkv, dbias, nbh, hpw);
+                     (const bf16*)dctx, lse, (bf16*)dqkv, dbias, nbh, hpw, queue);
   UC2_LAUNCH_CHECK();
   return 0;
 }
@@ -507,12 +537,12 @@ extern "C" int uc2_attn_fwd_mfma(int B, int L, int nh, int D, const void* qkv, c
 
 extern "C" int uc2_attn_bwd_mfma(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
                                  float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx,
-                                 const void* dctx, const float* lse, void* dqkv, float* dbias, void* stream) {
+                                 const void* dctx, const float* lse, void* dqkv, float* dbias, int* queue, void* stream) {
   UC2_CHECK_ARG(uc2_attn_mfma_supported(L, D));
   UC2_CHECK_ARG(B >= 0 && nh >= 1 && drop_p >= 0.f && drop_p < 1.f);
   UC2_CHECK_ARG(((nh * D) % 8) == 0);
   if (B == 0) return 0;
   UC2_CHECK_ARG(qkv && ctx && dctx && lse && dqkv);
   hipStream_t st = (hipStream_t)stream;
-  AM_DISPATCH(launch_bwd, B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv, dbias, st);
+  AM_DISPATCH(launch_bwd, B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv, dbias, queue, st);
 }

@@ -22,6 +22,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*GetVersion)(int*) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -32,7 +33,7 @@ struct Rccl {
 struct Comm {
   ncclComm_t comm = nullptr;
   hipStream_t side = nullptr;
-  hipEvent_t ready = nullptr, done = nullptr;
+  hipEvent_t ready = nullptr, ready2 = nullptr, done = nullptr;
   int rank = 0, world = 1;
   bool pending = false;
 } g_comm;
@@ -40,13 +41,21 @@ struct Comm {
 int rccl_open() {
   if (g_rccl.so) return 0;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) { g_rccl.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.so) break; }
-  if (!g_rccl.so) { uc2_set_error(__FILE__, __LINE__, "librccl.so not found (dlopen)"); return -2; }
-#define UC2_SYM(F, N) do { *(void**)(&g_rccl.F) = dlsym(g_rccl.so, N); if (!g_rccl.F) { uc2_set_error(__FILE__, __LINE__, "librccl: missing symbol " N); return -2; } } while (0)
+  void* so = nullptr;
+  for (const char* n : names) { so = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (so) break; }
+  if (!so) { uc2_set_error(__FILE__, __LINE__, "librccl.so not found (dlopen)"); return -2; }
+  // resolved into a local table and published only when every REQUIRED symbol exists: a failed open must not leave a handle
+  // that makes the next rccl_open() return 0 with null function pointers behind it
+  Rccl r;
+#define UC2_SYM(F, N) do { *(void**)(&r.F) = dlsym(so, N); if (!r.F) { uc2_set_error(__FILE__, __LINE__, "librccl: missing symbol " N); dlclose(so); return -2; } } while (0)
+#define UC2_SYM_OPT(F, N) do { *(void**)(&r.F) = dlsym(so, N); } while (0)
   UC2_SYM(GetUniqueId, "ncclGetUniqueId"); UC2_SYM(CommInitRank, "ncclCommInitRank"); UC2_SYM(CommDestroy, "ncclCommDestroy");
-  UC2_SYM(CommCount, "ncclCommCount"); UC2_SYM(GetVersion, "ncclGetVersion");
   UC2_SYM(AllReduce, "ncclAllReduce"); UC2_SYM(Broadcast, "ncclBroadcast"); UC2_SYM(GetErrorString, "ncclGetErrorString");
+  UC2_SYM_OPT(CommCount, "ncclCommCount"); UC2_SYM_OPT(GetVersion, "ncclGetVersion"); UC2_SYM_OPT(CommAbort, "ncclCommAbort");   // diagnostics / teardown: optional
 #undef UC2_SYM
+#undef UC2_SYM_OPT
+  r.so = so;
+  g_rccl = r;
   return 0;
 }
 }  // namespace
@@ -80,11 +89,13 @@ extern "C" int uc2_comm_init(int rank, int world, const void* unique_id, int byt
   UC2_NCCL(g_rccl.CommInitRank(&c.comm, world, id, rank));
   hipError_t e = hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c.ready, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c.ready2, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c.done, hipEventDisableTiming);
-  int count = 0;
-  ncclResult_t r = (e == hipSuccess) ? g_rccl.CommCount(c.comm, &count) : ncclSuccess;
+  int count = world;                                   // (a librccl without ncclCommCount: trust the argument)
+  ncclResult_t r = (e == hipSuccess && g_rccl.CommCount) ? g_rccl.CommCount(c.comm, &count) : ncclSuccess;
   if (e != hipSuccess || r != ncclSuccess || count != world) {
     if (c.done) (void)hipEventDestroy(c.done);
+    if (c.ready2) (void)hipEventDestroy(c.ready2);
     if (c.ready) (void)hipEventDestroy(c.ready);
     if (c.side) (void)hipStreamDestroy(c.side);
     g_rccl.CommDestroy(c.comm);
@@ -105,6 +116,7 @@ extern "C" int uc2_comm_version(char* out, int bytes) {
   UC2_CHECK_ARG(out && bytes >= 16);
   if (int rc = rccl_open()) return rc;
   int v = 0;
+  if (!g_rccl.GetVersion) { uc2_set_error(__FILE__, __LINE__, "librccl: no ncclGetVersion"); return -2; }
   UC2_NCCL(g_rccl.GetVersion(&v));
   const int major = v >= 10000 ? v / 10000 : v / 1000, minor = v >= 10000 ? (v % 10000) / 100 : (v % 1000) / 100, patch = v % 100;
   snprintf(out, bytes, "%d.%d.%d", major, minor, patch);
@@ -118,9 +130,13 @@ static int comm_dtype(int dtype, ncclDataType_t* t) {
 }
 
 // in-place all-reduce of one gradient bucket on the side stream, ordered after everything enqueued so far on
-// `compute_stream`; average != 0 -> mean over ranks (Horovod's default, utils/distributed.py:34), else sum.
-// Returns immediately; the result may be read on a stream only after uc2_comm_wait on that stream.
-extern "C" int uc2_comm_allreduce_bucket(void* buf, size_t count, int dtype, int average, void* compute_stream) {
+// `compute_stream` AND (if not NULL) on `other_stream`; average != 0 -> mean over ranks (Horovod's default,
+// utils/distributed.py:34), else sum.  Returns immediately; the result may be read on a stream only after uc2_comm_wait on
+// that stream.  `other_stream` is the caller's weight-gradient side stream: a layer's bucket is final when both the main
+// stream (bias / LayerNorm gradients, dX chain) and that stream (dW GEMMs) have reached this point -- the collective waits
+// for the two events itself, so the main stream is never serialised behind the weight-gradient GEMMs (round 3 joined them).
+extern "C" int uc2_comm_allreduce_bucket_after(void* buf, size_t count, int dtype, int average, void* compute_stream,
+                                               void* other_stream) {
   UC2_CHECK_ARG(g_comm.comm != nullptr);
   ncclDataType_t t;
   UC2_CHECK_ARG(comm_dtype(dtype, &t) == 0);
@@ -128,9 +144,16 @@ extern "C" int uc2_comm_allreduce_bucket(void* buf, size_t count, int dtype, int
   UC2_CHECK_ARG(buf != nullptr);
   UC2_HIP(hipEventRecord(g_comm.ready, (hipStream_t)compute_stream));
   UC2_HIP(hipStreamWaitEvent(g_comm.side, g_comm.ready, 0));
+  if (other_stream && other_stream != compute_stream) {
+    UC2_HIP(hipEventRecord(g_comm.ready2, (hipStream_t)other_stream));
+    UC2_HIP(hipStreamWaitEvent(g_comm.side, g_comm.ready2, 0));
+  }
   UC2_NCCL(g_rccl.AllReduce(buf, buf, count, t, average ? ncclAvg : ncclSum, g_comm.comm, g_comm.side));
   g_comm.pending = true;
   return 0;
+}
+extern "C" int uc2_comm_allreduce_bucket(void* buf, size_t count, int dtype, int average, void* compute_stream) {
+  return uc2_comm_allreduce_bucket_after(buf, count, dtype, average, compute_stream, nullptr);
 }
 
 // rank `root`'s bytes everywhere (initial parameter broadcast, pretrain.py:457), in place, same ordering rules
@@ -156,11 +179,24 @@ extern "C" int uc2_comm_wait(void* stream) {
   return 0;
 }
 
+static void comm_release_handles() {
+  (void)hipEventDestroy(g_comm.ready); (void)hipEventDestroy(g_comm.ready2); (void)hipEventDestroy(g_comm.done);
+  (void)hipStreamDestroy(g_comm.side);
+  g_comm = Comm();
+}
 extern "C" int uc2_comm_destroy(void) {
   if (!g_comm.comm) return 0;
   (void)hipStreamSynchronize(g_comm.side);
   g_rccl.CommDestroy(g_comm.comm);
-  (void)hipEventDestroy(g_comm.ready); (void)hipEventDestroy(g_comm.done); (void)hipStreamDestroy(g_comm.side);
-  g_comm = Comm();
+  comm_release_handles();
+  return 0;
+}
+// teardown of a rank that is leaving on an error while its peers may be inside a collective: ncclCommAbort does not wait for
+// outstanding operations (ncclCommDestroy can block for ever there); falls back to nothing but releasing the handles when the
+// loaded librccl has no abort
+extern "C" int uc2_comm_abort(void) {
+  if (!g_comm.comm) return 0;
+  if (g_rccl.CommAbort) g_rccl.CommAbort(g_comm.comm);
+  comm_release_handles();
   return 0;
 }

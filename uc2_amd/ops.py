@@ -599,11 +599,19 @@ def join_side_streams():
     for key in list(_side_dirty):
         torch.cuda.current_stream(torch.device(*key)).wait_stream(_side_streams[key])
     _side_dirty.clear()
+    _join_queued[0] = False            # (a backward that raised never ran its callback: the next one must queue a new join)
 
 
 def _end_of_backward_join():
     _join_queued[0] = False
     join_side_streams()
+
+
+def pending_side_stream(device):
+    """the weight-gradient side stream of `device` if kernels have been enqueued on it since the last join, else None.
+    GradSync orders a layer's all-reduce behind it (uc2_comm_allreduce_bucket_after) instead of joining it into the main stream."""
+    key = (device.type, device.index)
+    return _side_streams[key] if key in _side_dirty else None
 
 
 WGRAD_SIDE_MIN_ROWS = 16384      # below this many tokens the step is close to host-bound and the extra event / stream traffic makes it
@@ -622,8 +630,11 @@ def linear_wgrad(dy2, x2, dw, db):
         _linear_wgrad_now(dy2, x2, dw, db)
     dy2.record_stream(side)                      # keep the caching allocator from recycling them too early
     x2.record_stream(side)
+    was_clean = not _side_dirty
     _side_dirty.add((dev.type, dev.index))
-    if not _join_queued[0]:
+    if was_clean or not _join_queued[0]:
+        # (keyed on the dirty set going non-empty, not only on the flag: a backward that raised after queueing never runs its
+        #  callback, and a flag left set would keep every later backward from registering the join)
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward_join)
             _join_queued[0] = True
@@ -745,8 +756,13 @@ def attn_bwd(qkv, mask2d, ctx, dctx, lse, B, L, nh, D, drop_p=0.0, seed=None, se
     """dqkv; with dbias (fp32 [3H]) also dbias += column sums of dqkv = the gradient of the fused q|k|v bias"""
     dqkv = torch.empty_like(qkv)
     with _Timed("attn_bwd", B * L * nh * D * qkv.element_size() * 8 + B * nh * L * 4):   # qkv, ctx, dctx, lse in; dqkv out
-        call("uc2_attn_bwd", dt(qkv.dtype), ATTN_IMPL if impl is None else impl, B, L, nh, D, ptr(qkv), ptr(mask2d),
-             1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(dbias), stream())
+        if GEMM_QUEUE and qkv.dtype == torch.bfloat16:       # N > 1: the persistent kernels share the chip with the all-reduce kernels
+            call("uc2_attn_bwd_queued", dt(qkv.dtype), ATTN_IMPL if impl is None else impl, B, L, nh, D, ptr(qkv), ptr(mask2d),
+                 1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(dbias),
+                 ptr(_gemm_queue(qkv.device)[12:14]), stream())
+        else:
+            call("uc2_attn_bwd", dt(qkv.dtype), ATTN_IMPL if impl is None else impl, B, L, nh, D, ptr(qkv), ptr(mask2d),
+                 1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(dbias), stream())
     return dqkv
 
 
@@ -917,7 +933,10 @@ class BertLayerFn(torch.autograd.Function):
             wgrad_group(grouped)
         hook = ctx.cfg.get("grad_ready_hook")
         if hook is not None:
-            join_side_streams()                  # this layer's weight gradients must be complete before its all-reduce
+            # this layer's gradients are all enqueued: the main stream holds the bias / LayerNorm gradients, the side stream the
+            # four dW GEMMs.  The hook's all-reduce waits for both streams itself (ops.pending_side_stream ->
+            # uc2_comm_allreduce_bucket_after); joining the side stream into the main stream here (round 3) serialised every
+            # layer boundary of the main stream behind that layer's weight-gradient GEMMs exactly when N > 1.
             hook(ctx.layer)
         return (dx, None, None, None) + (None,) * len(ctx.params)
 

@@ -59,9 +59,32 @@ class NativeComm:
         cls.active = True
         if not cls._atexit:
             import atexit
-            atexit.register(cls.destroy)                     # ncclCommDestroy + stream / events, once, at interpreter exit
+            import sys
+            prev_hook = sys.excepthook
+
+            def _failed(tp, val, tb):                        # an uncaught exception ends this rank while its peers may sit in a
+                cls._failing = True                          # collective: ncclCommDestroy could then block for ever at exit
+                prev_hook(tp, val, tb)
+            sys.excepthook = _failed
+            atexit.register(cls._at_exit)                    # communicator + stream / events, once, at interpreter exit
             cls._atexit = True
         return True
+
+    _failing = False
+
+    @classmethod
+    def _at_exit(cls):
+        if cls._failing:
+            cls.abort()
+        else:
+            cls.destroy()
+
+    @classmethod
+    def abort(cls):
+        """error-path teardown: ncclCommAbort (does not wait for outstanding collectives), then the library's handles"""
+        if cls.active:
+            _lib.load().uc2_comm_abort()
+            cls.active = False
 
     @staticmethod
     def world():
@@ -86,9 +109,11 @@ class NativeComm:
             cls.active = False
 
     @staticmethod
-    def allreduce_avg(t):
-        """in-place mean over ranks of a contiguous fp32 / bf16 CUDA tensor, asynchronous (side stream)"""
-        _lib.call("uc2_comm_allreduce_bucket", t.data_ptr(), t.numel(), _lib.dt(t.dtype), 1, _lib.stream())
+    def allreduce_avg(t, after=None):
+        """in-place mean over ranks of a contiguous fp32 / bf16 CUDA tensor, asynchronous (the library's side stream), ordered
+        after the current stream and, if given, after the torch stream `after` (the weight-gradient side stream)"""
+        _lib.call("uc2_comm_allreduce_bucket_after", t.data_ptr(), t.numel(), _lib.dt(t.dtype), 1, _lib.stream(),
+                  None if after is None else after.cuda_stream)
 
     @staticmethod
     def broadcast(t, root):
@@ -118,12 +143,21 @@ class _Reducer:
     def __init__(self):
         self.works, self.sum_views, self.native_used = [], [], False
 
-    def start(self, v):
+    def start(self, v, after=None):
+        """after: a second torch stream whose work so far must be complete before the reduction reads v (the weight-gradient
+        side stream of uc2_amd.ops); the current stream is always waited for"""
         if _world() == 1 and not (NativeComm.active and _native_ok(v)):
             return                                           # one rank: the mean is the value (and there may be no process group)
         if _native_ok(v):
-            NativeComm.allreduce_avg(v)
+            NativeComm.allreduce_avg(v, after)
             self.native_used = True
+        elif after is not None and v.is_cuda:
+            # torch.distributed orders a collective behind the stream that is current when it is issued: issue it from the side
+            # stream, after that stream has been told to wait for the main one -- the main stream itself waits for nothing
+            after.wait_stream(torch.cuda.current_stream(v.device))
+            with torch.cuda.stream(after):
+                self.works.append(dist.all_reduce(v, async_op=True))
+            self.sum_views.append(v)
         else:
             self.works.append(dist.all_reduce(v, async_op=True))
             self.sum_views.append(v)
@@ -312,7 +346,11 @@ class GradSync:
         lo = min(st.offsets[id(p)] for p in ps)
         hi = max(st.offsets[id(p)] + p.numel() for p in ps)
         v = st.grad[lo:hi]
-        self._red.start(v)                 # 28 MB of fp32 per layer, in flight while the layers below run their backward
+        after = None
+        if v.is_cuda:
+            from .. import ops
+            after = ops.pending_side_stream(v.device)          # this layer's dW GEMMs, if they went to the side stream
+        self._red.start(v, after)          # 28 MB of fp32 per layer, in flight while the layers below run their backward
         self._views.append(v)
         self._done.append((lo, hi))
 
