@@ -112,7 +112,10 @@ def make_cfg(layers):
 
 
 def synth_batch(B, task, seed, device, T_TXT=T_TXT, N_REG=N_REG):
-    """CC-shaped synthetic batch, generated directly on the device"""
+    """CC-shaped synthetic batch, generated directly on the device.  Tasks: itm, mlm, and the other tasks
+    of the pretrain mix / the MRM heads -- vmlm (labels over the joint sequence, masked regions carry a token id,
+    data/mlm.py + model/model.py:600-625), tlm (two captions per sample: a second <s> mid-way, position ids restart,
+    data/mlm.py:420-429), mrfr and mrc-kl (15 % of the regions masked, at least one per pair, data/mrm.py:13-39)"""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -128,7 +131,15 @@ def synth_batch(B, task, seed, device, T_TXT=T_TXT, N_REG=N_REG):
                  gather_index=torch.arange(L, device=device).unsqueeze(0).repeat(B, 1))
     if task == "itm":
         batch["targets"] = (torch.rand(B, generator=g, device=device) < 0.5).long()
-    else:
+        return batch
+    if task == "tlm":
+        mid = T_TXT // 2
+        ids[:, mid] = 0                                      # the second caption's <s>
+        ids[:, mid - 1] = 2
+        p = torch.arange(T_TXT, device=device)
+        pid = torch.where(p < mid, p + 2, p - mid + 2)       # restart at 2 on every <s> (uc2_amd/utils/synth.py::tlm_position_ids)
+        batch["position_ids"] = pid.unsqueeze(0).repeat(B, 1)
+    if task in ("mlm", "tlm", "vmlm"):
         lab = torch.full((B, T_TXT), -1, dtype=torch.long, device=device)
         pick = torch.rand(B, T_TXT, generator=g, device=device) < 0.15
         pick[:, 0] = False
@@ -138,7 +149,31 @@ def synth_batch(B, task, seed, device, T_TXT=T_TXT, N_REG=N_REG):
         ids = ids.clone()
         ids[pick] = 250001
         batch["input_ids"], batch["txt_labels"] = ids, lab
-        batch["n_txt_labels"] = int(pick.sum().item())      # host-side count of the masked tokens, as a data loader has it (uc2_amd/data/loader.py)
+    if task in ("vmlm", "mrfr", "mrc-kl"):
+        im = torch.rand(B, N_REG, generator=g, device=device) < 0.15
+        im[:, 0] |= ~im.any(1)
+        batch["img_masks"] = im
+        batch["img_feat"] = feat.masked_fill(im.unsqueeze(-1), 0)
+        if task == "vmlm":
+            full = torch.full((B, L), -1, dtype=torch.long, device=device)
+            full[:, :T_TXT] = batch["txt_labels"]
+            tok = torch.randint(5, BASE["vocab_size"], (B, N_REG), generator=g, device=device)
+            full[:, T_TXT:] = torch.where(im, tok, torch.full_like(tok, -1))
+            batch["txt_labels"] = full
+        else:
+            tgt = torch.zeros(B, L, dtype=torch.bool, device=device)
+            tgt[:, T_TXT:] = im
+            batch["img_mask_tgt"] = tgt
+            batch["n_img_mask_tgt"] = int(im.sum().item())
+            if task == "mrfr":
+                batch["feat_targets"] = feat[im].contiguous()
+            else:
+                soft = torch.rand(B, N_REG, 1601, generator=g, device=device) ** 8
+                soft = soft / soft.sum(-1, keepdim=True)
+                batch["label_targets"] = soft[im].contiguous()
+    if "txt_labels" in batch:
+        # host-side count of the masked positions, as a data loader has it (uc2_amd/data/loader.py)
+        batch["n_txt_labels"] = int((batch["txt_labels"] != -1).sum().item())
     return batch
 
 
@@ -501,6 +536,35 @@ def main():
                 "note": "the reference's own regime: %d-pair micro-batches x %d accumulation micro-steps per optimizer step "
                         "(config/uc2_pretrain.json:17-19), all-reduce + clip + AdamW once per window" % (REF_MICRO, REF_ACCUM)}
         del rb
+        # ---- BASELINE.json configs[2] as SURVEY.md 8(d) specifies it, on this GPU: the pretrain task mix itm : mlm : vmlm : tlm =
+        # 9 : 12 : 9 : 3 (config/uc2_pretrain.json:72-76,100-102), one task per accumulation window like MetaLoader
+        # (data/loader.py:41-45), 104-pair micro-batches x 3, all-reduce + clip + AdamW per window; 33 windows in a fixed
+        # shuffled order.  Then one window each of the MRM heads (mrfr, mrc-kl: model/model.py:668-688,738-775).
+        import random as _random
+        order = ["itm"] * 9 + ["mlm"] * 12 + ["vmlm"] * 9 + ["tlm"] * 3
+        _random.Random(7).shuffle(order)
+        mb = {t: [synth_batch(REF_MICRO, t, 12000 * (rank + 1) + 17 * i + j, dev) for j in range(REF_ACCUM)]
+              for i, t in enumerate(("itm", "mlm", "vmlm", "tlm"))}
+        d4, _ = timed(lambda i: opt_step(mb[order[i % len(order)]], order[i % len(order)]), 8, len(order))
+        n4 = REF_MICRO * REF_ACCUM * world * len(order)
+        workloads["reference_regime_mix"] = {
+            "pairs_per_s": round(n4 / d4, 1), "ms_per_optimizer_step": round(d4 / len(order) * 1e3, 2),
+            "micro_batch_pairs": REF_MICRO, "accumulation_steps": REF_ACCUM, "windows": len(order),
+            "mix": "itm:mlm:vmlm:tlm = 9:12:9:3", "mfma_frac_encoder": round(n4 / d4 * ENC_GFLOP_PER_PAIR * 1e9
+                                                                              / (world * PEAK_BF16_TFLOPS * 1e12), 4),
+            "note": "BASELINE.json configs[2] on one GPU per rank: the pretrain task mix of config/uc2_pretrain.json:72-102, one task "
+                    "per accumulation window (data/loader.py:41-45), 104-pair micro-batches x 3, clip 5.0 + AdamW per window"}
+        del mb
+        for t in ("mrfr", "mrc-kl"):
+            rbm = [synth_batch(REF_MICRO, t, 15000 * (rank + 1) + j, dev) for j in range(REF_ACCUM)]
+            d5, _ = timed(lambda i: opt_step(rbm, t), 3, k3 // 2)
+            workloads["reference_regime_" + t.replace("-", "_")] = {
+                "pairs_per_s": round(REF_MICRO * REF_ACCUM * world * (k3 // 2) / d5, 1),
+                "ms_per_optimizer_step": round(d5 / (k3 // 2) * 1e3, 2), "micro_batch_pairs": REF_MICRO, "accumulation_steps": REF_ACCUM,
+                "note": "MRM head %s (model/model.py:668-688,738-775) in the reference's regime" % t}
+            del rbm
+        from uc2_amd.model.model import VLXLMRForPretraining as _M
+        workloads["count_hint_mismatches"] = _M.hint_mismatches()       # must be 0: every batch above carried exact counts
 
     in_sync = True
     if world > 1:          # data-parallel invariant: every replica holds bit-identical weights after the steps
@@ -558,8 +622,9 @@ def main():
                        "seq_len": T_TXT + N_REG, "parallelism": "dp%d" % world, "final_loss": round(lossv, 4), "replicas_in_sync": in_sync,
                        "gradient_allreduce": comm_path, "rccl_ranks": rccl_ranks, "rccl_version": rccl_version,
                        "gemm_item_queue": bool(ops.GEMM_QUEUE),
+                       "dgrad_routes": {"%dx%dx%d epi %d" % k: v for k, v in sorted(ops.DGRAD_ROUTES.items())},
                        "gemm_plans": {"%s%s %dx%dx%d" % ("T" if k[0] else "N", "T" if k[1] else "N", k[2], k[3], k[4]):
-                                      "%s split %d" % ("generic" if v[0] == 99 else "ping-pong" if v[0] == 8 else "ping-pong 192" if v[0] == 9 else "ping-pong rolling" if v[0] == 10 else "ping-pong 16x16x32" if v[0] == 12 else "ring v%d" % v[0], v[1])
+                                      "%s split %d" % ("generic" if v[0] == 99 else "ping-pong" if v[0] == 8 else "ping-pong 192" if v[0] == 9 else "ping-pong 16x16x32" if v[0] == 12 else "ring v%d" % v[0], v[1])
                                       for k, v in sorted(ops._TUNE.items())}},
             "mfma_frac_encoder": round(value * ENC_GFLOP_PER_PAIR * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": {"bound": "mfma", "kernel": kname,

@@ -23,8 +23,14 @@
 
 #define AM_MAXW 5       // up to 160 positions
 #define AM_LOG2E 1.4426950408889634f
+#ifndef AM_BWD_EARLY
+#define AM_BWD_EARLY 2       // with AM_BWD_PREFETCH == 2: how many of the four tiles (Q, K, dO, O) are fetched early
+#endif
 #ifndef AM_BWD_PREFETCH
-#define AM_BWD_PREFETCH 0    // backward: fetch the next head into registers during the compute (costs ~80 VGPRs)
+#define AM_BWD_PREFETCH 0    // backward: 1 = fetch the next head into registers before the main loop (costs ~80 VGPRs there: spills),
+                             //           2 = fetch AM_BWD_EARLY of its four tiles at the start of the dQ phase, where the main loop's accumulators are dead
+                             //           (round 4; measured at the bench size, same box: 289-291 us with 1, 2 or 3 early tiles against 291 without
+                             //           and 288.5 for round 3's kernel -- the backward is not bound by its load latency either; off)
 #endif
 
 __device__ __forceinline__ bf16x8 zero8() { return bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
@@ -129,6 +135,10 @@ __device__ __forceinline__ void store_tile_regs(char* dst, const bf16x8 (&r)[NCH
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// (Round 4 measured a persistent form of this kernel -- a resident round of workgroups walking heads with the next head's Q / K / V
+//  prefetched into registers under the current head's compute -- at the bench size: 139.0-139.5 us against 138.2 for this one
+//  (scratch/ab_attn_libs.py, same box).  The forward is not bound by the latency of its per-workgroup chain; what moved it in
+//  round 3 was the access pattern (head-major buffers: 147 -> 121 us).  Not kept.)
 template <int D, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, const bf16* __restrict__ qkv,
                                                                 const float* __restrict__ mask, float scale,
@@ -294,26 +304,39 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
   // ---- fetch of one head into registers: Q, K, dO, O tiles (NCH chunks each), this lane's V fragments, mask / lse of row tid
   bf16x8 rq[NCH], rk[NCH], rg[NCH], ro[NCH], rvf[KS];
   float rmask = 0.f, rlse = 0.f;
-  auto fetch = [&](int hd) __attribute__((always_inline)) {
+  // (the thread index goes through an opaque copy: hipcc otherwise hoists the ~20 per-lane 64-bit load addresses out of the head
+  //  loop, where they live -- and spill -- across the main loop)
+  auto fetch_tiles = [&](int hd, int lo, int hi) __attribute__((always_inline)) {      // tiles lo .. hi-1 of (0 Q, 1 K, 2 dO, 3 O)
     const int fb = hd / nh, fh = hd - fb * nh;
     const bf16* fbase = qkv + (size_t)fb * L * ld + fh * D;
-    load_tile_regs<D, NCH>(rq, fbase, ld, L, tid, NTHR);
-    load_tile_regs<D, NCH>(rk, fbase + H, ld, L, tid, NTHR);
-    load_tile_regs<D, NCH>(rg, dctx + (size_t)fb * L * H + fh * D, H, L, tid, NTHR);
-    load_tile_regs<D, NCH>(ro, ctx + (size_t)fb * L * H + fh * D, H, L, tid, NTHR);
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
+    if (lo <= 0 && 0 < hi) load_tile_regs<D, NCH>(rq, fbase, ld, L, t_, NTHR);
+    if (lo <= 1 && 1 < hi) load_tile_regs<D, NCH>(rk, fbase + H, ld, L, t_, NTHR);
+    if (lo <= 2 && 2 < hi) load_tile_regs<D, NCH>(rg, dctx + (size_t)fb * L * H + fh * D, H, L, t_, NTHR);
+    if (lo <= 3 && 3 < hi) load_tile_regs<D, NCH>(ro, ctx + (size_t)fb * L * H + fh * D, H, L, t_, NTHR);
+  };
+  auto fetch_rest = [&](int hd) __attribute__((always_inline)) {                       // V fragments, mask / lse of row tid
+    const int fb = hd / nh, fh = hd - fb * nh;
+    const bf16* fbase = qkv + (size_t)fb * L * ld + fh * D;
+    int r0_ = r0;
+    asm volatile("" : "+v"(r0_));
 #pragma unroll
     for (int s = 0; s < KS; ++s)
-      rvf[s] = (r0 < L) ? *reinterpret_cast<const bf16x8*>(fbase + 2 * H + (size_t)r0 * ld + 16 * s + 8 * h) : zero8();
+      rvf[s] = (r0 < L) ? *reinterpret_cast<const bf16x8*>(fbase + 2 * H + (size_t)r0_ * ld + 16 * s + 8 * h) : zero8();
     if (tid < Lp && tid < L) {
       rmask = mask ? mask[(size_t)fb * L + tid] : 0.f;
       rlse = lse[(size_t)hd * L + tid];
     }
   };
-  if (AM_BWD_PREFETCH) fetch(bh);
+  auto fetch = [&](int hd) __attribute__((always_inline)) { fetch_tiles(hd, 0, 4); fetch_rest(hd); };
+  if (AM_BWD_PREFETCH == 1 && bh < bh_end) fetch(bh);
+  if (AM_BWD_PREFETCH == 2 && bh < bh_end) fetch_tiles(bh, 0, AM_BWD_EARLY);      // (only the early tiles are carried around the loop)
   for (; bh < bh_end; ++bh) {
   const int b = bh / nh, head = bh - b * nh;
   bf16* dbase = dqkv + (size_t)b * L * ld + head * D;
   if (!AM_BWD_PREFETCH) fetch(bh);                     // no register prefetch: the CU's other workgroup covers the latency
+  if (AM_BWD_PREFETCH == 2) { fetch_tiles(bh, AM_BWD_EARLY, 4); fetch_rest(bh); }     // what the dQ phase of the previous head did not fetch
   // ---- registers -> LDS (the previous head's readers are past the barrier at the end of the loop body)
   store_tile_regs<D, NCH>(Qs, rq, tid, NTHR);
   store_tile_regs<D, NCH>(Ks, rk, tid, NTHR);
@@ -338,7 +361,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
 #pragma unroll
   for (int s = 0; s < KS; ++s) vf[s] = rvf[s];
   __syncthreads();
-  if (AM_BWD_PREFETCH && bh + 1 < bh_end) fetch(bh + 1);        // in flight during the compute below
+  if (AM_BWD_PREFETCH == 1 && bh + 1 < bh_end) fetch(bh + 1);        // in flight during the compute below
 
   // ---------------- rows = query, cols = key (this wave's 32 keys) -> dK, dV, and dS^T into LDS ----------------
   f32x16 dk[DB], dv[DB];
@@ -411,6 +434,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
     }
   }
   __syncthreads();                                     // every wave's dS^T columns are in LDS
+  // the next head's tiles: issued here, where dk / dv / the score tiles are dead (the prefetch then costs no register at the
+  // kernel's peak); they are in flight during the dQ phase, its stores and the barrier, and the CU's other workgroup
+  if (AM_BWD_PREFETCH == 2 && bh + 1 < bh_end) fetch_tiles(bh + 1, 0, AM_BWD_EARLY);
   // ---------------- dQ^T = K^T dS^T for this wave's 32 queries, contracted over all keys ----------------
   {
     f32x16 dq[DB];

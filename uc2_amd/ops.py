@@ -546,6 +546,10 @@ def linear_fwd(x2, w, bias, epi=EPI_NONE, aux_out=None, flags=0):
 
 
 DGRAD_TRANSPOSED_W = os.environ.get("UC2_DGRAD_WT", "1") != "0"     # bf16: dX = dY W reads a k-contiguous copy W^T (store.compute_t)
+DGRAD_WT_MIN_ROWS = 16384        # ... from this many tokens (its own knob, not the side stream's: at the reference's 104-pair
+                                 # micro-batch the k-contiguous form is no faster on the ring kernels and 8 % slower for the
+                                 # gelu'-multiply GEMM, scratch/nn_dgrad_small.py; at 38 400 rows 2-4 % faster, at 98 304 4-10 %)
+DGRAD_ROUTES = {}                # (M, N, K, epilogue) -> "W^T" | "W": which form linear_dgrad took, for the run record (bench.py)
 
 
 def linear_dgrad(dy2, w, epi=EPI_NONE, aux_in=None, colsum_out=None, flags=0, wt=None):
@@ -557,9 +561,17 @@ def linear_dgrad(dy2, w, epi=EPI_NONE, aux_in=None, colsum_out=None, flags=0, wt
     K = w.shape[1]
     if colsum_out is not None and epi != EPI_DGELU:
         raise _lib.Uc2Error("colsum_out needs EPI_DGELU")
-    if wt is not None and gemm_plan(dy2.dtype, False, False, M, K, N)[0] == 12:
-        # (only where the plan for the k-contiguous form is the 16x16x32 kernel, which has every epilogue of this path for it)
-        return _gemm_planned(dy2, wt, M, K, N, False, False, epi=epi, aux_in=aux_in, aux_out=colsum_out, flags=flags)
+    # The plan table is keyed by (layout, shape), not by epilogue: the k-contiguous form is taken where the plan of the NN
+    # shape is the 16x16x32 kernel (it has every epilogue of this path for it).  The lookup must never start a tuning pass
+    # inside a backward (a dozen timed launches + a host sync for a shape the forward never ran): untuned shapes keep W.
+    route = "W"
+    if wt is not None:
+        hit = _TUNE.get((False, False, M, K, N, False)) or _TUNE.get(_bucket_key((False, False, M, K, N, False)))
+        if hit is not None and hit[0] == 12 and _plan_fits(hit, (False, False, M, K, N, False)):
+            route = "W^T"
+    DGRAD_ROUTES[(M, K, N, int(epi))] = route
+    if route == "W^T":
+        return gemm(dy2, wt, M, K, N, split_k=1, variant=12, epi=epi, aux_in=aux_in, aux_out=colsum_out, flags=flags)
     return _gemm_planned(dy2, w, M, K, N, False, True, epi=epi, aux_in=aux_in, aux_out=colsum_out, flags=flags)
 
 
@@ -892,9 +904,8 @@ class BertLayerFn(torch.autograd.Function):
         fp8 = ctx.fp8
         I_ = P["iw"].shape[0]
         # k-contiguous copies W^T for the input-gradient GEMMs (bf16; refreshed once per optimizer step, one launch for all)
-        # (from ~16 k tokens: at the reference's 104-pair micro-batch the k-contiguous form is no faster on the ring kernels and
-        #  8 % slower for the gelu'-multiply GEMM, scratch/nn_dgrad_small.py; at 38 400 rows it is 2-4 % faster, at 98 304 4-10 %)
-        use_wt = DGRAD_TRANSPOSED_W and dtype == torch.bfloat16 and not fp8 and M >= WGRAD_SIDE_MIN_ROWS
+        # (from DGRAD_WT_MIN_ROWS tokens)
+        use_wt = DGRAD_TRANSPOSED_W and dtype == torch.bfloat16 and not fp8 and M >= DGRAD_WT_MIN_ROWS
         WT = (lambda pf, pl=None, shp=None: st.compute_t(pf, pl, shp)) if use_wt else (lambda *a_: None)
         # small token counts: the four weight gradients go out as ONE grouped launch at the end (wgrad_group)
         grouped = [] if (WGRAD_GROUP and dtype == torch.bfloat16 and M < WGRAD_SIDE_MIN_ROWS and M % 128 == 0) else None

@@ -191,17 +191,20 @@ class ParamStore:
     # ---- k-contiguous copies W^T of the layer weights (bf16), for the input-gradient GEMMs dX = dY W ----
     def compute_t(self, p_first, p_last=None, shape=None):
         """bf16 [cols, rows] transpose of the 2-D parameter p_first (or of the adjacent parameters p_first..p_last viewed as
-        `shape`, e.g. q|k|v -> [3H, H]), kept at the same offset of a second bf16 arena and refreshed with ONE batched launch
-        whenever the weights changed (once per optimizer step).  None if the shape is not made of whole 64 x 64 tiles."""
+        `shape`, e.g. q|k|v -> [3H, H]), kept in a second bf16 arena that spans ONLY the encoder layers' slice of the parameter
+        arena (170 MB for uc2-base, not the 0.55 GB the vocabulary tables would add; same relative offsets) and refreshed with
+        ONE batched launch whenever the weights changed (once per optimizer step).  None if the shape is not made of whole
+        64 x 64 tiles or the parameter lies outside that slice.  Call prepare_t() outside the step (warm-up / model set-up) to
+        allocate the arena before the first backward needs it."""
         import ctypes
         rows, cols = (tuple(shape) if shape is not None else tuple(p_first.shape))
         if rows % 64 or cols % 64:
             return None
         self.sync_shadow()
-        if getattr(self, "shadow_t", None) is None:
-            self.shadow_t = torch.empty(self.total, dtype=torch.bfloat16, device=self.device)
-            self._t_items, self._t_version = {}, -1
+        self.prepare_t()
         o = self.offsets[id(p_first)]
+        if o < self._t_lo or o + rows * cols > self._t_hi:
+            return None
         new = o not in self._t_items
         if new:
             self._t_items[o] = (rows, cols)
@@ -211,9 +214,26 @@ class ParamStore:
             class _Item(ctypes.Structure):
                 _fields_ = [("offset", ctypes.c_size_t), ("rows", ctypes.c_int), ("cols", ctypes.c_int)]
             arr = (_Item * len(todo))(*[_Item(oo, r, c) for oo, (r, c) in todo])
-            _lib.call("uc2_transpose_batch", len(todo), arr, _lib.ptr(self.shadow), _lib.ptr(self.shadow_t), _lib.stream())
+            # (the kernel addresses source and destination with the same element offset: the destination base is shifted by _t_lo)
+            _lib.call("uc2_transpose_batch", len(todo), arr, _lib.ptr(self.shadow), _lib.ptr(self.shadow_t) - 2 * self._t_lo,
+                      _lib.stream())
             self._t_version = self.version
-        return self.shadow_t[o:o + rows * cols].view(cols, rows)
+        return self.shadow_t[o - self._t_lo:o - self._t_lo + rows * cols].view(cols, rows)
+
+    def prepare_t(self):
+        """allocate the W^T arena: the slice of the parameter arena from the first to the last 2-D parameter of the encoder
+        layers (names containing 'encoder.layer.' / 'layer.<i>.'; a bare BertLayer: all its 2-D parameters)"""
+        if getattr(self, "shadow_t", None) is not None:
+            return
+        cand = [(self.offsets[id(p)], self.offsets[id(p)] + p.numel()) for n, p in zip(self.names, self.params)
+                if p.dim() == 2 and _slot_numel(p) == p.numel() and ("encoder.layer." in n or n.startswith("layer."))]
+        if not cand:
+            cand = [(self.offsets[id(p)], self.offsets[id(p)] + p.numel()) for p in self.params
+                    if p.dim() == 2 and _slot_numel(p) == p.numel()]
+        self._t_lo = min(c[0] for c in cand) if cand else 0
+        self._t_hi = max(c[1] for c in cand) if cand else 0
+        self.shadow_t = torch.empty(max(self._t_hi - self._t_lo, 1), dtype=torch.bfloat16, device=self.device)
+        self._t_items, self._t_version = {}, -1
 
 
 def store_of(module):

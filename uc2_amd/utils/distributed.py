@@ -142,6 +142,7 @@ class _Reducer:
 
     def __init__(self):
         self.works, self.sum_views, self.native_used = [], [], False
+        self.staged = []               # (device view, host copy) pairs of the gloo route
 
     def start(self, v, after=None):
         """after: a second torch stream whose work so far must be complete before the reduction reads v (the weight-gradient
@@ -151,6 +152,18 @@ class _Reducer:
         if _native_ok(v):
             NativeComm.allreduce_avg(v, after)
             self.native_used = True
+        elif v.is_cuda and dist.get_backend() == "gloo" and os.environ.get("UC2_GLOO_DIRECT", "0") != "1":
+            # gloo is the functional-test data plane (several ranks sharing the one GPU of a test box; the product path is RCCL).
+            # Its own handling of device tensors (internal streams + events per collective) stopped making progress with 4
+            # processes on one MI355X (every rank parked in work.wait(), round 4; 2 ranks and a bare 4-rank all-reduce of the same
+            # sizes were fine): the bytes are staged through host memory here instead -- copy down (ordered after both streams),
+            # reduce the host copy, copy back in finish().  What the test checks (hook order, spans, mean, replicas) is unchanged.
+            if after is not None:
+                torch.cuda.current_stream(v.device).wait_stream(after)
+            h = v.detach().to("cpu")                               # synchronises with the current stream
+            self.works.append(dist.all_reduce(h, async_op=True))
+            self.staged.append((v, h))
+            self.sum_views.append(v)
         elif after is not None and v.is_cuda:
             # torch.distributed orders a collective behind the stream that is current when it is issued: issue it from the side
             # stream, after that stream has been told to wait for the main one -- the main stream itself waits for nothing
@@ -166,6 +179,9 @@ class _Reducer:
         """wait for everything started; apply 1/world to the summed views and `extra_scale` to all of `views`"""
         for w in self.works:
             w.wait()
+        for v, h in self.staged:
+            v.copy_(h)
+        self.staged = []
         if self.native_used:
             NativeComm.wait()
         W = _world()
@@ -362,6 +378,7 @@ class GradSync:
         """hand the in-flight per-layer reductions to the caller's reducer (it waits for them and finishes the mean)"""
         red.works.extend(self._red.works)
         red.sum_views.extend(self._red.sum_views)
+        red.staged.extend(self._red.staged)
         red.native_used = red.native_used or self._red.native_used
         self._red = _Reducer()
         self.armed = False
