@@ -11,9 +11,6 @@
 // ------------------------------------------------------------------------------------------------------
 #include "gemm_pp16.h"
 
-#ifndef UC2_PP16_EARLY
-#define UC2_PP16_EARLY 0         /* MFMAs of a C section issued after its closing barrier (PP_C) */
-#endif
 #ifndef UC2_PP_DIAG
 #define UC2_PP_DIAG 0            /* 1: build the main-loop diagnostics 0x100 / 0x200 (tests/bench_pp.py) */
 #endif
@@ -185,14 +182,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
         _Pragma("unroll") for (int nbl = 0; nbl < 2; ++nbl)                                                    \
           acc[H][mb][2 * (JB) + nbl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BREG[2 * nbl + ks], a[mb][ks], acc[H][mb][2 * (JB) + nbl], 0, 0, 0); \
   } while (0)
-  // MFMAs LO .. HI_-1 of a C section in issue order (x = 8 ks + 2 mb + nbl)
-#define PP_MFMA_R(H, JB, BREG, LO, HI_)                                                                        \
-  do {                                                                                                         \
-    _Pragma("unroll") for (int x_ = (LO); x_ < (HI_); ++x_) {                                                  \
-      const int ks = x_ >> 3, mb = (x_ >> 1) & 3, nbl = x_ & 1;                                                \
-      acc[H][mb][2 * (JB) + nbl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BREG[2 * nbl + ks], a[mb][ks], acc[H][mb][2 * (JB) + nbl], 0, 0, 0); \
-    }                                                                                                          \
-  } while (0)
 #define PP16_FA(BUF, B_, KS_) (TA ? fa[BUF][B_] : fa[BUF][KS_])
 #define PP16_FB(BUF, B_, KS_) (TB ? fb[BUF][B_] : fb[BUF][KS_])
 #define PP_READ_A(BUF, UNIT)                                                                                   \
@@ -227,25 +216,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
     __builtin_amdgcn_s_barrier();                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
   } while (0)
-  // A whole C section.  UC2_PP16_EARLY = E > 0: the wave arrives at the closing barrier E MFMAs BEFORE the end of its C section.
-  // The barrier only tells the partner row "start your MFMAs" (this wave's LDS reads ended before the section began), and its
-  // release takes about as long as a few MFMAs: the partner's first MFMA then queues right behind this wave's last ones instead
-  // of ~70 cycles after them.
-#define PP_C(H, JB, BREG)                                                                                      \
-  do {                                                                                                         \
-    if (UC2_PP16_EARLY > 0) {                                                                                  \
-      PP_MFMA_R(H, JB, BREG, 0, 16 - UC2_PP16_EARLY);                                                          \
-      __builtin_amdgcn_sched_barrier(0);                                                                       \
-      __builtin_amdgcn_s_barrier();                                                                            \
-      __builtin_amdgcn_sched_barrier(0);                                                                       \
-      PP_MFMA_R(H, JB, BREG, 16 - UC2_PP16_EARLY, 16);                                                         \
-      __builtin_amdgcn_s_setprio(0);                                                                           \
-      __builtin_amdgcn_sched_barrier(0);                                                                       \
-    } else {                                                                                                   \
-      PP_MFMA(H, JB, BREG);                                                                                    \
-      PP_SYNC_C();                                                                                             \
-    }                                                                                                          \
-  } while (0)
 
   // main-loop diagnostics (with 0x800): 0x100 = no LDS-DMA issue (stale LDS contents), 0x200 = no fragment reads after the first k-tile
   const bool dg_nodma = UC2_PP_DIAG && (p.atomic & 0x100) != 0, dg_nord = UC2_PP_DIAG && (p.atomic & 0x200) != 0;     // (make EXTRA=-DUC2_PP_DIAG=1)
@@ -267,12 +237,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
     if (!dg_nord || kt == 0) PP_READ_A(CB, 0);
     if ((!TAIL || f0 + 6 < nunits || more) && !dg_nodma) PP_ISSUE(2, nb);
     PP_SYNC_L((TAIL && !more) ? nunits - 3 - f0 : 4, 0);
-    PP_C(0, 0, b0);
+    PP_MFMA(0, 0, b0);
+    PP_SYNC_C();
     // ---- phase 1
     if (!dg_nord || kt == 0) PP_READ_B(b1, CB, 2);
     if ((!TAIL || f0 + 7 < nunits || more) && !dg_nodma) PP_ISSUE(3, nb);
     PP_SYNC_L((TAIL && !more) ? nunits - 4 - f0 : 4, 1);
-    PP_C(0, 1, b1);
+    PP_MFMA(0, 1, b1);
+    PP_SYNC_C();
     // ---- phase 2
     // The stream does not drain at the end of an item: the last six phases (from here on in the first of the two tail
     // k-tiles; every unit of the current item has been issued) fetch the NEXT item's first six units, in the order and
@@ -282,19 +254,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
     if (!dg_nord || kt == 0) PP_READ_A(CB, 3);
     if ((!TAIL || f0 + 8 < nunits || more) && !dg_nodma) PP_ISSUE(1, nb ^ 1);
     PP_SYNC_L((TAIL && !more) ? nunits - 5 - f0 : 4, 2);
-    PP_C(1, 1, b1);
+    PP_MFMA(1, 1, b1);
+    PP_SYNC_C();
     // ---- phase 3
     if ((!TAIL || kt + 1 < nt) && (!dg_nord || kt == 0)) PP_READ_B(b1, CB ^ 1, 1);
     if ((!TAIL || f0 + 9 < nunits || more) && !dg_nodma) PP_ISSUE(0, nb ^ 1);
     PP_SYNC_L((TAIL && !more) ? nunits - 6 - f0 : 4, 3);
+    PP_MFMA(1, 0, b0);
     if (TAIL && kt == nt - 1) {                        // wave row 1 has no partner barrier left after its last C section
-      PP_MFMA(1, 0, b0);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       if (wr == 0) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     } else {
-      PP_C(1, 0, b0);
+      PP_SYNC_C();
     }
   };
 
@@ -459,8 +432,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
 #undef PP_ISSUE
 #undef PP_PROLOGUE
 #undef PP_MFMA
-#undef PP_MFMA_R
-#undef PP_C
 #undef PP_READ_A
 #undef PP_READ_B
 #undef PP_SYNC_L

@@ -566,8 +566,17 @@ def linear_dgrad(dy2, w, epi=EPI_NONE, aux_in=None, colsum_out=None, flags=0, wt
     # inside a backward (a dozen timed launches + a host sync for a shape the forward never ran): untuned shapes keep W.
     route = "W"
     if wt is not None:
-        hit = _TUNE.get((False, False, M, K, N, False)) or _TUNE.get(_bucket_key((False, False, M, K, N, False)))
-        if hit is not None and hit[0] == 12 and _plan_fits(hit, (False, False, M, K, N, False)):
+        key = (False, False, M, K, N, False)
+        hit = _TUNE.get(key) or _TUNE.get(_bucket_key(key))
+        if hit is None and M >= DGRAD_WT_MIN_ROWS:
+            # no plan for this token count: take the plan of the nearest tuned token count of the same (N, K) -- above the
+            # threshold the choice between the kernels does not depend on M any more (every committed plan there is variant 12)
+            near = [(abs(k[2] - M), v) for k, v in _TUNE.items() if not k[0] and not k[1] and not k[5] and k[3] == K and k[4] == N
+                    and k[2] >= DGRAD_WT_MIN_ROWS]
+            if near:
+                hit = min(near, key=lambda t: t[0])[1]
+                _TUNE[key] = hit
+        if hit is not None and hit[0] == 12 and _plan_fits(hit, key):
             route = "W^T"
     DGRAD_ROUTES[(M, K, N, int(epi))] = route
     if route == "W^T":
