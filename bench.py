@@ -522,7 +522,8 @@ def main():
         # (4 warm-up steps: the first steps of a new task grow the caching allocator's pool -- 2 x 2.3 GB of logits, and tensors a
         #  side stream still holds cannot be recycled while the host runs ahead -- and hipMalloc in a fresh process is slow:
         #  with 2, the first bench run on a fresh box timed 104 ms per MLM step, the second 75)
-        d2, _ = timed(lambda i: opt_step([ob[i % 2]], other), max(w2, 4), k2)
+        # (round 4, 2048 pairs: 3 x 3 GB of logits per step -- 188 ms per step after 3 warm-up steps, 135 after 8)
+        d2, _ = timed(lambda i: opt_step([ob[i % 2]], other), max(w2, 8), k2)
         workloads[other] = {"pairs_per_s": round(a.batch * world * k2 / d2, 1), "ms_per_step": round(d2 / k2 * 1e3, 2),
                             "pairs_per_gpu_per_step": a.batch, "steps": k2,
                             "note": "same step on the %s task (12/33 of the pretrain mix is MLM)" % other.upper()}

@@ -308,10 +308,10 @@ def test_pretrain_base_geometry_mix_tasks_vs_golden(dtype):
             if key + "/argmax" in g.files:
                 agree = float((scores.argmax(-1).cpu().numpy() == g[key + "/argmax"]).mean())
                 rep["argmax agreement"] = agree
-                assert agree >= 0.9
+                assert agree >= 0.8           # ~35 masked positions at B = 4: one flip is 3 %; near-ties of a random-init head (measured 0.88-1.0)
             for name in names:
                 rep["grad L2 " + name.split("roberta.")[1]] = check_against_golden(
-                    g, "%s/grad/%s" % (key, name), P[name].grad, 0.08, what=task, metric="l2")
+                    g, "%s/grad/%s" % (key, name), P[name].grad, 0.04, what=task, metric="l2")          # measured 0.8-1.7 %
             for k, v in rep.items():
                 print("bf16 base4var %-7s %-55s %.4g" % (task, k, v))
     del model
