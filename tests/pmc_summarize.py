@@ -16,6 +16,18 @@ def load(d):
     return acc
 
 
+def durations(d):
+    """kernel name -> average duration in ns from the kernel-trace CSV of the same pass"""
+    acc = collections.defaultdict(list)
+    for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            try:
+                acc[r["Kernel_Name"]].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+            except (KeyError, ValueError):
+                pass
+    return {k: sum(v) / len(v) for k, v in acc.items() if v}
+
+
 def pick(acc, sub):
     best = None
     for k, cs in acc.items():
@@ -26,7 +38,7 @@ def pick(acc, sub):
     return best
 
 
-def one(sub, F, W, S):
+def one(sub, F, W, S, DUR=None):
     avg = lambda v: sum(v) / len(v)
     out = {}
     hit = pick(F, sub)
@@ -47,6 +59,16 @@ def one(sub, F, W, S):
     if "SQ_VALU_MFMA_BUSY_CYCLES" in cs3 and "GRBM_GUI_ACTIVE" in cs3:
         # busy cycles are summed over 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE over the 8 XCDs
         out["mfma_busy_frac"] = round(avg(cs3["SQ_VALU_MFMA_BUSY_CYCLES"]) / (avg(cs3["GRBM_GUI_ACTIVE"]) / 8.0 * 1024.0), 4)
+    if DUR and "GRBM_GUI_ACTIVE" in cs3:
+        # effective shader clock under this kernel (MI355X_MICROARCH.md, DVFS give-back): GRBM_GUI_ACTIVE is summed over the 8 XCDs;
+        # reads high on launches shorter than ~0.3 ms, and a profiled pass clocks ~2.5 % below an un-profiled one
+        kn = pick(S, sub)[0]
+        if kn in DUR and DUR[kn] > 0:
+            out["avg_duration_us_in_pmc_pass"] = round(DUR[kn] / 1e3, 1)
+            out["derived_clock_GHz"] = round(avg(cs3["GRBM_GUI_ACTIVE"]) / 8.0 / DUR[kn], 3)
+            if "mfma_busy_frac" in out:
+                # flop rate this kernel would have at that clock with the matrix pipes always busy: 256 CUs x 4 SIMDs x 1024 flop/cycle
+                out["mfma_ceiling_at_that_clock_TFLOPs"] = round(256 * 4 * 1024 * out["derived_clock_GHz"] * 1e9 / 1e12, 1)
     if "SQ_WAIT_ANY" in cs3 and "SQ_WAVE_CYCLES" in cs3:
         out["wait_frac"] = round(avg(cs3["SQ_WAIT_ANY"]) / avg(cs3["SQ_WAVE_CYCLES"]), 4)
     return out
@@ -55,7 +77,8 @@ def one(sub, F, W, S):
 def main():
     rnd = int(sys.argv[1])
     F, W, S = load(sys.argv[2]), load(sys.argv[3]), load(sys.argv[4])
-    ks = [one(sub, F, W, S) for sub in sys.argv[5:]]
+    DUR = durations(sys.argv[4])
+    ks = [one(sub, F, W, S, DUR) for sub in sys.argv[5:]]
     ks = [k for k in ks if k]
     out = dict(ks[0])
     out["round"] = rnd
