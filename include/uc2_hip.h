@@ -132,6 +132,14 @@ int uc2_ln_bwd(int dtype, int M, int H, const void* dy, const void* x, const voi
                const float* mean, const float* rstd, float drop_p, int drop_after, const uint64_t* seed_ptr,
                uint64_t seed_imm, void* dx, void* dres, float* dgamma, float* dbeta, float* dbias, void* ws,
                void* stream);
+/* uc2_ln_bwd in its two stages: _partial writes dx / dres and per-workgroup partial column sums into ws (want_dbias: those of dx
+ * too); _reduce adds them into dgamma / dbeta / dbias (+=).  Nothing downstream in a backward pass reads the three vectors, so the
+ * second stage may run on another stream (the caller orders it after the first): uc2_amd/ops.py puts it on the weight-gradient
+ * side stream, off the input-gradient chain.  uc2_ln_bwd == both on one stream. */
+int uc2_ln_bwd_partial(int dtype, int M, int H, const void* dy, const void* x, const void* residual, const float* gamma,
+                       const float* mean, const float* rstd, float drop_p, int drop_after, const uint64_t* seed_ptr,
+                       uint64_t seed_imm, void* dx, void* dres, int want_dbias, void* ws, void* stream);
+int uc2_ln_bwd_reduce(int dtype, int M, int H, const void* ws, float* dgamma, float* dbeta, float* dbias, void* stream);
 
 /* ---- fused scaled-dot-product attention over the packed QKV projection (BertSelfAttention.forward,
  *      model/layer.py:75-101; additive key mask model/model.py:433-436) --------------------------------------------

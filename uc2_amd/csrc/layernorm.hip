@@ -390,10 +390,18 @@ static int ln_bwd_resident(int want) {
 
 extern "C" size_t uc2_ln_bwd_workspace(int M, int H) { return (size_t)ln_bwd_blocks(M) * 3 * H * sizeof(float); }
 
-extern "C" int uc2_ln_bwd(int dtype, int M, int H, const void* dy, const void* x, const void* residual,
-                          const float* gamma, const float* mean, const float* rstd, float drop_p, int drop_after,
-                          const uint64_t* seed_ptr, uint64_t seed_imm, void* dx, void* dres, float* dgamma, float* dbeta,
-                          float* dbias, void* ws, void* stream) {
+// number of workgroups (= partial rows in ws) the backward kernel of (dtype, M, H) is launched with
+static int ln_bwd_nblocks(int dtype, int M, int H) {
+  const int nb = ln_bwd_blocks(M), nc = (H + 255) / 256;
+  if (dtype == 0) return nc == 1 ? ln_bwd_resident<float, 1>(nb) : nc == 2 ? ln_bwd_resident<float, 2>(nb) : nc == 3 ? ln_bwd_resident<float, 3>(nb) : ln_bwd_resident<float, 4>(nb);
+  return nc == 1 ? ln_bwd_resident<bf16, 1>(nb) : nc == 2 ? ln_bwd_resident<bf16, 2>(nb) : nc == 3 ? ln_bwd_resident<bf16, 3>(nb) : ln_bwd_resident<bf16, 4>(nb);
+}
+
+// first stage only: dx / dres and the per-workgroup partial column sums in ws (want_dbias: also those of dx)
+extern "C" int uc2_ln_bwd_partial(int dtype, int M, int H, const void* dy, const void* x, const void* residual,
+                                  const float* gamma, const float* mean, const float* rstd, float drop_p, int drop_after,
+                                  const uint64_t* seed_ptr, uint64_t seed_imm, void* dx, void* dres, int want_dbias, void* ws,
+                                  void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
   UC2_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= LN_MAXC * 256);
   UC2_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
@@ -401,16 +409,13 @@ extern "C" int uc2_ln_bwd(int dtype, int M, int H, const void* dy, const void* x
   UC2_CHECK_ARG(dy && x && gamma && mean && rstd && ws);
   const uint32_t th = drop_thresh(drop_p);
   const float ks = 1.0f / (1.0f - drop_p);
-  int nb = ln_bwd_blocks(M);
+  const int nb = ln_bwd_nblocks(dtype, M, H);
   hipStream_t st = (hipStream_t)stream;
   const int nc = (H + 255) / 256;
 #define LN_BWD_LAUNCH(TT, NCC)                                                                                      \
-  do {                                                                                                              \
-    nb = ln_bwd_resident<TT, NCC>(nb);                                                                              \
-    hipLaunchKernelGGL((ln_bwd_kernel<TT, NCC>), dim3(nb), dim3(256), 0, st, M, H, (const TT*)dy, (const TT*)x,      \
-                       (const TT*)residual, gamma, mean, rstd, th, ks, seed_ptr, seed_imm, (TT*)dx, (TT*)dres,       \
-                       (float*)ws, dbias ? 1 : 0, drop_after);                                                      \
-  } while (0)
+  hipLaunchKernelGGL((ln_bwd_kernel<TT, NCC>), dim3(nb), dim3(256), 0, st, M, H, (const TT*)dy, (const TT*)x,        \
+                     (const TT*)residual, gamma, mean, rstd, th, ks, seed_ptr, seed_imm, (TT*)dx, (TT*)dres,         \
+                     (float*)ws, want_dbias ? 1 : 0, drop_after)
   if (dtype == 0) {
     if (nc == 1) LN_BWD_LAUNCH(float, 1); else if (nc == 2) LN_BWD_LAUNCH(float, 2);
     else if (nc == 3) LN_BWD_LAUNCH(float, 3); else LN_BWD_LAUNCH(float, 4);
@@ -420,11 +425,33 @@ extern "C" int uc2_ln_bwd(int dtype, int M, int H, const void* dy, const void* x
   }
 #undef LN_BWD_LAUNCH
   UC2_LAUNCH_CHECK();
-  if (dgamma || dbeta || dbias) {
-    const int nout = dbias ? 3 : 2;
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((nout * H + 63) / 64, nb >= 256 ? 16 : 1), dim3(256), 0, st, nb, H, nout,
-                       (const float*)ws, dgamma, dbeta, dbias);
-    UC2_LAUNCH_CHECK();
-  }
   return 0;
+}
+
+// second stage: dgamma / dbeta / dbias += the column sums of the partial rows a uc2_ln_bwd_partial of the same (dtype, M, H) left
+// in ws.  Nothing in the backward chain reads these three vectors, so the caller may run this on another stream (ordered after
+// the first stage): next to a persistent GEMM of a concurrent stream this small kernel otherwise waits ~100 us for a free CU
+// with the whole input-gradient chain queued behind it (profiles/r04_bench_n1_kernel_stats.csv: 121 us against 5.6 us alone).
+extern "C" int uc2_ln_bwd_reduce(int dtype, int M, int H, const void* ws, float* dgamma, float* dbeta, float* dbias,
+                                 void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  UC2_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= LN_MAXC * 256);
+  if (M <= 0 || !(dgamma || dbeta || dbias)) return 0;
+  UC2_CHECK_ARG(ws);
+  const int nb = ln_bwd_nblocks(dtype, M, H);
+  const int nout = dbias ? 3 : 2;
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((nout * H + 63) / 64, nb >= 256 ? 16 : 1), dim3(256), 0, (hipStream_t)stream, nb,
+                     H, nout, (const float*)ws, dgamma, dbeta, dbias);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int uc2_ln_bwd(int dtype, int M, int H, const void* dy, const void* x, const void* residual,
+                          const float* gamma, const float* mean, const float* rstd, float drop_p, int drop_after,
+                          const uint64_t* seed_ptr, uint64_t seed_imm, void* dx, void* dres, float* dgamma, float* dbeta,
+                          float* dbias, void* ws, void* stream) {
+  const int rc = uc2_ln_bwd_partial(dtype, M, H, dy, x, residual, gamma, mean, rstd, drop_p, drop_after, seed_ptr, seed_imm, dx,
+                                    dres, dbias != nullptr, ws, stream);
+  if (rc != 0) return rc;
+  return uc2_ln_bwd_reduce(dtype, M, H, ws, dgamma, dbeta, dbias, stream);
 }

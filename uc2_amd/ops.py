@@ -611,6 +611,8 @@ _join_queued = [False]
 def _side_stream(device):
     key = (device.type, device.index)
     if key not in _side_streams:
+        # (same priority as the main stream: torch on ROCm offers (0, -1) only; a high-priority side stream measured 111.8-116.7 ms
+        #  per step against 111.3-111.5)
         _side_streams[key] = torch.cuda.Stream(device=device)
     return _side_streams[key]
 
@@ -639,18 +641,22 @@ WGRAD_SIDE_MIN_ROWS = 16384      # below this many tokens the step is close to h
                                  # erratic (104-pair micro-batches: 27.6-45.5 ms per optimizer step with the side stream, 30.8 without)
 
 
-def linear_wgrad(dy2, x2, dw, db):
-    """dW[N,K] += dY^T X ; db[N] += colsum(dY)  (fp32 accumulation buffers)"""
-    if not WGRAD_SIDE_STREAM or dy2.shape[0] < WGRAD_SIDE_MIN_ROWS or torch.cuda.is_current_stream_capturing():
-        return _linear_wgrad_now(dy2, x2, dw, db)
-    dev = dy2.device
+def _side_route(rows):
+    return WGRAD_SIDE_STREAM and rows >= WGRAD_SIDE_MIN_ROWS and not torch.cuda.is_current_stream_capturing()
+
+
+def _on_side_stream(dev, fn, inputs):
+    """run fn() on the side stream of `dev`, ordered after everything enqueued so far on the current stream; `inputs` are the
+    tensors it reads (kept from the caching allocator until the side stream is done with them).  The side stream is joined at the
+    end of the backward pass (autograd callback), or right away outside one."""
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev)
     side.wait_stream(main)                       # inputs were produced on the main stream
     with torch.cuda.stream(side):
-        _linear_wgrad_now(dy2, x2, dw, db)
-    dy2.record_stream(side)                      # keep the caching allocator from recycling them too early
-    x2.record_stream(side)
+        fn()
+    for t in inputs:
+        if t is not None:
+            t.record_stream(side)
     was_clean = not _side_dirty
     _side_dirty.add((dev.type, dev.index))
     if was_clean or not _join_queued[0]:
@@ -661,6 +667,13 @@ def linear_wgrad(dy2, x2, dw, db):
             _join_queued[0] = True
         except RuntimeError:                     # not inside a backward pass: join right away
             join_side_streams()
+
+
+def linear_wgrad(dy2, x2, dw, db):
+    """dW[N,K] += dY^T X ; db[N] += colsum(dY)  (fp32 accumulation buffers)"""
+    if not _side_route(dy2.shape[0]):
+        return _linear_wgrad_now(dy2, x2, dw, db)
+    _on_side_stream(dy2.device, lambda: _linear_wgrad_now(dy2, x2, dw, db), (dy2, x2))
 
 
 # Below WGRAD_SIDE_MIN_ROWS tokens a layer's four weight gradients are too small to fill the chip one by one (9-36 output tiles
@@ -747,19 +760,35 @@ def ln_fwd(x2, res2, gamma, beta, eps, drop_p=0.0, seed=None, seed_imm=0, want_s
     return y, mean, rstd
 
 
+LN_REDUCE_SIDE = os.environ.get("UC2_LN_REDUCE_SIDE", "1") != "0"
+
+
 def ln_bwd(dy2, x2, res2, gamma, mean, rstd, dgamma, dbeta, drop_p=0.0, seed=None, seed_imm=0, need_dres=True,
            dbias=None, drop_after=False):
     """returns (dx, dres); with drop_p == 0 they are the same tensor.  dbias (optional, fp32 [H]) accumulates
-    the column sum of dx: the bias gradient of the dense layer that produced x, for free in the same pass."""
+    the column sum of dx: the bias gradient of the dense layer that produced x, for free in the same pass.
+    Two kernels: the streaming pass (dx, dres, per-workgroup partial column sums) and a small reduction of the partials into
+    dgamma / dbeta / dbias.  Nothing in the backward chain reads those three, so where the weight gradients run on the side
+    stream the reduction goes there too: beside a persistent weight-gradient GEMM that owns every CU, the 5 us kernel waited
+    ~115 us for a CU with the whole input-gradient chain queued behind it (24 times per step)."""
     M, H = x2.shape
     lib = _lib.load()
     ws = torch.empty(lib.uc2_ln_bwd_workspace(M, H) // 4, dtype=torch.float32, device=x2.device)
     dx = torch.empty_like(x2)
     dres = torch.empty_like(x2) if (drop_p > 0.0 and need_dres and not drop_after) else None
     streams = 3 + (1 if res2 is not None else 0) + (1 if dres is not None else 0)     # dy, x, (res) in; dx, (dres) out
+    d = dt(x2.dtype)
     with _Timed("ln_bwd", M * H * x2.element_size() * streams):
-        call("uc2_ln_bwd", dt(x2.dtype), M, H, ptr(dy2), ptr(x2), ptr(res2), ptr(gamma), ptr(mean), ptr(rstd), drop_p,
-             int(drop_after), ptr(seed), seed_imm, ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(ws), stream())
+        call("uc2_ln_bwd_partial", d, M, H, ptr(dy2), ptr(x2), ptr(res2), ptr(gamma), ptr(mean), ptr(rstd), drop_p,
+             int(drop_after), ptr(seed), seed_imm, ptr(dx), ptr(dres), int(dbias is not None), ptr(ws), stream())
+
+    def reduce():
+        call("uc2_ln_bwd_reduce", d, M, H, ptr(ws), ptr(dgamma), ptr(dbeta), ptr(dbias), stream())
+    if dgamma is not None or dbeta is not None or dbias is not None:
+        if LN_REDUCE_SIDE and _side_route(M):
+            _on_side_stream(x2.device, reduce, (ws,))
+        else:
+            reduce()
     return dx, (dres if dres is not None else dx)
 
 
