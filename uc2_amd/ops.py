@@ -578,7 +578,8 @@ def linear_dgrad(dy2, w, epi=EPI_NONE, aux_in=None, colsum_out=None, flags=0, wt
                 _TUNE[key] = hit
         if hit is not None and hit[0] == 12 and _plan_fits(hit, key):
             route = "W^T"
-    DGRAD_ROUTES[(M, K, N, int(epi))] = route
+    if wt is not None:
+        DGRAD_ROUTES[(M, K, N, int(epi))] = route
     if route == "W^T":
         return gemm(dy2, wt, M, K, N, split_k=1, variant=12, epi=epi, aux_in=aux_in, aux_out=colsum_out, flags=flags)
     return _gemm_planned(dy2, w, M, K, N, False, True, epi=epi, aux_in=aux_in, aux_out=colsum_out, flags=flags)
