@@ -607,19 +607,21 @@ def test_large_geometry_fp8_vs_golden():
         batch = synth.make_batch(250002, 2, 80, 50, task=task, seed=1)
         seq, scores, loss = run_task(model, batch, task)
         key = "large2/%s" % task
-        e1 = check_against_golden(g, key + "/seq", seq, 0.5, metric="l2")     # 96 GEMMs of e4m3 operands deep
+        e1 = check_against_golden(g, key + "/seq", seq, 0.15, metric="l2")    # 96 GEMMs of e4m3 operands deep; measured 0.10-0.11
         ref_mean = float(g[key + "/loss/sum3"][0]) / loss.numel()
         e2 = abs(loss.mean().item() - ref_mean) / abs(ref_mean)
         agree = float((scores.argmax(-1).cpu().numpy() == g[key + "/argmax"]).mean())
         P = dict(model.named_parameters())
         e3 = check_against_golden(g, "%s/grad/roberta.encoder.layer.23.output.dense.weight" % key,
-                                  P["roberta.encoder.layer.23.output.dense.weight"].grad, 0.6, metric="l2")
+                                  P["roberta.encoder.layer.23.output.dense.weight"].grad, 0.35 if task == "itm" else 0.2, metric="l2")
+        # (measured 0.29 for ITM -- at initialisation the ITM gradient is a difference of large cancelling terms, the bf16 run of the
+        #  tiny config needs 0.25 for it too -- and 0.13 for MLM)
         print("large fp8 %s: seq slice L2 rel %.3g, mean-loss rel %.3g, argmax agreement %.3f, last-layer grad L2 rel %.3g" % (task, e1, e2, agree, e3))
         assert e2 < 3e-2
         if task == "itm":
             assert agree == 1.0
         else:
-            assert agree >= 0.8
+            assert agree >= 0.9                                             # measured 0.917
     del model
     torch.cuda.empty_cache()
 
