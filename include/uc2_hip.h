@@ -144,7 +144,11 @@ int uc2_ln_bwd_reduce(int dtype, int M, int H, const void* ws, float* dgamma, fl
 /* ---- fused scaled-dot-product attention over the packed QKV projection (BertSelfAttention.forward,
  *      model/layer.py:75-101; additive key mask model/model.py:433-436) --------------------------------------------
  *   qkv [B*L, 3*nh*D] (q|k|v, head h at column h*D), mask [B, L] fp32 additive, ctx [B*L, nh*D], lse [B,nh,L].
- *   impl: 0 auto, 1 fp32-math kernels (any dtype), 2 MFMA kernels (bf16, L <= 160, D in {32,64}). */
+ *   impl: 0 auto, 1 fp32-math kernels (any dtype), 2 MFMA kernels (bf16, L <= 160, D in {32,64}); OR-ed with
+ *   UC2_ATTN_QKV_INTERLEAVED (MFMA kernels only): qkv and dqkv are [B*L, nh, 3, D] -- q|k|v of a head adjacent per token, what a
+ *   QKV GEMM on row-interleaved weights (uc2_qkv_interleave_batch) writes: one 384-byte segment per (token, head) instead of
+ *   three 128-byte ones.  ctx, dctx, lse and dbias_qkv (reference order q | k | v) are the same in both layouts. */
+#define UC2_ATTN_QKV_INTERLEAVED 16
 int uc2_attn_fwd(int dtype, int impl, int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
                  float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse, void* stream);
 int uc2_attn_bwd(int dtype, int impl, int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
@@ -249,6 +253,16 @@ int uc2_cast(int from_dtype, int to_dtype, size_t n, const void* in, void* out, 
  * as [rows][cols] (offsets in elements, rows and cols multiples of 64).  Used to keep k-contiguous copies W^T of the layer
  * weights (nn.Linear.weight [out, in], model/layer.py:76-156) beside their bf16 compute copies, refreshed once per optimizer
  * step, so that the input-gradient GEMMs dX = dY W read both operands k-contiguously. */
+/* head-interleaved copies of fused QKV projections (model/layer.py:76-78 query / key / value as one [3H, H] block): for every
+ * item the bf16 weight rows and the fp32 bias entries go from row w nh D + h D + d (w = 0 q, 1 k, 2 v) to row h 3D + w D + d.
+ * Offsets are element offsets from the four bases; b_*_base may both be NULL.  One launch for up to 64 items. */
+typedef struct { size_t w_src, w_dst, b_src, b_dst; } Uc2IlvItem;
+int uc2_qkv_interleave_batch(int n, const Uc2IlvItem* items, int nh, int D, int cols, const void* w_src_base, void* w_dst_base,
+                             const float* b_src_base, float* b_dst_base, void* stream);
+/* uc2_gemm_splitk_reduce for a weight gradient whose partial tiles have their ROWS in that interleaved order (dW = dqkv^T x with
+ * interleaved dqkv): row h 3D + w D + d of the partials is added to row w M/3 + h D + d of C (the parameter arena's order) */
+int uc2_gemm_splitk_reduce_qkv(int M, int N, void* C, int ldc, int split_k, int accumulate, const void* workspace,
+                               size_t workspace_bytes, int qkv_head_dim, void* stream);
 typedef struct { size_t offset; int rows, cols; } Uc2TransposeItem;
 int uc2_transpose_batch(int n, const Uc2TransposeItem* items, const void* src_base, void* dst_base, void* stream);
 

@@ -648,6 +648,71 @@ def test_gemm_dgelu_fused_colsum(variant):
     assert rel_err(got, want) < 2e-3
 
 
+def _ilv_perm(nh, D, device):
+    """index list: interleaved row h 3D + w D + d  <-  reference row w nh D + h D + d"""
+    h = torch.arange(nh, device=device).view(nh, 1, 1)
+    w = torch.arange(3, device=device).view(1, 3, 1)
+    d = torch.arange(D, device=device).view(1, 1, D)
+    return (w * nh * D + h * D + d).reshape(-1)
+
+
+@pytest.mark.parametrize("B,L,nh,D,p", [(3, 96, 12, 64, 0.0), (2, 70, 4, 32, 0.1), (64, 96, 12, 64, 0.1)])
+def test_attention_interleaved_qkv_layout_equals_plain(B, L, nh, D, p):
+    """UC2_ATTN_QKV_INTERLEAVED: the MFMA attention kernels on [B L, nh, 3, D] buffers (a head's q | k | v adjacent per token)
+    against the same data in the projection's natural [B L, 3, nh, D] order: ctx, lse, dqkv (up to the column permutation) and
+    the fused bias gradient (always in reference order) bit-identical"""
+    H = nh * D
+    perm = _ilv_perm(nh, D, DEV)
+    qkv = rnd((B * L, 3 * H), 1, 0.7, dtype=torch.bfloat16)
+    qkv_i = qkv[:, perm].contiguous()
+    mask = torch.zeros(B, L, device=DEV)
+    mask[0, L - 5:] = -10000.0
+    dctx = rnd((B * L, H), 2, dtype=torch.bfloat16)
+    seed = torch.full((1,), 77, dtype=torch.int64, device=DEV)
+    ctx, lse = ops.attn_fwd(qkv, mask, B, L, nh, D, p, seed, 3, impl=2)
+    ctx_i, lse_i = ops.attn_fwd(qkv_i, mask, B, L, nh, D, p, seed, 3, impl=2, ilv=True)
+    assert torch.equal(ctx, ctx_i) and torch.equal(lse, lse_i)
+    db, db_i = torch.zeros(3 * H, device=DEV), torch.zeros(3 * H, device=DEV)
+    dq = ops.attn_bwd(qkv, mask, ctx, dctx, lse, B, L, nh, D, p, seed, 3, impl=2, dbias=db)
+    dq_i = ops.attn_bwd(qkv_i, mask, ctx, dctx, lse, B, L, nh, D, p, seed, 3, impl=2, dbias=db_i, ilv=True)
+    assert torch.equal(dq[:, perm], dq_i)
+    assert rel_err(db_i, db) < 1e-6
+
+
+def test_qkv_interleave_batch_and_permuting_splitk_reduce():
+    """uc2_qkv_interleave_batch (row-permuted bf16 copies of [Wq; Wk; Wv] + fp32 biases, several blocks in one launch) against
+    index_select, and uc2_gemm_splitk_reduce_qkv (a weight gradient whose rows come out interleaved is added to the arena in
+    reference order) against the plain GEMM on un-permuted operands: bit-identical"""
+    import ctypes
+    from uc2_amd import _lib
+    nh, D, cols, nblk = 12, 64, 768, 3
+    H3 = 3 * nh * D
+    perm = _ilv_perm(nh, D, DEV)
+    wsrc = rnd((nblk * H3 + 5 * 64, cols), 1, dtype=torch.bfloat16)         # blocks at different offsets of one buffer
+    bsrc = rnd((nblk * H3 + 640,), 2)
+    wdst = torch.zeros((nblk * H3, cols), dtype=torch.bfloat16, device=DEV)
+    bdst = torch.zeros(nblk * H3, device=DEV)
+
+    class _Ilv(ctypes.Structure):
+        _fields_ = [("w_src", ctypes.c_size_t), ("w_dst", ctypes.c_size_t), ("b_src", ctypes.c_size_t), ("b_dst", ctypes.c_size_t)]
+    offs = [(i * H3 + 64 * i) for i in range(nblk)]
+    arr = (_Ilv * nblk)(*[_Ilv(o * cols, i * H3 * cols, o + 128, i * H3) for i, o in enumerate(offs)])
+    _lib.call("uc2_qkv_interleave_batch", nblk, arr, nh, D, cols, wsrc.data_ptr(), wdst.data_ptr(), bsrc.data_ptr(), bdst.data_ptr(),
+              _lib.stream())
+    for i, o in enumerate(offs):
+        assert torch.equal(wdst[i * H3:(i + 1) * H3], wsrc[o:o + H3][perm])
+        assert torch.equal(bdst[i * H3:(i + 1) * H3], bsrc[o + 128:o + 128 + H3][perm])
+    # dW[3H, cols] += dY^T X with the columns of dY interleaved
+    M = 4096
+    dy = rnd((M, H3), 3, dtype=torch.bfloat16)
+    x = rnd((M, cols), 4, dtype=torch.bfloat16)
+    acc = rnd((H3, cols), 5)
+    ref = ops.gemm(dy, x, H3, cols, M, ta=True, tb=True, out=acc.clone(), accumulate=True, split_k=4, variant=12)
+    got = ops.gemm(dy[:, perm].contiguous(), x, H3, cols, M, ta=True, tb=True, out=acc.clone(), accumulate=True, split_k=4, variant=12,
+                   qkv_rows_d=D)
+    assert torch.equal(got, ref)
+
+
 def test_attention_bwd_work_queue_matches_static_partition():
     """uc2_attn_bwd_queued (N > 1: chunks of heads from an atomic counter, so that a launch sharing the chip with an all-reduce
     kernel does not wait a second round for workgroups placed late) against the static partition at the bench size (12 288

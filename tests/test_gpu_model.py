@@ -148,6 +148,56 @@ def test_bert_layer_backward_paths_at_bench_token_counts():
             assert rel_err(g[n], g_ref[n]) < 4e-3, n
 
 
+def test_bert_layer_interleaved_qkv_route_is_bit_identical():
+    """ops.QKV_INTERLEAVED (from 16 384 tokens): the QKV GEMM on the row-permuted weight copy, attention on head-interleaved q|k|v,
+    dWqkv un-permuted by its split-K reduction, dX through W'^T -- same dot products in the same order as the plain layout: the
+    layer output and every parameter gradient bit-identical, dx up to the summation order of its contraction over the interleaved
+    index (base geometry, 176 x 96 tokens, dropout on, side stream on)"""
+    cfg = make_cfg(O.BASE, drop=0.1)
+    layer = BertLayer(cfg)
+    synth.det_init_(layer)
+    layer.to(DEV).train()
+    set_compute_dtype(layer, torch.bfloat16)
+    B, L, H = 176, 96, 768
+    x0 = (synth.det_normal((B, L, H), 3) * 0.5).to(DEV).to(torch.bfloat16)
+    ext = torch.zeros(B, 1, 1, L, device=DEV)
+    ext[::5, :, :, L - 11:] = -10000.0
+    dy = (synth.det_normal((B, L, H), 4) * 0.1).to(DEV).to(torch.bfloat16)
+
+    def run(on):
+        was, ops.QKV_INTERLEAVED = ops.QKV_INTERLEAVED, on
+        try:
+            layer.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            ops.rng.manual_seed(5)
+            y = layer(x, ext)
+            y.backward(dy)
+            ops.join_side_streams()
+            torch.cuda.synchronize()
+            return y.detach().clone(), x.grad.clone(), OrderedDict((n, p.grad.detach().clone()) for n, p in layer.named_parameters())
+        finally:
+            ops.QKV_INTERLEAVED = was
+    y0, dx0, g0 = run(False)
+    y1, dx1, g1 = run(True)
+    assert torch.equal(y1, y0)
+    # (dx = dqkv W contracts over the interleaved index: same products, another summation order -- bf16 rounding of the result)
+    assert rel_err(dx1.float(), dx0.float()) < 3e-3
+    for n in g0:
+        if n.endswith("bias") or "LayerNorm" in n:
+            assert rel_err(g1[n], g0[n]) < 1e-5 or g0[n].norm() < 1e-6, n      # (column sums added up with fp32 atomics: order varies run to run)
+        else:
+            assert torch.equal(g1[n], g0[n]), n                                # weight gradients: bit-identical
+    with torch.no_grad():                                                       # forward-only route (scoring / validation)
+        layer.eval()
+        a = layer(x0, ext)
+        was, ops.QKV_INTERLEAVED = ops.QKV_INTERLEAVED, False
+        try:
+            b = layer(x0, ext)
+        finally:
+            ops.QKV_INTERLEAVED = was
+        assert torch.equal(a, b)
+
+
 def test_embedding_dropout_sits_after_layernorm():
     """training mode, p > 0: the reference computes dropout(LayerNorm(emb)) (model/model.py:331-333,361-363), so every
     embedding output element is 0 or eval_output / (1 - p)"""

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UC2_LIB_PATH") or os.path.join(_HERE, "libuc2_hip.so")      # (UC2_LIB_PATH: A/B of two builds on one box)
 _lib = None
-ABI_VERSION = 6          # include/uc2_hip.h; bumped whenever a signature changes
+ABI_VERSION = 7          # include/uc2_hip.h; bumped whenever a signature changes
 
 P, I, F, U64, I64, SZ = c_void_p, c_int, c_float, c_uint64, c_int64, c_size_t
 
@@ -51,6 +51,8 @@ SIGNATURES = {
     "uc2_gather_rows_fwd": (I, [I, I, I, I, I, P, P, P, P]),
     "uc2_gather_rows_bwd": (I, [I, I, I, I, I, P, P, P, P]),
     "uc2_transpose_batch": (I, [I, P, P, P, P]),
+    "uc2_qkv_interleave_batch": (I, [I, P, I, I, I, P, P, P, P, P]),
+    "uc2_gemm_splitk_reduce_qkv": (I, [I, I, P, I, I, I, P, SZ, I, P]),
     "uc2_gather_rows2_fwd": (I, [I, I, I, I, I, I, P, P, P, P, P]),
     "uc2_gather_rows2_bwd": (I, [I, I, I, I, I, I, P, P, P, P, P]),
     "uc2_collate_regions": (I, [I, I, I, I, P, P, P, P, P]),

@@ -11,6 +11,7 @@
 // per key, K,V or Q,dO staged in LDS as fp32).  They are the parity path for both dtypes and
 // the on-device checker for the MFMA kernels in attention_mfma.hip.
 #include "common.h"
+#define UC2_ATTN_QKV_INTERLEAVED 16        /* include/uc2_hip.h: OR-ed into `impl` */
 
 #define AT_PAD 4
 
@@ -312,32 +313,38 @@ extern "C" int uc2_attn_bwd_simple(int dtype, int B, int L, int nh, int D, const
 // ---- public dispatch: impl 0 = auto, 1 = simple (fp32 math), 2 = MFMA (bf16 only) ----
 extern "C" int uc2_attn_fwd_mfma(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
                                  float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse,
-                                 void* stream);
+                                 int ilv, void* stream);
 extern "C" int uc2_attn_bwd_mfma(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
                                  float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx,
-                                 const void* dctx, const float* lse, void* dqkv, float* dbias, int* queue, void* stream);
+                                 const void* dctx, const float* lse, void* dqkv, float* dbias, int* queue, int ilv, void* stream);
 extern "C" int uc2_colsum_accum(int dtype, int M, int N, const void* X, int ldx, const uint8_t* rowmask, float* out, void* stream);
 extern "C" int uc2_attn_mfma_supported(int L, int D);
 
 extern "C" int uc2_attn_fwd(int dtype, int impl, int B, int L, int nh, int D, const void* qkv, const float* mask,
                             float scale, float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx,
                             float* lse, void* stream) {
+  const int ilv = (impl & UC2_ATTN_QKV_INTERLEAVED) ? 1 : 0;      // q|k|v of a head interleaved per token (MFMA kernels only)
+  impl &= ~UC2_ATTN_QKV_INTERLEAVED;
   UC2_CHECK_ARG(impl >= 0 && impl <= 2);
   const bool mfma = (impl == 2) || (impl == 0 && dtype == 1 && uc2_attn_mfma_supported(L, D));
+  UC2_CHECK_ARG(mfma || !ilv);
   if (mfma) {
     UC2_CHECK_ARG(dtype == 1 && uc2_attn_mfma_supported(L, D));
-    return uc2_attn_fwd_mfma(B, L, nh, D, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, lse, stream);
+    return uc2_attn_fwd_mfma(B, L, nh, D, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, lse, ilv, stream);
   }
   return uc2_attn_fwd_simple(dtype, B, L, nh, D, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, lse, stream);
 }
 extern "C" int uc2_attn_bwd_queued(int dtype, int impl, int B, int L, int nh, int D, const void* qkv, const float* mask,
                                    float scale, float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx,
                                    const void* dctx, const float* lse, void* dqkv, float* dbias_qkv, int* queue, void* stream) {
+  const int ilv = (impl & UC2_ATTN_QKV_INTERLEAVED) ? 1 : 0;
+  impl &= ~UC2_ATTN_QKV_INTERLEAVED;
   UC2_CHECK_ARG(impl >= 0 && impl <= 2);
   const bool mfma = (impl == 2) || (impl == 0 && dtype == 1 && uc2_attn_mfma_supported(L, D));
+  UC2_CHECK_ARG(mfma || !ilv);
   if (mfma) {
     UC2_CHECK_ARG(dtype == 1 && uc2_attn_mfma_supported(L, D));
-    return uc2_attn_bwd_mfma(B, L, nh, D, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv, dbias_qkv, queue, stream);
+    return uc2_attn_bwd_mfma(B, L, nh, D, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv, dbias_qkv, queue, ilv, stream);
   }
   const int rc = uc2_attn_bwd_simple(dtype, B, L, nh, D, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv,
                                      stream);

@@ -23,6 +23,12 @@
 
 #define AM_MAXW 5       // up to 160 positions
 #define AM_LOG2E 1.4426950408889634f
+// QKV layouts (runtime, `ilv`): 0 = [B L][3][nh][D] -- the fused projection's natural column order q | k | v, head h at column h D;
+// 1 = head-interleaved [B L][nh][3][D] -- one 384-byte segment per (token, head) at D = 64 instead of three 128-byte segments 1536
+// bytes apart (ops.BertLayerFn runs the QKV GEMM on a row-permuted copy of the weights; round 4: forward 144 -> 128 us at 12 288
+// heads).  AM_HS = offset of head h inside a row / h, AM_WS = offset of k (and half that of v) from q.
+#define AM_HS(D, H) (ilv ? 3 * (D) : (D))
+#define AM_WS(D, H) (ilv ? (D) : (H))
 #ifndef AM_BWD_EARLY
 #define AM_BWD_EARLY 2       // with AM_BWD_PREFETCH == 2: how many of the four tiles (Q, K, dO, O) are fetched early
 #endif
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
                                                                 uint32_t thresh, float keep_scale,
                                                                 const uint64_t* __restrict__ seed_ptr,
                                                                 uint64_t seed_imm, bf16* __restrict__ ctx,
-                                                                float* __restrict__ lse) {
+                                                                float* __restrict__ lse, int ilv) {
   constexpr int KS = D / 16, DB = D / 32, RS = D * 2 + 16, Lp = NW * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
   const int bh = blockIdx.x, b = bh / nh, head = bh - b * nh;
   const int H = nh * D, ld = 3 * H;
   const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
-  const bf16* base = qkv + (size_t)b * L * ld + head * D;
+  const bf16* base = qkv + (size_t)b * L * ld + head * AM_HS(D, H);
   const int tid = threadIdx.x;
   const int w = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
   const int q = 32 * w + c;
@@ -169,8 +175,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
       // loop costs eight dependent memory round trips per workgroup)
     constexpr int NCH = Lp * (D / 8) / (NW * 64);
     bf16x8 rk[NCH], rv[NCH];
-    load_tile_regs<D, NCH>(rk, base + H, ld, L, tid, NW * 64);
-    load_tile_regs<D, NCH>(rv, base + 2 * H, ld, L, tid, NW * 64);
+    load_tile_regs<D, NCH>(rk, base + AM_WS(D, H), ld, L, tid, NW * 64);
+    load_tile_regs<D, NCH>(rv, base + 2 * AM_WS(D, H), ld, L, tid, NW * 64);
     for (int k = tid; k < Lp; k += NW * 64) {
       Ms[k] = (k < L) ? (mask ? mask[(size_t)b * L + k] * AM_LOG2E : 0.f) : -1e30f;        // base-2 domain: p = exp2(s c2 + m' - max')
       Hk[k] = attn_line_hash(seed, bh, k, UC2_ATTN_SALT_K);
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
                                                                 const bf16* __restrict__ dctx,
                                                                 const float* __restrict__ lse,
                                                                 bf16* __restrict__ dqkv, float* __restrict__ dbias, int nbh, int hpw,
-                                                                int* __restrict__ queue) {
+                                                                int* __restrict__ queue, int ilv) {
   constexpr int KS = D / 16, DB = D / 32, RS = D * 2 + 16, Lp = NW * 32;
   constexpr int RSD = Lp * 2 + 16;                     // dS^T image: [key][query] bf16
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -308,22 +314,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
   //  loop, where they live -- and spill -- across the main loop)
   auto fetch_tiles = [&](int hd, int lo, int hi) __attribute__((always_inline)) {      // tiles lo .. hi-1 of (0 Q, 1 K, 2 dO, 3 O)
     const int fb = hd / nh, fh = hd - fb * nh;
-    const bf16* fbase = qkv + (size_t)fb * L * ld + fh * D;
+    const bf16* fbase = qkv + (size_t)fb * L * ld + fh * AM_HS(D, H);
     int t_ = tid;
     asm volatile("" : "+v"(t_));
     if (lo <= 0 && 0 < hi) load_tile_regs<D, NCH>(rq, fbase, ld, L, t_, NTHR);
-    if (lo <= 1 && 1 < hi) load_tile_regs<D, NCH>(rk, fbase + H, ld, L, t_, NTHR);
+    if (lo <= 1 && 1 < hi) load_tile_regs<D, NCH>(rk, fbase + AM_WS(D, H), ld, L, t_, NTHR);
     if (lo <= 2 && 2 < hi) load_tile_regs<D, NCH>(rg, dctx + (size_t)fb * L * H + fh * D, H, L, t_, NTHR);
     if (lo <= 3 && 3 < hi) load_tile_regs<D, NCH>(ro, ctx + (size_t)fb * L * H + fh * D, H, L, t_, NTHR);
   };
   auto fetch_rest = [&](int hd) __attribute__((always_inline)) {                       // V fragments, mask / lse of row tid
     const int fb = hd / nh, fh = hd - fb * nh;
-    const bf16* fbase = qkv + (size_t)fb * L * ld + fh * D;
+    const bf16* fbase = qkv + (size_t)fb * L * ld + fh * AM_HS(D, H);
     int r0_ = r0;
     asm volatile("" : "+v"(r0_));
 #pragma unroll
     for (int s = 0; s < KS; ++s)
-      rvf[s] = (r0 < L) ? *reinterpret_cast<const bf16x8*>(fbase + 2 * H + (size_t)r0_ * ld + 16 * s + 8 * h) : zero8();
+      rvf[s] = (r0 < L) ? *reinterpret_cast<const bf16x8*>(fbase + 2 * AM_WS(D, H) + (size_t)r0_ * ld + 16 * s + 8 * h) : zero8();
     if (tid < Lp && tid < L) {
       rmask = mask ? mask[(size_t)fb * L + tid] : 0.f;
       rlse = lse[(size_t)hd * L + tid];
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
   if (AM_BWD_PREFETCH == 2 && bh < bh_end) fetch_tiles(bh, 0, AM_BWD_EARLY);      // (only the early tiles are carried around the loop)
   for (; bh < bh_end; ++bh) {
   const int b = bh / nh, head = bh - b * nh;
-  bf16* dbase = dqkv + (size_t)b * L * ld + head * D;
+  bf16* dbase = dqkv + (size_t)b * L * ld + head * AM_HS(D, H);
   if (!AM_BWD_PREFETCH) fetch(bh);                     // no register prefetch: the CU's other workgroup covers the latency
   if (AM_BWD_PREFETCH == 2) { fetch_tiles(bh, AM_BWD_EARLY, 4); fetch_rest(bh); }     // what the dQ phase of the previous head did not fetch
   // ---- registers -> LDS (the previous head's readers are past the barrier at the end of the loop body)
@@ -429,8 +435,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
     }
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
-      store_acc_block(dbase + (size_t)r0 * ld + H + 32 * db, dk[db], 1.0f, h, r0 < L);
-      store_acc_block(dbase + (size_t)r0 * ld + 2 * H + 32 * db, dv[db], 1.0f, h, r0 < L);
+      store_acc_block(dbase + (size_t)r0 * ld + AM_WS(D, H) + 32 * db, dk[db], 1.0f, h, r0 < L);
+      store_acc_block(dbase + (size_t)r0 * ld + 2 * AM_WS(D, H) + 32 * db, dv[db], 1.0f, h, r0 < L);
     }
   }
   __syncthreads();                                     // every wave's dS^T columns are in LDS
@@ -480,18 +486,18 @@ extern "C" int uc2_attn_mfma_supported(int L, int D) { return (D == 32 || D == 6
 
 template <int D, int NW>
 static int launch_fwd(int B, int L, int nh, const void* qkv, const float* mask, float scale, float drop_p,
-                      const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse, hipStream_t st) {
+                      const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse, int ilv, hipStream_t st) {
   constexpr int RS = D * 2 + 16, Lp = NW * 32;
   const size_t smem = 2 * Lp * RS + 2 * Lp * sizeof(float);
   hipLaunchKernelGGL((attn_fwd_mfma_kernel<D, NW>), dim3(B * nh), dim3(NW * 64), smem, st, L, nh, (const bf16*)qkv, mask,
-                     scale, drop_thresh(drop_p), 1.0f / (1.0f - drop_p), seed_ptr, seed_imm, (bf16*)ctx, lse);
+                     scale, drop_thresh(drop_p), 1.0f / (1.0f - drop_p), seed_ptr, seed_imm, (bf16*)ctx, lse, ilv);
   UC2_LAUNCH_CHECK();
   return 0;
 }
 template <int D, int NW>
 static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, float scale, float drop_p,
                       const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx, const void* dctx,
-                      const float* lse, void* dqkv, float* dbias, int* queue, hipStream_t st) {
+                      const float* lse, void* dqkv, float* dbias, int* queue, int ilv, hipStream_t st) {
   constexpr int RS = D * 2 + 16, Lp = NW * 32, RSD = Lp * 2 + 16;
   const size_t smem = 3 * Lp * RS + Lp * RSD + 5 * Lp * sizeof(float) + 16 + (dbias ? 3 * (size_t)nh * D * sizeof(float) : 0);
   auto kern = attn_bwd_mfma_kernel<D, NW>;
@@ -522,7 +528,7 @@ static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, 
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, L, nh, (const bf16*)qkv, mask, scale,
                      drop_thresh(drop_p), 1.0f / (1.0f - drop_p), seed_ptr, seed_imm, (const bf16*)ctx,
-                     (const bf16*)dctx, lse, (bf16*)dqkv, dbias, nbh, hpw, queue);
+                     (const bf16*)dctx, lse, (bf16*)dqkv, dbias, nbh, hpw, queue, ilv);
   UC2_LAUNCH_CHECK();
   return 0;
 }
@@ -551,24 +557,24 @@ static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, 
 
 extern "C" int uc2_attn_fwd_mfma(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
                                  float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse,
-                                 void* stream) {
+                                 int ilv, void* stream) {
   UC2_CHECK_ARG(uc2_attn_mfma_supported(L, D));
   UC2_CHECK_ARG(B >= 0 && nh >= 1 && drop_p >= 0.f && drop_p < 1.f);
   UC2_CHECK_ARG(((nh * D) % 8) == 0);
   if (B == 0) return 0;
   UC2_CHECK_ARG(qkv && ctx);
   hipStream_t st = (hipStream_t)stream;
-  AM_DISPATCH(launch_fwd, B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, lse, st);
+  AM_DISPATCH(launch_fwd, B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, lse, ilv, st);
 }
 
 extern "C" int uc2_attn_bwd_mfma(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
                                  float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx,
-                                 const void* dctx, const float* lse, void* dqkv, float* dbias, int* queue, void* stream) {
+                                 const void* dctx, const float* lse, void* dqkv, float* dbias, int* queue, int ilv, void* stream) {
   UC2_CHECK_ARG(uc2_attn_mfma_supported(L, D));
   UC2_CHECK_ARG(B >= 0 && nh >= 1 && drop_p >= 0.f && drop_p < 1.f);
   UC2_CHECK_ARG(((nh * D) % 8) == 0);
   if (B == 0) return 0;
   UC2_CHECK_ARG(qkv && ctx && dctx && lse && dqkv);
   hipStream_t st = (hipStream_t)stream;
-  AM_DISPATCH(launch_bwd, B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv, dbias, queue, st);
+  AM_DISPATCH(launch_bwd, B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv, dbias, queue, ilv, st);
 }

@@ -910,6 +910,48 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(TrBatch b, const b
     *reinterpret_cast<bf16x4*>(d + (size_t)col * b.rows[i] + tx * 4) = v;
   }
 }
+// Head-interleaved copies of fused QKV projections: for every item a bf16 weight block [3 nh D, cols] (rows q | k | v, head h at
+// row h D of each third) and its fp32 bias [3 nh D] are copied with row w nh D + h D + d -> row h 3D + w D + d.  A GEMM on the copy
+// writes a head's q | k | v as ONE 384-byte segment per token (D = 64) instead of three 128-byte segments 1536 bytes apart -- the
+// attention kernels' only access pattern (4.2 -> 4.7 TB/s forward).  One launch for all layers, once per optimizer step.
+#define UC2_ILV_MAX 64
+struct IlvBatch { int n, nh, D, cols; unsigned long long w_src[UC2_ILV_MAX], w_dst[UC2_ILV_MAX], b_src[UC2_ILV_MAX], b_dst[UC2_ILV_MAX]; };
+__global__ __launch_bounds__(256) void qkv_interleave_kernel(IlvBatch b, const bf16* __restrict__ wsrc, bf16* __restrict__ wdst,
+                                                             const float* __restrict__ bsrc, float* __restrict__ bdst) {
+  const int item = blockIdx.y, rows = 3 * b.nh * b.D, cpr = b.cols / 8;       // 16-byte chunks per row
+  const bf16* s = wsrc + b.w_src[item];
+  bf16* d = wdst + b.w_dst[item];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * cpr; i += gridDim.x * blockDim.x) {
+    const int r = i / cpr, c = i - r * cpr;                                  // destination row r = h 3D + w D + dd
+    const int h = r / (3 * b.D), rr = r - h * 3 * b.D, w = rr / b.D, dd = rr - w * b.D;
+    const int sr = w * b.nh * b.D + h * b.D + dd;
+    *reinterpret_cast<bf16x8*>(d + (size_t)r * b.cols + c * 8) = *reinterpret_cast<const bf16x8*>(s + (size_t)sr * b.cols + c * 8);
+    if (c == 0 && bsrc) bdst[b.b_dst[item] + r] = bsrc[b.b_src[item] + sr];
+  }
+}
+struct Uc2IlvItem { size_t w_src, w_dst, b_src, b_dst; };            // mirrors include/uc2_hip.h (element offsets)
+extern "C" int uc2_qkv_interleave_batch(int n, const Uc2IlvItem* items, int nh, int D, int cols, const void* w_src_base,
+                                        void* w_dst_base, const float* b_src_base, float* b_dst_base, void* stream) {
+  UC2_CHECK_ARG(n >= 0 && (n == 0 || items));
+  if (n == 0) return 0;
+  UC2_CHECK_ARG(nh > 0 && D > 0 && cols > 0 && (cols % 8) == 0 && w_src_base && w_dst_base && w_src_base != w_dst_base);
+  UC2_CHECK_ARG((b_src_base == nullptr) == (b_dst_base == nullptr));
+  for (int i0 = 0; i0 < n; i0 += UC2_ILV_MAX) {
+    IlvBatch b{};
+    b.n = n - i0 < UC2_ILV_MAX ? n - i0 : UC2_ILV_MAX; b.nh = nh; b.D = D; b.cols = cols;
+    for (int k = 0; k < b.n; ++k) {
+      const Uc2IlvItem& it = items[i0 + k];
+      UC2_CHECK_ARG((it.w_src % 8) == 0 && (it.w_dst % 8) == 0);
+      b.w_src[k] = it.w_src; b.w_dst[k] = it.w_dst; b.b_src[k] = it.b_src; b.b_dst[k] = it.b_dst;
+    }
+    const int work = 3 * nh * D * (cols / 8);
+    hipLaunchKernelGGL(qkv_interleave_kernel, dim3((work + 255) / 256 < 512 ? (work + 255) / 256 : 512, b.n), dim3(256), 0,
+                       (hipStream_t)stream, b, (const bf16*)w_src_base, (bf16*)w_dst_base, b_src_base, b_dst_base);
+  }
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
 struct Uc2TransposeItem { size_t offset; int rows, cols; };        // mirrors include/uc2_hip.h
 extern "C" int uc2_transpose_batch(int n, const Uc2TransposeItem* items, const void* src_base, void* dst_base, void* stream) {
   UC2_CHECK_ARG(n >= 0 && (n == 0 || items));

@@ -269,8 +269,11 @@ extern "C" int uc2_colsum_accum(int dtype, int M, int N, const void* X, int ldx,
 // weight-gradient items store their fp32 partial tiles with plain stores and uc2_splitk_reduce adds them into C --
 // no atomics, so the result is bit-reproducible, and 64 MB of partials cost ~25 us instead of ~50 us of fp32 atomics.
 
+// qkv_d > 0: the partial rows are in the head-interleaved q|k|v order of the fused QKV projection (row h 3D + w D + d, D = qkv_d;
+// ops.BertLayerFn writes its QKV activations / gradients that way for the attention kernels' sake) and go to row w M/3 + h D + d of C,
+// the order of the parameter arena
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int ldc, int split, const float* __restrict__ ws,
-                                                            float* __restrict__ C, int accumulate) {
+                                                            float* __restrict__ C, int accumulate, int qkv_d) {
   const size_t mn4 = (size_t)M * N / 4;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < mn4; i += (size_t)gridDim.x * blockDim.x) {
     float4 a = reinterpret_cast<const float4*>(ws)[i];
@@ -278,7 +281,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int ld
       const float4 b = reinterpret_cast<const float4*>(ws + (size_t)z * M * N)[i];
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
-    const size_t e = i * 4, m = e / N, n = e - m * N;
+    const size_t e = i * 4;
+    size_t m = e / N;
+    const size_t n = e - m * N;
+    if (qkv_d > 0) {
+      const size_t hh = m / (3 * (size_t)qkv_d), r = m - hh * 3 * qkv_d, w = r / qkv_d, d = r - w * qkv_d;
+      m = w * (size_t)(M / 3) + hh * qkv_d + d;
+    }
     float4* c = reinterpret_cast<float4*>(C + m * ldc + n);
     if (accumulate) { const float4 o = *c; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
     *c = a;
@@ -288,7 +297,7 @@ void uc2_splitk_reduce(const GemmArgs& p, hipStream_t st) {        // called by 
   const size_t mn4 = (size_t)p.M * p.N / 4;
   const int blocks = (int)((mn4 + 255) / 256 < 2048 ? (mn4 + 255) / 256 : 2048);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.M, p.N, p.ldc, p.split_k, p.partial,
-                     reinterpret_cast<float*>(p.C), p.accumulate);
+                     reinterpret_cast<float*>(p.C), p.accumulate, 0);
 }
 // second stage on its own (after a uc2_gemm issued with UC2_GEMM_DEFER_REDUCE): C (=|+=) sum_z workspace[z]
 extern "C" int uc2_gemm_splitk_reduce(int M, int N, void* C, int ldc, int split_k, int accumulate, const void* workspace,
@@ -299,6 +308,20 @@ extern "C" int uc2_gemm_splitk_reduce(int M, int N, void* C, int ldc, int split_
   p.M = M; p.N = N; p.C = C; p.ldc = ldc; p.split_k = split_k; p.accumulate = accumulate;
   p.partial = reinterpret_cast<float*>(const_cast<void*>(workspace));
   uc2_splitk_reduce(p, (hipStream_t)stream);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+// the same with the rows of the partial tiles in the head-interleaved q|k|v order (see splitk_reduce_kernel); M = 3 nh qkv_head_dim
+extern "C" int uc2_gemm_splitk_reduce_qkv(int M, int N, void* C, int ldc, int split_k, int accumulate, const void* workspace,
+                                          size_t workspace_bytes, int qkv_head_dim, void* stream) {
+  UC2_CHECK_ARG(C && workspace && (size_t)split_k * M * N * sizeof(float) <= workspace_bytes);
+  UC2_CHECK_ARG((N & 3) == 0 && (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 && ((uintptr_t)workspace & 15) == 0);
+  UC2_CHECK_ARG(qkv_head_dim > 0 && M % (3 * qkv_head_dim) == 0);
+  const size_t mn4 = (size_t)M * N / 4;
+  const int blocks = (int)((mn4 + 255) / 256 < 2048 ? (mn4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, M, N, ldc, split_k,
+                     reinterpret_cast<const float*>(workspace), reinterpret_cast<float*>(C), accumulate, qkv_head_dim);
   UC2_LAUNCH_CHECK();
   return 0;
 }

@@ -213,7 +213,8 @@ def _gemm_queue(device):
 
 
 def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=None, epi=EPI_NONE,
-         aux_in=None, aux_out=None, accumulate=False, split_k=1, lda=None, ldb=None, ldc=None, variant=None, flags=0):
+         aux_in=None, aux_out=None, accumulate=False, split_k=1, lda=None, ldb=None, ldc=None, variant=None, flags=0,
+         qkv_rows_d=0):
     """C[M,N] (=|+=) epi(sum_k A(m,k) B(n,k) + bias[n]); see uc2_amd/csrc/gemm.hip.
     variant: kernel to use for THIS call (None = the library's default for the shape); the plan travels with the
     call, the library holds no kernel-selection state."""
@@ -247,7 +248,11 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
         e0.record()                # on torch's current stream == the stream the kernel is launched on
     else:
         e0 = None
-    defer = two_stage and e0 is not None         # time the GEMM kernel alone: run the reduction pass separately
+    # qkv_rows_d = D > 0: a weight gradient whose rows come out in the head-interleaved q|k|v order (dW = dqkv^T x with interleaved
+    # dqkv): the reduction pass puts them back into the parameter arena's order (uc2_gemm_splitk_reduce_qkv); two-stage only
+    if qkv_rows_d and not two_stage:
+        raise _lib.Uc2Error("qkv_rows_d needs the two-stage split-K path (variant 8 / 12, fp32 output, split_k > 1)")
+    defer = two_stage and (e0 is not None or qkv_rows_d > 0)         # (timing: the GEMM kernel alone, the reduction pass separately)
     if defer:
         flags |= GEMM_DEFER_REDUCE
     if GEMM_QUEUE and dtype == torch.bfloat16:
@@ -260,8 +265,12 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
              ptr(ws), 0 if ws is None else ws.numel(), flags, stream())
     if e0 is not None:
         e1.record()
-        if defer:
+    if defer:
+        if qkv_rows_d:
+            call("uc2_gemm_splitk_reduce_qkv", M, N, ptr(out), ldc, split_k, int(accumulate), ptr(ws), ws.numel(), int(qkv_rows_d), stream())
+        else:
             call("uc2_gemm_splitk_reduce", M, N, ptr(out), ldc, split_k, int(accumulate), ptr(ws), ws.numel(), stream())
+    if e0 is not None:
         if variant in (8, 9, 12):  # ping-pong kernels: transposed accumulators unless fp32 atomics; the epilogue kind is a template argument
             epi_t = int(epi) + 4 if (flags & GEMM_AUX_DERIV and epi in (EPI_GELU, EPI_DGELU)) else int(epi)   # EPI_GELU_D = 5, EPI_MUL = 6
             key = (bool(ta), bool(tb), variant, bool(c_f32 and not two_stage), epi_t)
@@ -793,26 +802,32 @@ def ln_bwd(dy2, x2, res2, gamma, mean, rstd, dgamma, dbeta, drop_p=0.0, seed=Non
     return dx, (dres if dres is not None else dx)
 
 
-def attn_fwd(qkv, mask2d, B, L, nh, D, drop_p=0.0, seed=None, seed_imm=0, impl=None, want_lse=True):
+ATTN_QKV_INTERLEAVED = 16          # include/uc2_hip.h UC2_ATTN_QKV_INTERLEAVED, OR-ed into `impl`
+
+
+def attn_fwd(qkv, mask2d, B, L, nh, D, drop_p=0.0, seed=None, seed_imm=0, impl=None, want_lse=True, ilv=False):
+    """ilv: qkv is [B L, nh, 3, D] (q|k|v of a head adjacent per token) instead of [B L, 3, nh, D]"""
     H = nh * D
     ctx = torch.empty((B * L, H), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, nh, L), dtype=torch.float32, device=qkv.device) if want_lse else None
     with _Timed("attn_fwd", B * L * H * qkv.element_size() * 4 + B * nh * L * 4):       # q,k,v in; ctx, lse out
-        call("uc2_attn_fwd", dt(qkv.dtype), ATTN_IMPL if impl is None else impl, B, L, nh, D, ptr(qkv), ptr(mask2d),
+        call("uc2_attn_fwd", dt(qkv.dtype), (ATTN_IMPL if impl is None else impl) | (ATTN_QKV_INTERLEAVED if ilv else 0), B, L, nh, D, ptr(qkv), ptr(mask2d),
              1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(lse), stream())
     return ctx, lse
 
 
-def attn_bwd(qkv, mask2d, ctx, dctx, lse, B, L, nh, D, drop_p=0.0, seed=None, seed_imm=0, impl=None, dbias=None):
-    """dqkv; with dbias (fp32 [3H]) also dbias += column sums of dqkv = the gradient of the fused q|k|v bias"""
+def attn_bwd(qkv, mask2d, ctx, dctx, lse, B, L, nh, D, drop_p=0.0, seed=None, seed_imm=0, impl=None, dbias=None, ilv=False):
+    """dqkv; with dbias (fp32 [3H]) also dbias += column sums of dqkv = the gradient of the fused q|k|v bias (always in the
+    reference order q | k | v).  ilv: qkv and dqkv are in the head-interleaved layout (see attn_fwd)"""
     dqkv = torch.empty_like(qkv)
+    impl = (ATTN_IMPL if impl is None else impl) | (ATTN_QKV_INTERLEAVED if ilv else 0)
     with _Timed("attn_bwd", B * L * nh * D * qkv.element_size() * 8 + B * nh * L * 4):   # qkv, ctx, dctx, lse in; dqkv out
         if GEMM_QUEUE and qkv.dtype == torch.bfloat16:       # N > 1: the persistent kernels share the chip with the all-reduce kernels
-            call("uc2_attn_bwd_queued", dt(qkv.dtype), ATTN_IMPL if impl is None else impl, B, L, nh, D, ptr(qkv), ptr(mask2d),
+            call("uc2_attn_bwd_queued", dt(qkv.dtype), impl, B, L, nh, D, ptr(qkv), ptr(mask2d),
                  1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(dbias),
                  ptr(_gemm_queue(qkv.device)[12:14]), stream())
         else:
-            call("uc2_attn_bwd", dt(qkv.dtype), ATTN_IMPL if impl is None else impl, B, L, nh, D, ptr(qkv), ptr(mask2d),
+            call("uc2_attn_bwd", dt(qkv.dtype), impl, B, L, nh, D, ptr(qkv), ptr(mask2d),
                  1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(dbias), stream())
     return dqkv
 
@@ -854,6 +869,28 @@ def layer_params(layer):
             it.dense.weight, it.dense.bias, o.dense.weight, o.dense.bias, o.LayerNorm.weight, o.LayerNorm.bias)
 
 
+QKV_INTERLEAVED = os.environ.get("UC2_QKV_ILV", "1") != "0"     # head-interleaved q|k|v activations from QKV_ILV_MIN_ROWS tokens
+QKV_ILV_MIN_ROWS = 16384
+
+
+def _ilv_wgrad_plan(n_out, n_in, rows, device):
+    """(variant, split_k) of the two-stage ping-pong weight-gradient GEMM dW[n_out, n_in] += dY^T X over `rows` tokens, or None if
+    that kernel cannot take the shape.  The interleaved route needs this path: its reduction pass is what puts the rows of dWqkv
+    back into the parameter arena's order."""
+    key = (True, True, n_out, n_in, rows, True)
+    v, sp = gemm_plan(torch.bfloat16, True, True, n_out, n_in, rows, True)
+    if v in (8, 12) and sp > 1 and _plan_fits((v, sp), key):
+        return v, sp
+    tiles = (n_out // 256) * (n_in // 256)
+    if n_out % 256 or n_in % 256 or tiles == 0:
+        return None
+    valid = [s_ for s_ in range(2, 129) if s_ * 256 <= rows and _plan_fits((12, s_), key)]
+    if not valid:
+        return None
+    cus = _num_cus(device)
+    return 12, min(valid, key=lambda s_: (abs(tiles * s_ - cus), s_))
+
+
 class BertLayerFn(torch.autograd.Function):
     """x -> LN(x + Wo.Attn(x)) -> LN(a + W2.gelu(W1.a)).  10 kernel launches forward, 21 backward.
     Weight/bias/LN gradients are accumulated by the kernels directly into the fp32 gradient arena
@@ -882,11 +919,25 @@ class BertLayerFn(torch.autograd.Function):
 
         wqkv = st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype)
         bqkv = st.span(st.data, P["qb"], P["vb"], (3 * H,))
+        # Head-interleaved q|k|v (round 4): the QKV GEMM runs on a row-permuted copy of [Wq; Wk; Wv] (store.qkv_interleaved), so a
+        # head's q | k | v is ONE 384-byte segment per token instead of three 128-byte segments 1536 bytes apart -- the attention
+        # kernels' access pattern is what bounds them (forward 4.2 -> 4.7 TB/s).  Same dot products in the same order: qkv, dqkv,
+        # ctx and every gradient are bit-identical to the plain layout.  Needs the MFMA attention kernels and, for the backward,
+        # the two-stage ping-pong weight-gradient GEMM (its reduction pass un-permutes the rows of dWqkv).
+        ilv = None
+        if (QKV_INTERLEAVED and dtype == torch.bfloat16 and M >= QKV_ILV_MIN_ROWS and M % 128 == 0 and not cfg.get("fp8")
+                and ATTN_IMPL in (0, 2) and D in (32, 64) and _lib.load().uc2_attn_mfma_supported(L, D)
+                and not torch.cuda.is_current_stream_capturing()):
+            plan = _ilv_wgrad_plan(3 * H, H, M, x.device) if any(ctx.needs_input_grad) or training else (12, 2)
+            pack = st.qkv_interleaved(P["qw"], P["vw"], P["qb"], nh) if plan is not None else None
+            if pack is not None:
+                ilv = (pack, plan)
+                wqkv, bqkv = pack[0], pack[2]
         if not any(ctx.needs_input_grad):
             # forward-only (retrieval scoring, validation, the hard-negative scoring pass): nothing is kept for a
             # backward -- no gelu' stream out of the FFN1 GEMM, no LayerNorm statistics, no log-sum-exp
             qkv = linear_fwd(x2, wqkv, bqkv)
-            ctxv, _ = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn, want_lse=False)
+            ctxv, _ = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn, want_lse=False, ilv=ilv is not None)
             del qkv
             o1 = linear_fwd(ctxv, st.compute(P["ow"], dtype), P["ob"].data)
             a, _, _ = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, s_ln1, want_stats=False)
@@ -909,7 +960,7 @@ class BertLayerFn(torch.autograd.Function):
             o2 = linear_fwd_fp8(u, st, P["fw"], P["fw"], (H, I_), P["fb"].data)
         else:
             qkv = linear_fwd(x2, wqkv, bqkv)
-            ctxv, lse = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn)
+            ctxv, lse = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn, ilv=ilv is not None)
             o1 = linear_fwd(ctxv, st.compute(P["ow"], dtype), P["ob"].data)
             a, mean1, rstd1 = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, s_ln1)
             # `pre` holds gelu'(a W1^T + b1), not the pre-activation itself (UC2_GEMM_AUX_DERIV): one more exp2 beside
@@ -921,6 +972,7 @@ class BertLayerFn(torch.autograd.Function):
         ctx.save_for_backward(x2, mask2d, qkv, ctxv, lse, o1, mean1, rstd1, a, pre, u, o2, mean2, rstd2, seed)
         ctx.layer, ctx.cfg, ctx.shape, ctx.p = layer, cfg, (B, L, H, nh, D), (p_h, p_a, (s_attn, s_ln1, s_ln2))
         ctx.params, ctx.fp8 = params, fp8
+        ctx.ilv_plan = ilv[1] if ilv is not None else None
         return y.view(B, L, H)
 
     @staticmethod
@@ -970,15 +1022,33 @@ class BertLayerFn(torch.autograd.Function):
         # d(q|k|v bias) comes out of attn_bwd: column sums of the dQ/dK/dV accumulators, added up per workgroup in LDS and
         # flushed with one global atomic per column and workgroup (the separate column-sum pass re-read dqkv: 97 us)
         # (the fp32-math kernels run the column-sum pass inside uc2_attn_bwd)
-        dqkv = attn_bwd(qkv, mask2d, ctxv, dctx, lse, B, L, nh, D, p_a, seed, s_attn, dbias=dbqkv)
-        wgrad(dqkv, x2, dwqkv)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            if fp8:
-                dx = linear_dgrad_fp8(dqkv, st, P["qw"], P["vw"], (3 * H, H), EPI_ADD, dz1).view(B, L, H)
+        ilv_plan = ctx.ilv_plan
+        dqkv = attn_bwd(qkv, mask2d, ctxv, dctx, lse, B, L, nh, D, p_a, seed, s_attn, dbias=dbqkv, ilv=ilv_plan is not None)
+        if ilv_plan is not None:
+            # dqkv is head-interleaved: dWqkv comes out with its rows in that order, the split-K reduction puts them back
+            # (dqkv^T x on the two-stage ping-pong kernel: _ilv_wgrad_plan); the input gradient contracts over the interleaved
+            # index on both operands (W' / W'^T)
+            v_, sp_ = ilv_plan
+            w_ilv, wt_ilv, _ = st.qkv_interleaved(P["qw"], P["vw"], P["qb"], nh)
+
+            def _wg():
+                gemm(dqkv, x2, 3 * H, H, M, ta=True, tb=True, out=dwqkv, accumulate=True, split_k=sp_, variant=v_, qkv_rows_d=D)
+            if _side_route(M):
+                _on_side_stream(dqkv.device, _wg, (dqkv, x2))
             else:
-                dx = linear_dgrad(dqkv, st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype), EPI_ADD, dz1,
-                                  wt=WT(P["qw"], P["vw"], (3 * H, H))).view(B, L, H)
+                _wg()
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = linear_dgrad(dqkv, w_ilv, EPI_ADD, dz1, wt=wt_ilv if use_wt else None).view(B, L, H)
+        else:
+            wgrad(dqkv, x2, dwqkv)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                if fp8:
+                    dx = linear_dgrad_fp8(dqkv, st, P["qw"], P["vw"], (3 * H, H), EPI_ADD, dz1).view(B, L, H)
+                else:
+                    dx = linear_dgrad(dqkv, st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype), EPI_ADD, dz1,
+                                      wt=WT(P["qw"], P["vw"], (3 * H, H))).view(B, L, H)
         if grouped:
             wgrad_group(grouped)
         hook = ctx.cfg.get("grad_ready_hook")

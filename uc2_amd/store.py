@@ -220,6 +220,51 @@ class ParamStore:
             self._t_version = self.version
         return self.shadow_t[o - self._t_lo:o - self._t_lo + rows * cols].view(cols, rows)
 
+    # ---- head-interleaved copies of the fused QKV projections (bf16 W, W^T; fp32 bias) ----
+    def qkv_interleaved(self, qw, vw, qb, nh, want_t=True):
+        """(W' [3H, H] bf16, W'^T [H, 3H] bf16 or None, b' [3H] fp32): the adjacent query | key | value weights and biases with
+        row w nh D + h D + d moved to row h 3D + w D + d.  The QKV GEMM on W' writes a head's q | k | v adjacent per token, which
+        is what the attention kernels want to read (uc2_amd/ops.py::BertLayerFn).  Copies of all registered blocks are refreshed
+        by one interleave launch + one transpose launch whenever the weights changed (once per optimizer step)."""
+        import ctypes
+        self.sync_shadow()
+        H3, cols = 3 * qw.shape[0], qw.shape[1]
+        D = qw.shape[0] // nh
+        if getattr(self, "_ilv_w", None) is None:
+            n = sum(1 for nm in self.names if nm.endswith("query.weight"))
+            self._ilv_shape = (H3, cols, nh, D)
+            self._ilv_w = torch.empty(max(n, 1) * H3 * cols, dtype=torch.bfloat16, device=self.device)
+            self._ilv_wt = torch.empty_like(self._ilv_w)
+            self._ilv_b = torch.empty(max(n, 1) * H3, dtype=torch.float32, device=self.device)
+            self._ilv_items, self._ilv_version = {}, -1
+        if self._ilv_shape != (H3, cols, nh, D):
+            return None
+        o = self.offsets[id(qw)]
+        new = o not in self._ilv_items
+        if new:
+            if len(self._ilv_items) * H3 * cols >= self._ilv_w.numel():
+                return None
+            self._ilv_items[o] = (len(self._ilv_items), self.offsets[id(qb)])
+        if self._ilv_version != self.version or new:
+            todo = list(self._ilv_items.items()) if self._ilv_version != self.version else [(o, self._ilv_items[o])]
+
+            class _Ilv(ctypes.Structure):
+                _fields_ = [("w_src", ctypes.c_size_t), ("w_dst", ctypes.c_size_t), ("b_src", ctypes.c_size_t), ("b_dst", ctypes.c_size_t)]
+
+            class _Tr(ctypes.Structure):
+                _fields_ = [("offset", ctypes.c_size_t), ("rows", ctypes.c_int), ("cols", ctypes.c_int)]
+            a1 = (_Ilv * len(todo))(*[_Ilv(wo, slot * H3 * cols, bo, slot * H3) for wo, (slot, bo) in todo])
+            _lib.call("uc2_qkv_interleave_batch", len(todo), a1, nh, D, cols, _lib.ptr(self.shadow), _lib.ptr(self._ilv_w),
+                      _lib.ptr(self.data), _lib.ptr(self._ilv_b), _lib.stream())
+            if H3 % 64 == 0 and cols % 64 == 0:
+                a2 = (_Tr * len(todo))(*[_Tr(slot * H3 * cols, H3, cols) for _, (slot, _) in todo])
+                _lib.call("uc2_transpose_batch", len(todo), a2, _lib.ptr(self._ilv_w), _lib.ptr(self._ilv_wt), _lib.stream())
+            self._ilv_version = self.version
+        slot = self._ilv_items[o][0]
+        w = self._ilv_w[slot * H3 * cols:(slot + 1) * H3 * cols].view(H3, cols)
+        wt = self._ilv_wt[slot * H3 * cols:(slot + 1) * H3 * cols].view(cols, H3) if (want_t and H3 % 64 == 0 and cols % 64 == 0) else None
+        return w, wt, self._ilv_b[slot * H3:(slot + 1) * H3]
+
     def prepare_t(self):
         """allocate the W^T arena: the slice of the parameter arena from the first to the last 2-D parameter of the encoder
         layers (names containing 'encoder.layer.' / 'layer.<i>.'; a bare BertLayer: all its 2-D parameters)"""
