@@ -29,6 +29,11 @@
 // heads).  AM_HS = offset of head h inside a row / h, AM_WS = offset of k (and half that of v) from q.
 #define AM_HS(D, H) (ilv ? 3 * (D) : (D))
 #define AM_WS(D, H) (ilv ? (D) : (H))
+#ifndef AM_LINE_STORES
+#define AM_LINE_STORES 0     // backward: 1 = dQ / dK / dV leave as whole 128-byte lines through LDS (0: 16-byte pieces of 32 rows per
+                             // instruction).  Measured (round 4, same box, bit-identical): 295.9 / 577.8 us with, 299.5 / 579.3 without at
+                             // 12 288 / 24 576 heads -- the store granularity is not what bounds the kernel; off
+#endif
 #ifndef AM_BWD_EARLY
 #define AM_BWD_EARLY 2       // with AM_BWD_PREFETCH == 2: how many of the four tiles (Q, K, dO, O) are fetched early
 #endif
@@ -97,6 +102,35 @@ __device__ __forceinline__ void store_acc_block(bf16* __restrict__ row_ptr, cons
       o[4 + e] = (bf16)__uint_as_float(sw[1]);
     }
     if (ok) *reinterpret_cast<bf16x8*>(row_ptr + 16 * k + 8 * h) = o;
+  }
+}
+// The same block set stored as WHOLE 128-byte lines (round 4): store_acc_block writes 16-byte pieces of 32 different rows per
+// wave-instruction, i.e. 64 partial-line requests -- the write pattern the GEMM epilogue got rid of in round 2 (+7..19 % there).
+// A wave's [32 rows x D] bf16 output goes through a wave-private LDS image (32 rows x 2 D bytes; 16-byte chunk q of row r at
+// r 2D + ((q ^ (r & (2D/16 - 1))) << 4), 8-byte pieces written with a 2-way bank conflict, read back conflict-free) and leaves in
+// the line layout: lane l owns chunk l % (D/8) of row l / (D/8) + (512/D) it -- D/8 lanes cover one row segment of 2 D bytes.
+// LDS executes a wave's operations in order, so the buffer is reused back to back without barriers.
+template <int D, int DB>
+__device__ __forceinline__ void store_acc_lines(bf16* __restrict__ gbase, size_t ld, int row0, int L, const f32x16 (&a)[DB],
+                                                char* __restrict__ tbuf, int lane) {
+  constexpr int RB = 2 * D, CPR = D / 8, RPI = 64 / CPR, NIT = 32 / RPI;      // bytes per row, chunks per row, rows per instruction
+  const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (bf16)a[db][4 * g + e];
+      const int q = 4 * db + g;                                               // 16-byte chunk of the row; this lane's half = h
+      *reinterpret_cast<bf16x4*>(tbuf + c * RB + ((q ^ (c & (CPR - 1))) << 4) + 8 * h) = v;
+    }
+  const int lr = lane / CPR, lc = lane % CPR;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int r = RPI * it + lr;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(tbuf + r * RB + ((lc ^ (r & (CPR - 1))) << 4));
+    if (row0 + r < L) *reinterpret_cast<bf16x8*>(gbase + (size_t)(row0 + r) * ld + 8 * lc) = v;
   }
 }
 // row of accumulator register i for lane half h
@@ -226,7 +260,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
         const int i = 4 * g + e;
         const float p = __builtin_amdgcn_exp2f(sc[kb][i] - mx);
         sum += p;
-        sc[kb][i] = kp[e] ? (thresh ? p * keep_scale : p) : 0.f;
+        sc[kb][i] = kp[e] ? p : 0.f;                     // (the 1 / (1 - p_drop) of the kept entries is folded into the output scale)
       }
     }
   sum += __shfl_xor(sum, 32);
@@ -244,7 +278,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
       for (int s = 0; s < 2; ++s)
         o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr(Vs, RS, 32 * kb + 16 * s, 32 * db, lane), pack8(sc[kb], s), o,
                                                     0, 0, 0);
-    store_acc_block(out + 32 * db, o, inv, h, q < L);
+    store_acc_block(out + 32 * db, o, thresh ? inv * keep_scale : inv, h, q < L);
   }
   if (lse && q < L && h == 0) lse[(size_t)bh * L + q] = (mx + __builtin_amdgcn_logf(sum)) * 0.69314718056f;     // natural-log lse
 }
@@ -433,13 +467,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
       acc_colsum_atomic<DB>(dk, r0 < L, Cs + H + head * D, lane);
       acc_colsum_atomic<DB>(dv, r0 < L, Cs + 2 * H + head * D, lane);
     }
+    if (!AM_LINE_STORES) {
 #pragma unroll
-    for (int db = 0; db < DB; ++db) {
-      store_acc_block(dbase + (size_t)r0 * ld + AM_WS(D, H) + 32 * db, dk[db], 1.0f, h, r0 < L);
-      store_acc_block(dbase + (size_t)r0 * ld + 2 * AM_WS(D, H) + 32 * db, dv[db], 1.0f, h, r0 < L);
+      for (int db = 0; db < DB; ++db) {
+        store_acc_block(dbase + (size_t)r0 * ld + AM_WS(D, H) + 32 * db, dk[db], 1.0f, h, r0 < L);
+        store_acc_block(dbase + (size_t)r0 * ld + 2 * AM_WS(D, H) + 32 * db, dv[db], 1.0f, h, r0 < L);
+      }
     }
   }
-  __syncthreads();                                     // every wave's dS^T columns are in LDS
+  __syncthreads();                                     // every wave's dS^T columns are in LDS (and Qs / Gs are dead)
+  if (AM_LINE_STORES) {                                // dK, dV as whole lines through this wave's slice of the dead Q tile
+    store_acc_lines<D, DB>(dbase + AM_WS(D, H), ld, 32 * w, L, dk, Qs + w * 32 * 2 * D, lane);
+    store_acc_lines<D, DB>(dbase + 2 * AM_WS(D, H), ld, 32 * w, L, dv, Qs + w * 32 * 2 * D, lane);
+  }
   // the next head's tiles: issued here, where dk / dv / the score tiles are dead (the prefetch then costs no register at the
   // kernel's peak); they are in flight during the dQ phase, its stores and the barrier, and the CU's other workgroup
   if (AM_BWD_PREFETCH == 2 && bh + 1 < bh_end) fetch_tiles(bh + 1, 0, AM_BWD_EARLY);
@@ -458,8 +498,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
         dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr(Ks, RS, 16 * ks, 32 * db, lane), bfrag, dq[db], 0, 0, 0);
     }
     if (dbias) acc_colsum_atomic<DB>(dq, r0 < L, Cs + head * D, lane);          // d(query bias)
+    if (AM_LINE_STORES) {
+      store_acc_lines<D, DB>(dbase, ld, 32 * w, L, dq, Gs + w * 32 * 2 * D, lane);
+    } else {
 #pragma unroll
-    for (int db = 0; db < DB; ++db) store_acc_block(dbase + (size_t)r0 * ld + 32 * db, dq[db], 1.0f, h, r0 < L);
+      for (int db = 0; db < DB; ++db) store_acc_block(dbase + (size_t)r0 * ld + 32 * db, dq[db], 1.0f, h, r0 < L);
+    }
   }
   __syncthreads();                                     // every wave is done with this head's LDS tiles
   }
