@@ -1119,7 +1119,8 @@ def test_wrong_count_hint_is_memory_safe_and_counted():
     l1, g1 = run(n + 5)
     assert l1.shape[0] == n + 5 and torch.equal(l1[:n], l0) and float(l1[n:].abs().sum()) == 0.0
     for k in g0:
-        assert torch.allclose(g1[k], g0[k], rtol=1e-5, atol=1e-7), k
+        # (fp32 atomics in the embedding / column-sum accumulations: the summation order varies from run to run)
+        assert rel_err(g1[k], g0[k]) < 1e-5 or float(g0[k].norm()) < 1e-9, k
     assert type(model).hint_mismatches() == base + 1
     l2, _ = run(n - 2)
     assert l2.shape[0] == n - 2 and torch.equal(l2, l0[:n - 2])
