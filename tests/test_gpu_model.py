@@ -1120,6 +1120,8 @@ def test_wrong_count_hint_is_memory_safe_and_counted():
     assert l1.shape[0] == n + 5 and torch.equal(l1[:n], l0) and float(l1[n:].abs().sum()) == 0.0
     for k in g0:
         # (fp32 atomics in the embedding / column-sum accumulations: the summation order varies from run to run)
+        if k.endswith("key.bias"):
+            continue                                    # mathematically zero (soft-max is shift invariant): rounding noise on both sides
         assert rel_err(g1[k], g0[k]) < 1e-5 or float(g0[k].norm()) < 1e-9, k
     assert type(model).hint_mismatches() == base + 1
     l2, _ = run(n - 2)
