@@ -690,6 +690,9 @@ def linear_wgrad(dy2, x2, dw, db):
 # each at ~10 k tokens = a single round on half of the 256 CUs): BertLayerFn.backward hands them to ONE launch of the persistent
 # ping-pong kernel (uc2_gemm_wgrad_group) at the end of the layer's backward.  104-pair micro-batch: 215 -> 136 us per layer.
 WGRAD_GROUP = os.environ.get("UC2_WGRAD_GROUP", "1") != "0"
+WGRAD_GROUP_SIDE = os.environ.get("UC2_GROUP_SIDE", "1") == "1"      # the grouped launch runs on the side stream (round 4, reference regime,
+                                                                     # same box x 3: 27.70-27.72 -> 27.11-27.27 ms per optimizer step, steady;
+                                                                     # round 3's per-GEMM side stream at this size was erratic)
 
 
 class _WgradItem(ctypes.Structure):             # include/uc2_hip.h: Uc2WgradItem
@@ -1050,7 +1053,13 @@ class BertLayerFn(torch.autograd.Function):
                     dx = linear_dgrad(dqkv, st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype), EPI_ADD, dz1,
                                       wt=WT(P["qw"], P["vw"], (3 * H, H))).view(B, L, H)
         if grouped:
-            wgrad_group(grouped)
+            if WGRAD_GROUP_SIDE and WGRAD_SIDE_STREAM and not torch.cuda.is_current_stream_capturing():
+                # the layer's grouped weight-gradient launch beside the next layer's backward (small token counts: the main chain's
+                # kernels leave CUs idle at their round tails and between launches)
+                trip = list(grouped)
+                _on_side_stream(dy2.device, lambda: wgrad_group(trip), [t for tr in trip for t in tr[:2]])
+            else:
+                wgrad_group(grouped)
         hook = ctx.cfg.get("grad_ready_hook")
         if hook is not None:
             # this layer's gradients are all enqueued: the main stream holds the bias / LayerNorm gradients, the side stream the
