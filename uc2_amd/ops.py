@@ -798,7 +798,7 @@ def ln_bwd(dy2, x2, res2, gamma, mean, rstd, dgamma, dbeta, drop_p=0.0, seed=Non
     def reduce():
         call("uc2_ln_bwd_reduce", d, M, H, ptr(ws), ptr(dgamma), ptr(dbeta), ptr(dbias), stream())
     if dgamma is not None or dbeta is not None or dbias is not None:
-        if LN_REDUCE_SIDE and _side_route(M):
+        if LN_REDUCE_SIDE and _side_route(M):      # (below WGRAD_SIDE_MIN_ROWS tokens it made the regime erratic: 27.0-30.8 ms against 27.0-27.1)
             _on_side_stream(x2.device, reduce, (ws,))
         else:
             reduce()
