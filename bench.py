@@ -478,11 +478,16 @@ def main():
     gtimer, htimer = ops.GemmTimer(), ops.HbmTimer()
     fence()
     ops.GEMM_TIMER, ops.HBM_TIMER = gtimer, htimer
+    ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = opt_step([batches[(a.warmup + i) % 2]], a.task)
     fence()
     dt = time.perf_counter() - t0
+    ms1 = torch.cuda.memory_stats(dev)
+    # device allocations (hipMalloc calls of the caching allocator) inside the timed region: 0 in a settled run
+    dev_allocs = int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0))
+    dev_alloc_mb = (ms1.get("reserved_bytes.all.peak", 0) - ms0.get("reserved_bytes.all.current", 0)) / 2 ** 20
     ops.GEMM_TIMER, ops.HBM_TIMER = None, None
     if world > 1:
         t = torch.tensor([dt], device=dev)
@@ -638,6 +643,7 @@ def main():
                        "seq_len": T_TXT + N_REG, "parallelism": "dp%d" % world, "final_loss": round(lossv, 4), "replicas_in_sync": in_sync,
                        "gradient_allreduce": comm_path, "rccl_ranks": rccl_ranks, "rccl_version": rccl_version,
                        "gemm_item_queue": bool(ops.GEMM_QUEUE),
+                       "device_allocations_in_timed_region": dev_allocs, "reserved_growth_in_timed_region_MB": round(dev_alloc_mb, 1),
                        "dgrad_routes": {"%dx%dx%d epi %d" % k: v for k, v in sorted(ops.DGRAD_ROUTES.items())},
                        "gemm_plans": {"%s%s %dx%dx%d" % ("T" if k[0] else "N", "T" if k[1] else "N", k[2], k[3], k[4]):
                                       "%s split %d" % ("generic" if v[0] == 99 else "ping-pong" if v[0] == 8 else "ping-pong 192" if v[0] == 9 else "ping-pong 16x16x32" if v[0] == 12 else "ring v%d" % v[0], v[1])
