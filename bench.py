@@ -16,7 +16,7 @@ Prints ONE JSON line on rank 0 (metric contract in the task description) with ex
   roofline      -- the dominant kernel (a bf16 MFMA GEMM instantiation) timed live with HIP events on its launch
                    stream over the timed steps, against the dense bf16 MFMA peak; `traffic` is carried from the
                    committed rocprofv3 PMC passes (profiles/), `hbm_kernels` are the HBM-bound kernels' GB/s
-  workloads     -- the same step on the MLM task and at the 1024 pairs per step of rounds 1-3; the reference's own regime:
+  workloads     -- the same step on the MLM task and at the 1024 / 2048 pairs per step of earlier rounds; the reference's own regime:
                    104-pair micro-batches x 3 accumulation micro-steps per optimizer step (config/uc2_pretrain.json:17-19), ITM
                    and MLM windows, the pretrain task mix itm:mlm:vmlm:tlm = 9:12:9:3 of BASELINE.json configs[2]
                    (config/uc2_pretrain.json:72-102) and one window each of the MRM heads (mrfr, mrc-kl); at N = 1 also the
@@ -50,10 +50,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=2048, help="pairs per GPU per step (round 4: 2048 -- 58 GB of saved activations of the "
-                                                            "288 GB; the optimizer pass, the split-K reductions and the tile-count "
-                                                            "quantisation of the N = 768 GEMMs are per step, not per pair: +4.5 %% over 1024 "
-                                                            "on one box; 4096 adds +1 %% more)")
+    ap.add_argument("--batch", type=int, default=6144, help="pairs per GPU per step.  Round 4: 6144 = 589 824 tokens, 187 GB of the 288 GB "
+                                                            "(30.7 GB of saved activations per 1024 pairs).  The optimizer pass over 280 M "
+                                                            "parameters, the split-K reductions, the weight copies and ~450 launch gaps are per "
+                                                            "step, not per pair (~5.6 ms): same box, 2048 / 3072 / 4096 / 6144 / 8192 pairs: "
+                                                            "0.369 / 0.373 / 0.378 / 0.382 / 0.329 of the bf16 peak (8192 = 267 GB reserved: the "
+                                                            "allocator starts to struggle)")
     ap.add_argument("--task", default="itm", choices=["itm", "mlm"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the MLM and reference-regime workloads")
@@ -535,15 +537,18 @@ def main():
                             "pairs_per_gpu_per_step": a.batch, "steps": k2,
                             "note": "same step on the %s task (12/33 of the pretrain mix is MLM)" % other.upper()}
         del ob
-        if a.batch != 1024:
-            # the round 1-3 headline configuration (1024 pairs per step), for round-over-round comparison
-            hb = [synth_batch(1024, a.task, 7000 * (rank + 1) + i, dev) for i in range(2)]
+        for hb_pairs, hb_note in ((1024, "the headline step at the 1024 pairs per step of rounds 1-3"),
+                                  (2048, "the headline step at 2048 pairs per step (this round's kernel experiments were measured at this size)")):
+            if a.batch == hb_pairs:
+                continue
+            # earlier headline configurations, for round-over-round comparison
+            hb = [synth_batch(hb_pairs, a.task, 7000 * (rank + 1) + i, dev) for i in range(2)]
             d6, _ = timed(lambda i: opt_step([hb[i % 2]], a.task), max(w2, 3), 2 * k2)
-            v6 = 1024 * world * 2 * k2 / d6
-            workloads["%s_1024_pairs_per_step" % a.task] = {
-                "pairs_per_s": round(v6, 1), "ms_per_step": round(d6 / (2 * k2) * 1e3, 2), "pairs_per_gpu_per_step": 1024,
+            v6 = hb_pairs * world * 2 * k2 / d6
+            workloads["%s_%d_pairs_per_step" % (a.task, hb_pairs)] = {
+                "pairs_per_s": round(v6, 1), "ms_per_step": round(d6 / (2 * k2) * 1e3, 2), "pairs_per_gpu_per_step": hb_pairs,
                 "mfma_frac_encoder": round(v6 * ENC_GFLOP_PER_PAIR * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
-                "note": "the headline step at the 1024 pairs per step of rounds 1-3"}
+                "note": hb_note}
             del hb
         rb = {t: [synth_batch(REF_MICRO, t, 9000 * (rank + 1) + i, dev) for i in range(REF_ACCUM)] for t in ("itm", "mlm")}
         k3 = 4 * k2                                  # (30 ms per optimizer step: five of them are too short a sample)
@@ -644,6 +649,8 @@ def main():
                        "gradient_allreduce": comm_path, "rccl_ranks": rccl_ranks, "rccl_version": rccl_version,
                        "gemm_item_queue": bool(ops.GEMM_QUEUE),
                        "device_allocations_in_timed_region": dev_allocs, "reserved_growth_in_timed_region_MB": round(dev_alloc_mb, 1),
+                       "peak_device_memory_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
+                       "peak_reserved_memory_GB": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1),
                        "dgrad_routes": {"%dx%dx%d epi %d" % k: v for k, v in sorted(ops.DGRAD_ROUTES.items())},
                        "gemm_plans": {"%s%s %dx%dx%d" % ("T" if k[0] else "N", "T" if k[1] else "N", k[2], k[3], k[4]):
                                       "%s split %d" % ("generic" if v[0] == 99 else "ping-pong" if v[0] == 8 else "ping-pong 192" if v[0] == 9 else "ping-pong 16x16x32" if v[0] == 12 else "ring v%d" % v[0], v[1])
