@@ -140,6 +140,11 @@ int uc2_ln_bwd_partial(int dtype, int M, int H, const void* dy, const void* x, c
                        const float* mean, const float* rstd, float drop_p, int drop_after, const uint64_t* seed_ptr,
                        uint64_t seed_imm, void* dx, void* dres, int want_dbias, void* ws, void* stream);
 int uc2_ln_bwd_reduce(int dtype, int M, int H, const void* ws, float* dgamma, float* dbeta, float* dbias, void* stream);
+/* the second stage of up to 32 LayerNorm backwards of the same H in one launch (items: M and ws of the uc2_ln_bwd_partial call,
+ * and where its sums go; any of dgamma / dbeta / dbias may be NULL): the micro-batch regime's 28 five-microsecond reductions per
+ * backward pass become one kernel at the end of the pass */
+typedef struct { int M; const void* ws; float* dgamma; float* dbeta; float* dbias; } Uc2LnReduceItem;
+int uc2_ln_bwd_reduce_batch(int dtype, int n, const Uc2LnReduceItem* items, int H, void* stream);
 
 /* ---- fused scaled-dot-product attention over the packed QKV projection (BertSelfAttention.forward,
  *      model/layer.py:75-101; additive key mask model/model.py:433-436) --------------------------------------------

@@ -104,6 +104,77 @@ def test_layernorm_fwd_bwd(dtype, M, H, with_res):
     assert rel_err(db, bs.grad) < tol(dtype, 2e-5, 1e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_deferred_reductions_one_launch(dtype):
+    """the micro-batch route (ops.LN_REDUCE_BATCH): inside a backward pass the second stages of the LayerNorm backwards are collected
+    and go out as one uc2_ln_bwd_reduce_batch launch from the end-of-pass callback -- same dgamma / dbeta / dbias as the immediate
+    reductions (sums of the same partial rows; the atomics' order differs), different M and NULL outputs in one batch, nothing
+    left pending afterwards; outside a pass nothing is deferred"""
+    H = 768
+    shapes = [(260, True), (1000, False), (37, True), (2048, True)] * 3          # 12 items
+    ins = []
+    for i, (M, with_bias) in enumerate(shapes):
+        x, r = rnd((M, H), 10 + i, dtype=dtype), rnd((M, H), 30 + i, dtype=dtype)
+        g, b = (1 + 0.1 * rnd((H,), 3)), rnd((H,), 4, 0.1)
+        dy = rnd((M, H), 50 + i, dtype=dtype)
+        _, mean, rstd = ops.ln_fwd(x, r, g, b, 1e-12)
+        ins.append((dy, x, r, g, mean, rstd, with_bias))
+
+    def run_all():
+        outs = []
+        for (dy, x, r, g, mean, rstd, with_bias) in ins:
+            dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+            dbias = torch.zeros(H, device=DEV) if with_bias else None
+            ops.ln_bwd(dy, x, r, g, mean, rstd, dg, None if not with_bias else db, dbias=dbias)     # (dbeta NULL where there is no dbias)
+            outs.append((dg, db, dbias))
+        return outs
+
+    ref = run_all()                                   # outside a backward pass: immediate reductions
+    assert not ops._ln_pending
+    torch.cuda.synchronize()
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, gr):
+            Fn.outs = run_all()
+            Fn.pending_inside = len(ops._ln_pending)
+            return gr
+
+    t = torch.zeros(4, device=DEV, requires_grad=True)
+    Fn.apply(t).sum().backward()
+    torch.cuda.synchronize()
+    assert Fn.pending_inside == len(shapes) and not ops._ln_pending and ops._ln_pending_task[0] == -1
+    for (dg, db, dbias), (rg, rb, rbias) in zip(Fn.outs, ref):
+        assert rel_err(dg, rg) < 1e-5 and rg.abs().max() > 0
+        assert rel_err(db, rb) < 1e-5 or (rb.abs().max() == 0 and db.abs().max() == 0)
+        if rbias is not None:
+            assert rel_err(dbias, rbias) < 1e-5
+    # a pass that raises leaves its entries behind; the next pass drops them instead of reducing them into its gradients
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, gr):
+            run_all()
+            raise RuntimeError("boom")
+
+    with pytest.raises(RuntimeError):
+        Boom.apply(t).sum().backward()
+    stale = len(ops._ln_pending)
+    Fn.apply(t).sum().backward()
+    torch.cuda.synchronize()
+    assert stale in (0, len(shapes)) and not ops._ln_pending      # (0: the engine ran the callback although the pass raised)
+    for (dg, db, dbias), (rg, rb, rbias) in zip(Fn.outs, ref):
+        assert rel_err(dg, rg) < 1e-5
+
+
 def test_layernorm_dropout_consistency():
     """dropout inside LN: mask is a pure function of (seed, index): fwd and bwd agree, rate is right"""
     M, H, p = 512, 768, 0.1

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UC2_LIB_PATH") or os.path.join(_HERE, "libuc2_hip.so")      # (UC2_LIB_PATH: A/B of two builds on one box)
 _lib = None
-ABI_VERSION = 7          # include/uc2_hip.h; bumped whenever a signature changes
+ABI_VERSION = 8          # include/uc2_hip.h; bumped whenever a signature changes
 
 P, I, F, U64, I64, SZ = c_void_p, c_int, c_float, c_uint64, c_int64, c_size_t
 
@@ -37,6 +37,7 @@ SIGNATURES = {
     "uc2_ln_bwd": (I, [I, I, I, P, P, P, P, P, P, F, I, P, U64, P, P, P, P, P, P, P]),
     "uc2_ln_bwd_partial": (I, [I, I, I, P, P, P, P, P, P, F, I, P, U64, P, P, I, P, P]),
     "uc2_ln_bwd_reduce": (I, [I, I, I, P, P, P, P, P]),
+    "uc2_ln_bwd_reduce_batch": (I, [I, I, P, I, P]),
     "uc2_attn_fwd": (I, [I, I, I, I, I, I, P, P, F, F, P, U64, P, P, P]),
     "uc2_attn_bwd": (I, [I, I, I, I, I, I, P, P, F, F, P, U64, P, P, P, P, P, P]),
     "uc2_attn_bwd_queued": (I, [I, I, I, I, I, I, P, P, F, F, P, U64, P, P, P, P, P, P, P]),

@@ -446,6 +446,67 @@ extern "C" int uc2_ln_bwd_reduce(int dtype, int M, int H, const void* ws, float*
   return 0;
 }
 
+// The second stage of up to UC2_LN_BATCH_MAX LayerNorm backwards in ONE launch (blockIdx.z = item).  At the reference's micro-batch
+// (9 984 tokens) a backward pass runs 28 of these 5.7 us reductions, each a launch of its own on the input-gradient chain
+// (profiles/r04_regime_itm_kernel_stats.csv: 1.7 % of the step); nothing reads dgamma / dbeta / dbias before the end of the pass,
+// so uc2_amd/ops.py collects the partial-sum workspaces and reduces them together at the end of the backward pass.
+#define UC2_LN_BATCH_MAX 32
+struct LnReduceBatch {
+  const float* ws[UC2_LN_BATCH_MAX];
+  float* dgamma[UC2_LN_BATCH_MAX];
+  float* dbeta[UC2_LN_BATCH_MAX];
+  float* dbias[UC2_LN_BATCH_MAX];
+  int nblk[UC2_LN_BATCH_MAX];
+};
+__global__ __launch_bounds__(256) void ln_bwd_reduce_batch_kernel(LnReduceBatch b, int H) {
+  __shared__ float red[4][64];
+  const int it = blockIdx.z;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + lane;
+  const int nblk = b.nblk[it];
+  const float* __restrict__ ws = b.ws[it];
+  float* const dgamma = b.dgamma[it];
+  float* const dbeta = b.dbeta[it];
+  float* const dbias = b.dbias[it];
+  const int nout = dbias ? 3 : 2;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+  float s = 0.f;
+  if (idx < nout * H)
+    for (int r = b0 + wv; r < b1; r += 4) s += ws[(size_t)r * 3 * H + idx];
+  red[wv][lane] = s;
+  __syncthreads();
+  if (wv == 0 && idx < nout * H) {
+    s = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (idx < H) { if (dgamma) atomicAdd(dgamma + idx, s); }
+    else if (idx < 2 * H) { if (dbeta) atomicAdd(dbeta + idx - H, s); }
+    else atomicAdd(dbias + idx - 2 * H, s);
+  }
+}
+
+struct Uc2LnReduceItem { int M; const void* ws; float* dgamma; float* dbeta; float* dbias; };      // mirrors include/uc2_hip.h
+extern "C" int uc2_ln_bwd_reduce_batch(int dtype, int n, const Uc2LnReduceItem* items, int H, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  UC2_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= LN_MAXC * 256);
+  UC2_CHECK_ARG(n >= 0 && n <= UC2_LN_BATCH_MAX && (n == 0 || items));
+  LnReduceBatch b;
+  int k = 0, nb_max = 0;
+  for (int i = 0; i < n; ++i) {
+    if (items[i].M <= 0 || !(items[i].dgamma || items[i].dbeta || items[i].dbias)) continue;
+    UC2_CHECK_ARG(items[i].ws);
+    b.ws[k] = (const float*)items[i].ws;
+    b.dgamma[k] = items[i].dgamma; b.dbeta[k] = items[i].dbeta; b.dbias[k] = items[i].dbias;
+    b.nblk[k] = ln_bwd_nblocks(dtype, items[i].M, H);
+    nb_max = b.nblk[k] > nb_max ? b.nblk[k] : nb_max;
+    ++k;
+  }
+  if (k == 0) return 0;
+  for (int i = k; i < UC2_LN_BATCH_MAX; ++i) { b.ws[i] = nullptr; b.dgamma[i] = b.dbeta[i] = b.dbias[i] = nullptr; b.nblk[i] = 0; }
+  hipLaunchKernelGGL(ln_bwd_reduce_batch_kernel, dim3((3 * H + 63) / 64, nb_max >= 256 ? 16 : 1, k), dim3(256), 0, (hipStream_t)stream, b, H);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int uc2_ln_bwd(int dtype, int M, int H, const void* dy, const void* x, const void* residual,
                           const float* gamma, const float* mean, const float* rstd, float drop_p, int drop_after,
                           const uint64_t* seed_ptr, uint64_t seed_imm, void* dx, void* dres, float* dgamma, float* dbeta,

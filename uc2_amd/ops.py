@@ -806,9 +806,62 @@ def ln_bwd(dy2, x2, res2, gamma, mean, rstd, dgamma, dbeta, drop_p=0.0, seed=Non
     if dgamma is not None or dbeta is not None or dbias is not None:
         if LN_REDUCE_SIDE and _side_route(M):      # (below WGRAD_SIDE_MIN_ROWS tokens it made the regime erratic: 27.0-30.8 ms against 27.0-27.1)
             _on_side_stream(x2.device, reduce, (ws,))
-        else:
+        elif not (LN_REDUCE_BATCH and M < WGRAD_SIDE_MIN_ROWS and _defer_ln_reduction(d, M, H, ws, dgamma, dbeta, dbias)):
             reduce()
     return dx, (dres if dres is not None else dx)
+
+
+# Small token counts (the reference's 104-pair micro-batches): the second stage of every LayerNorm backward of a pass goes out as ONE
+# launch at the end of the pass (uc2_ln_bwd_reduce_batch) -- 28 launches of 5.7 us on the input-gradient chain otherwise.  The
+# pending list belongs to one autograd graph task; entries a failed pass left behind are dropped, not reduced.
+LN_REDUCE_BATCH = os.environ.get("UC2_LN_REDUCE_BATCH", "1") != "0"
+_LN_BATCH_MAX = 32
+_ln_pending = []
+_ln_pending_task = [-1]
+
+
+class _LnReduceItem(ctypes.Structure):
+    _fields_ = [("M", ctypes.c_int), ("ws", ctypes.c_void_p), ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p),
+                ("dbias", ctypes.c_void_p)]
+
+
+def _defer_ln_reduction(d, M, H, ws, dgamma, dbeta, dbias):
+    """queue the reduction for the end of the current backward pass; False outside one (the caller reduces right away)"""
+    task = torch._C._current_graph_task_id()
+    if task < 0 or torch.cuda.is_current_stream_capturing():
+        return False
+    if _ln_pending_task[0] != task:
+        del _ln_pending[:]                       # (left by a pass that raised)
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(flush_ln_reductions)
+        except RuntimeError:
+            return False
+        _ln_pending_task[0] = task
+    _ln_pending.append((d, H, M, ws, dgamma, dbeta, dbias))
+    if len(_ln_pending) >= _LN_BATCH_MAX:
+        _flush_ln(keep_task=True)
+    return True
+
+
+def _flush_ln(keep_task):
+    items, _ln_pending[:] = list(_ln_pending), []
+    if not keep_task:
+        _ln_pending_task[0] = -1
+    groups = {}
+    for it in items:
+        groups.setdefault(it[:2], []).append(it)
+    for (d, H), its in groups.items():
+        arr = (_LnReduceItem * len(its))(*[_LnReduceItem(M, ptr(ws), ptr(dg), ptr(dbt), ptr(dbs)) for (_, _, M, ws, dg, dbt, dbs) in its])
+        call("uc2_ln_bwd_reduce_batch", d, len(its), arr, H, stream())
+
+
+def flush_ln_reductions(end_of_pass=True):
+    """reduce every pending LayerNorm backward now: the end-of-backward callback, and (end_of_pass False) BertLayerFn.backward
+    before it hands a layer's gradients to GradSync's all-reduce hook"""
+    if _ln_pending:
+        _flush_ln(keep_task=not end_of_pass)
+    elif end_of_pass:
+        _ln_pending_task[0] = -1
 
 
 ATTN_QKV_INTERLEAVED = 16          # include/uc2_hip.h UC2_ATTN_QKV_INTERLEAVED, OR-ed into `impl`
@@ -1072,6 +1125,7 @@ class BertLayerFn(torch.autograd.Function):
             # four dW GEMMs.  The hook's all-reduce waits for both streams itself (ops.pending_side_stream ->
             # uc2_comm_allreduce_bucket_after); joining the side stream into the main stream here (round 3) serialised every
             # layer boundary of the main stream behind that layer's weight-gradient GEMMs exactly when N > 1.
+            flush_ln_reductions(end_of_pass=False)      # (small batches: the layer's LayerNorm sums are still pending)
             hook(ctx.layer)
         return (dx, None, None, None) + (None,) * len(ctx.params)
 
