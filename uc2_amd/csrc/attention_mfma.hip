@@ -34,6 +34,9 @@
                              // instruction).  Measured (round 4, same box, bit-identical): 295.9 / 577.8 us with, 299.5 / 579.3 without at
                              // 12 288 / 24 576 heads -- the store granularity is not what bounds the kernel; off
 #endif
+#ifndef AM_LEAN
+#define AM_LEAN 1            // L == 32 NW: the kernels' lean load / store addressing (tile_lane_offset); 0 = the general path for every L
+#endif
 #ifndef AM_BWD_EARLY
 #define AM_BWD_EARLY 2       // with AM_BWD_PREFETCH == 2: how many of the four tiles (Q, K, dO, O) are fetched early
 #endif
@@ -104,6 +107,20 @@ __device__ __forceinline__ void store_acc_block(bf16* __restrict__ row_ptr, cons
     if (ok) *reinterpret_cast<bf16x8*>(row_ptr + 16 * k + 8 * h) = o;
   }
 }
+// store_acc_block for a workgroup-uniform base + one per-lane byte offset (row and lane half; L == Lp: no mask)
+__device__ __forceinline__ void store_acc_block_s(char* __restrict__ sbase, uint32_t voff, const f32x16& a) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[8 * k + e]), __float_as_uint(a[8 * k + 4 + e]), false, false);
+      o[e] = (bf16)__uint_as_float(sw[0]);
+      o[4 + e] = (bf16)__uint_as_float(sw[1]);
+    }
+    *reinterpret_cast<bf16x8*>(sbase + voff + 32 * k) = o;
+  }
+}
 // The same block set stored as WHOLE 128-byte lines (round 4): store_acc_block writes 16-byte pieces of 32 different rows per
 // wave-instruction, i.e. 64 partial-line requests -- the write pattern the GEMM epilogue got rid of in round 2 (+7..19 % there).
 // A wave's [32 rows x D] bf16 output goes through a wave-private LDS image (32 rows x 2 D bytes; 16-byte chunk q of row r at
@@ -172,6 +189,33 @@ __device__ __forceinline__ void store_tile_regs(char* dst, const bf16x8 (&r)[NCH
   }
 }
 
+// Lean forms for L == Lp (no row of the padded tile is past the sequence: L = 96 = 3 x 32, the bench geometry) -- round 4.
+// load_tile_regs computes, per 16-byte load, a signed division of the chunk index, a 64-bit multiply-add for the row and a bounds
+// branch with four zero moves: ~18 vector instructions per load, 20 loads per head in the backward (a fifth of its vector
+// instructions; both kernels are bound by instruction issue, profiles/r04_experiments.md section 3b).  Here the workgroup-uniform
+// part of the address (tensor, batch, head, chunk step i) stays in scalar registers and the per-lane part is ONE 32-bit byte offset
+// computed once per kernel (global_load saddr + voffset form): thread t owns chunk t % CPR of rows t / CPR + i NTHR / CPR.
+template <int D, int NTHR>
+__device__ __forceinline__ uint32_t tile_lane_offset(int ld, unsigned tid) {      // byte offset of this thread's chunk in rows of `ld` elements
+  constexpr unsigned CPR = D / 8;
+  return ((tid / CPR) * (unsigned)ld + (tid % CPR) * 8u) * 2u;
+}
+template <int D, int NCH, int NTHR>
+__device__ __forceinline__ void load_tile_lean(bf16x8 (&r)[NCH], const char* __restrict__ sbase, uint32_t voff, int ld) {
+  constexpr int CPR = D / 8;
+  static_assert(NTHR % CPR == 0, "a thread keeps its column chunk across steps");
+  const size_t step = (size_t)(NTHR / CPR) * (size_t)ld * 2u;                    // uniform
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) r[i] = *reinterpret_cast<const bf16x8*>(sbase + i * step + voff);
+}
+template <int D, int NCH, int NTHR>
+__device__ __forceinline__ void store_tile_lean(char* dst, const bf16x8 (&r)[NCH], unsigned tid) {
+  constexpr int RS = D * 2 + 16, CPR = D / 8;
+  char* p = dst + (tid / CPR) * RS + (tid % CPR) * 16;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) *reinterpret_cast<bf16x8*>(p + i * (NTHR / CPR) * RS) = r[i];
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -179,7 +223,7 @@ __device__ __forceinline__ void store_tile_regs(char* dst, const bf16x8 (&r)[NCH
 //  prefetched into registers under the current head's compute -- at the bench size: 139.0-139.5 us against 138.2 for this one
 //  (scratch/ab_attn_libs.py, same box).  The forward is not bound by the latency of its per-workgroup chain; what moved it in
 //  round 3 was the access pattern (head-major buffers: 147 -> 121 us).  Not kept.)
-template <int D, int NW>
+template <int D, int NW, bool FULL, bool DROP>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, const bf16* __restrict__ qkv,
                                                                 const float* __restrict__ mask, float scale,
                                                                 uint32_t thresh, float keep_scale,
@@ -202,21 +246,39 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
   // this lane's Q fragments: issued together with the K / V tile loads (after the barrier below they were a second, fully
   // exposed trip to memory per workgroup)
   bf16x8 qf[KS];
+  if (FULL) {                                        // L == Lp: no bounds, scalar bases + one lane offset (load_tile_lean)
+    const char* qb = reinterpret_cast<const char*>(base);
+    const uint32_t qoff = ((unsigned)q * (unsigned)ld + 8u * (unsigned)h) * 2u;
 #pragma unroll
-  for (int s = 0; s < KS; ++s)
-    qf[s] = (q < L) ? *reinterpret_cast<const bf16x8*>(base + (size_t)q * ld + 16 * s + 8 * h) : zero8();
+    for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qb + qoff + 32 * s);
+  } else {
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      qf[s] = (q < L) ? *reinterpret_cast<const bf16x8*>(base + (size_t)q * ld + 16 * s + 8 * h) : zero8();
+  }
   {   // K and V tiles: all 16-byte loads of the thread in flight together, then the LDS stores (a load -> wait -> store
       // loop costs eight dependent memory round trips per workgroup)
     constexpr int NCH = Lp * (D / 8) / (NW * 64);
     bf16x8 rk[NCH], rv[NCH];
-    load_tile_regs<D, NCH>(rk, base + AM_WS(D, H), ld, L, tid, NW * 64);
-    load_tile_regs<D, NCH>(rv, base + 2 * AM_WS(D, H), ld, L, tid, NW * 64);
+    if (FULL) {
+      const uint32_t toff = tile_lane_offset<D, NW * 64>(ld, tid);
+      load_tile_lean<D, NCH, NW * 64>(rk, reinterpret_cast<const char*>(base + AM_WS(D, H)), toff, ld);
+      load_tile_lean<D, NCH, NW * 64>(rv, reinterpret_cast<const char*>(base + 2 * AM_WS(D, H)), toff, ld);
+    } else {
+      load_tile_regs<D, NCH>(rk, base + AM_WS(D, H), ld, L, tid, NW * 64);
+      load_tile_regs<D, NCH>(rv, base + 2 * AM_WS(D, H), ld, L, tid, NW * 64);
+    }
     for (int k = tid; k < Lp; k += NW * 64) {
-      Ms[k] = (k < L) ? (mask ? mask[(size_t)b * L + k] * AM_LOG2E : 0.f) : -1e30f;        // base-2 domain: p = exp2(s c2 + m' - max')
+      Ms[k] = (FULL || k < L) ? (mask ? mask[(size_t)b * L + k] * AM_LOG2E : 0.f) : -1e30f;        // base-2 domain: p = exp2(s c2 + m' - max')
       Hk[k] = attn_line_hash(seed, bh, k, UC2_ATTN_SALT_K);
     }
-    store_tile_regs<D, NCH>(Ks, rk, tid, NW * 64);
-    store_tile_regs<D, NCH>(Vs, rv, tid, NW * 64);
+    if (FULL) {
+      store_tile_lean<D, NCH, NW * 64>(Ks, rk, tid);
+      store_tile_lean<D, NCH, NW * 64>(Vs, rv, tid);
+    } else {
+      store_tile_regs<D, NCH>(Ks, rk, tid, NW * 64);
+      store_tile_regs<D, NCH>(Vs, rv, tid, NW * 64);
+    }
   }
   __syncthreads();
 
@@ -250,7 +312,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       bool kp[4] = {true, true, true, true};
-      if (thresh) {
+      if (DROP) {                                      // (DROP = thresh != 0, a launch-time constant: as a run-time test hipcc branches per element)
         const uint4 hk4 = *reinterpret_cast<const uint4*>(Hk + 32 * kb + 8 * g + 4 * h);
         kp[0] = attn_keep(hq, hk4.x, thresh); kp[1] = attn_keep(hq, hk4.y, thresh);
         kp[2] = attn_keep(hq, hk4.z, thresh); kp[3] = attn_keep(hq, hk4.w, thresh);
@@ -261,6 +323,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
         const float p = __builtin_amdgcn_exp2f(sc[kb][i] - mx);
         sum += p;
         sc[kb][i] = kp[e] ? p : 0.f;                     // (the 1 / (1 - p_drop) of the kept entries is folded into the output scale)
+        // (select in fp32, then convert pairs: left alone, hipcc converts first and selects on the 16-bit halves -- shift, two
+        //  selects and a v_perm_b32 per pair instead of two selects)
+        asm volatile("" : "+v"(sc[kb][i]));
       }
     }
   sum += __shfl_xor(sum, 32);
@@ -278,9 +343,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
       for (int s = 0; s < 2; ++s)
         o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr(Vs, RS, 32 * kb + 16 * s, 32 * db, lane), pack8(sc[kb], s), o,
                                                     0, 0, 0);
-    store_acc_block(out + 32 * db, o, thresh ? inv * keep_scale : inv, h, q < L);
+    store_acc_block(out + 32 * db, o, DROP ? inv * keep_scale : inv, h, FULL || q < L);
   }
-  if (lse && q < L && h == 0) lse[(size_t)bh * L + q] = (mx + __builtin_amdgcn_logf(sum)) * 0.69314718056f;     // natural-log lse
+  if (lse && (FULL || q < L) && h == 0) lse[(size_t)bh * L + q] = (mx + __builtin_amdgcn_logf(sum)) * 0.69314718056f;     // natural-log lse
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -295,7 +360,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
 // wave and head, and no V tile in LDS.
 // (launch bound: 2 waves per SIMD = 256 registers per lane.  Unbounded, hipcc took 254 VGPRs + 96 AGPRs, which admits ONE
 // wave per SIMD: one 3-wave workgroup per CU with a SIMD idle -- rocprofv3 showed wave lifetimes of half the kernel.)
-template <int D, int NW>
+template <int D, int NW, bool FULL, bool DROP>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh, const bf16* __restrict__ qkv,
                                                                 const float* __restrict__ mask, float scale,
                                                                 uint32_t thresh, float keep_scale,
@@ -325,6 +390,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
   const int w = tid >> 6, lane = tid & 63, c = lane & 31, h = lane >> 5;
   const int r0 = 32 * w + c;                           // this lane's key (main loop) and query (dQ phase)
   constexpr int NTHR = NW * 64, CPR = D / 8, NCH = Lp * CPR / NTHR;
+  // (FULL) the per-lane byte offsets of the lean addressing: this thread's chunk in a q|k|v tile / a ctx tile, this lane's row
+  const uint32_t toff_qkv = tile_lane_offset<D, NTHR>(ld, tid), toff_ctx = tile_lane_offset<D, NTHR>(H, tid);
+  const uint32_t roff_qkv = ((unsigned)r0 * (unsigned)ld + 8u * (unsigned)h) * 2u;
   if (dbias) {                                         // (the head loop's first barrier orders this before any accumulation)
     for (int i = tid; i < 3 * H; i += NTHR) Cs[i] = 0.f;
   }
@@ -349,6 +417,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
   auto fetch_tiles = [&](int hd, int lo, int hi) __attribute__((always_inline)) {      // tiles lo .. hi-1 of (0 Q, 1 K, 2 dO, 3 O)
     const int fb = hd / nh, fh = hd - fb * nh;
     const bf16* fbase = qkv + (size_t)fb * L * ld + fh * AM_HS(D, H);
+    if (FULL) {
+      if (lo <= 0 && 0 < hi) load_tile_lean<D, NCH, NTHR>(rq, reinterpret_cast<const char*>(fbase), toff_qkv, ld);
+      if (lo <= 1 && 1 < hi) load_tile_lean<D, NCH, NTHR>(rk, reinterpret_cast<const char*>(fbase + AM_WS(D, H)), toff_qkv, ld);
+      if (lo <= 2 && 2 < hi) load_tile_lean<D, NCH, NTHR>(rg, reinterpret_cast<const char*>(dctx + (size_t)fb * L * H + fh * D), toff_ctx, H);
+      if (lo <= 3 && 3 < hi) load_tile_lean<D, NCH, NTHR>(ro, reinterpret_cast<const char*>(ctx + (size_t)fb * L * H + fh * D), toff_ctx, H);
+      return;
+    }
     int t_ = tid;
     asm volatile("" : "+v"(t_));
     if (lo <= 0 && 0 < hi) load_tile_regs<D, NCH>(rq, fbase, ld, L, t_, NTHR);
@@ -359,11 +434,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
   auto fetch_rest = [&](int hd) __attribute__((always_inline)) {                       // V fragments, mask / lse of row tid
     const int fb = hd / nh, fh = hd - fb * nh;
     const bf16* fbase = qkv + (size_t)fb * L * ld + fh * AM_HS(D, H);
-    int r0_ = r0;
-    asm volatile("" : "+v"(r0_));
+    if (FULL) {
+      const char* vb = reinterpret_cast<const char*>(fbase + 2 * AM_WS(D, H));
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
-      rvf[s] = (r0 < L) ? *reinterpret_cast<const bf16x8*>(fbase + 2 * AM_WS(D, H) + (size_t)r0_ * ld + 16 * s + 8 * h) : zero8();
+      for (int s = 0; s < KS; ++s) rvf[s] = *reinterpret_cast<const bf16x8*>(vb + roff_qkv + 32 * s);
+    } else {
+      int r0_ = r0;
+      asm volatile("" : "+v"(r0_));
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        rvf[s] = (r0 < L) ? *reinterpret_cast<const bf16x8*>(fbase + 2 * AM_WS(D, H) + (size_t)r0_ * ld + 16 * s + 8 * h) : zero8();
+    }
     if (tid < Lp && tid < L) {
       rmask = mask ? mask[(size_t)fb * L + tid] : 0.f;
       rlse = lse[(size_t)hd * L + tid];
@@ -378,9 +459,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
   if (!AM_BWD_PREFETCH) fetch(bh);                     // no register prefetch: the CU's other workgroup covers the latency
   if (AM_BWD_PREFETCH == 2) { fetch_tiles(bh, AM_BWD_EARLY, 4); fetch_rest(bh); }     // what the dQ phase of the previous head did not fetch
   // ---- registers -> LDS (the previous head's readers are past the barrier at the end of the loop body)
-  store_tile_regs<D, NCH>(Qs, rq, tid, NTHR);
-  store_tile_regs<D, NCH>(Ks, rk, tid, NTHR);
-  store_tile_regs<D, NCH>(Gs, rg, tid, NTHR);
+  if (FULL) {
+    store_tile_lean<D, NCH, NTHR>(Qs, rq, tid);
+    store_tile_lean<D, NCH, NTHR>(Ks, rk, tid);
+    store_tile_lean<D, NCH, NTHR>(Gs, rg, tid);
+  } else {
+    store_tile_regs<D, NCH>(Qs, rq, tid, NTHR);
+    store_tile_regs<D, NCH>(Ks, rk, tid, NTHR);
+    store_tile_regs<D, NCH>(Gs, rg, tid, NTHR);
+  }
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {                      // delta[row] = sum_d dO*O: 8 values per chunk, CPR consecutive lanes per row
     float dl = 0.f;
@@ -388,8 +475,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
     for (int e = 0; e < 8; ++e) dl += (float)rg[i][e] * (float)ro[i][e];
 #pragma unroll
     for (int o = 1; o < CPR; o <<= 1) dl += __shfl_xor(dl, o);
-    const int cidx = tid + i * NTHR, row = cidx / CPR;
-    if (cidx - row * CPR == 0) Ds[row] = dl * scale;       // delta, pre-multiplied by the softmax scale
+    // chunk tid + i NTHR = column chunk tid % CPR of row tid / CPR + i NTHR / CPR (NTHR is a multiple of CPR)
+    if (((unsigned)tid & (CPR - 1)) == 0) Ds[(unsigned)tid / CPR + i * (NTHR / CPR)] = dl * scale;       // delta, pre-multiplied by the softmax scale
   }
   if (tid < Lp) {
     Ms[tid] = (tid < L) ? rmask * AM_LOG2E : -1e30f;          // base-2 domain, like the forward
@@ -440,13 +527,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
           // per element: fma, sub, exp2; two selects for the dropout multipliers (1/(1-p) and scale/(1-p)); mul, fma, mul
           const float p = __builtin_amdgcn_exp2f(fmaf(sa[i], c2, mk) - l4[e]);
           float m1 = 1.0f, m2 = scale;
-          if (thresh) {
+          if (DROP) {
             const bool keep = attn_keep(hqv[e], hk2, thresh);
             m1 = keep ? keep_scale : 0.f;
             m2 = keep ? ks_scale : 0.f;
           }
           const float dsv = p * fmaf(pa[i], m2, -d4[e]);      // dS = P (dP_dropped - delta) scale, delta pre-scaled
-          pa[i] = thresh ? p * m1 : p;               // dropped P
+          pa[i] = DROP ? p * m1 : p;                 // dropped P
           sa[i] = dsv;                               // dS
           ds4[e] = (bf16)dsv;
         }
@@ -464,14 +551,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
         }
     }
     if (dbias) {                                                               // d(key bias), d(value bias)
-      acc_colsum_atomic<DB>(dk, r0 < L, Cs + H + head * D, lane);
-      acc_colsum_atomic<DB>(dv, r0 < L, Cs + 2 * H + head * D, lane);
+      acc_colsum_atomic<DB>(dk, FULL || r0 < L, Cs + H + head * D, lane);
+      acc_colsum_atomic<DB>(dv, FULL || r0 < L, Cs + 2 * H + head * D, lane);
     }
     if (!AM_LINE_STORES) {
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
-        store_acc_block(dbase + (size_t)r0 * ld + AM_WS(D, H) + 32 * db, dk[db], 1.0f, h, r0 < L);
-        store_acc_block(dbase + (size_t)r0 * ld + 2 * AM_WS(D, H) + 32 * db, dv[db], 1.0f, h, r0 < L);
+        if (FULL) {
+          store_acc_block_s(reinterpret_cast<char*>(dbase + AM_WS(D, H) + 32 * db), roff_qkv, dk[db]);
+          store_acc_block_s(reinterpret_cast<char*>(dbase + 2 * AM_WS(D, H) + 32 * db), roff_qkv, dv[db]);
+        } else {
+          store_acc_block(dbase + (size_t)r0 * ld + AM_WS(D, H) + 32 * db, dk[db], 1.0f, h, r0 < L);
+          store_acc_block(dbase + (size_t)r0 * ld + 2 * AM_WS(D, H) + 32 * db, dv[db], 1.0f, h, r0 < L);
+        }
       }
     }
   }
@@ -497,12 +589,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
       for (int db = 0; db < DB; ++db)
         dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr(Ks, RS, 16 * ks, 32 * db, lane), bfrag, dq[db], 0, 0, 0);
     }
-    if (dbias) acc_colsum_atomic<DB>(dq, r0 < L, Cs + head * D, lane);          // d(query bias)
+    if (dbias) acc_colsum_atomic<DB>(dq, FULL || r0 < L, Cs + head * D, lane);          // d(query bias)
     if (AM_LINE_STORES) {
       store_acc_lines<D, DB>(dbase, ld, 32 * w, L, dq, Gs + w * 32 * 2 * D, lane);
     } else {
 #pragma unroll
-      for (int db = 0; db < DB; ++db) store_acc_block(dbase + (size_t)r0 * ld + 32 * db, dq[db], 1.0f, h, r0 < L);
+      for (int db = 0; db < DB; ++db) {
+        if (FULL) store_acc_block_s(reinterpret_cast<char*>(dbase + 32 * db), roff_qkv, dq[db]);
+        else store_acc_block(dbase + (size_t)r0 * ld + 32 * db, dq[db], 1.0f, h, r0 < L);
+      }
     }
   }
   __syncthreads();                                     // every wave is done with this head's LDS tiles
@@ -510,7 +605,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
   if (!queue) break;
   if (tid == 0) Tk[0] = (int)gridDim.x + ticket;       // (the next write to Tk[0] is at least one head = several barriers away)
   __syncthreads();
-  chunk = Tk[0];
+  chunk = __builtin_amdgcn_readfirstlane(Tk[0]);       // (uniform: the heads' base addresses stay in scalar registers)
   }
   if (queue && tid == 0) {
     const int old = __hip_atomic_fetch_add(queue + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -533,8 +628,12 @@ static int launch_fwd(int B, int L, int nh, const void* qkv, const float* mask, 
                       const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse, int ilv, hipStream_t st) {
   constexpr int RS = D * 2 + 16, Lp = NW * 32;
   const size_t smem = 2 * Lp * RS + 2 * Lp * sizeof(float);
-  hipLaunchKernelGGL((attn_fwd_mfma_kernel<D, NW>), dim3(B * nh), dim3(NW * 64), smem, st, L, nh, (const bf16*)qkv, mask,
-                     scale, drop_thresh(drop_p), 1.0f / (1.0f - drop_p), seed_ptr, seed_imm, (bf16*)ctx, lse, ilv);
+  const uint32_t th = drop_thresh(drop_p);
+  const bool full = L == Lp && AM_LEAN;
+  auto kern = full ? (th ? attn_fwd_mfma_kernel<D, NW, true, true> : attn_fwd_mfma_kernel<D, NW, true, false>)
+                   : (th ? attn_fwd_mfma_kernel<D, NW, false, true> : attn_fwd_mfma_kernel<D, NW, false, false>);
+  hipLaunchKernelGGL(kern, dim3(B * nh), dim3(NW * 64), smem, st, L, nh, (const bf16*)qkv, mask, scale, th, 1.0f / (1.0f - drop_p),
+                     seed_ptr, seed_imm, (bf16*)ctx, lse, ilv);
   UC2_LAUNCH_CHECK();
   return 0;
 }
@@ -544,7 +643,10 @@ static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, 
                       const float* lse, void* dqkv, float* dbias, int* queue, int ilv, hipStream_t st) {
   constexpr int RS = D * 2 + 16, Lp = NW * 32, RSD = Lp * 2 + 16;
   const size_t smem = 3 * Lp * RS + Lp * RSD + 5 * Lp * sizeof(float) + 16 + (dbias ? 3 * (size_t)nh * D * sizeof(float) : 0);
-  auto kern = attn_bwd_mfma_kernel<D, NW>;
+  const uint32_t th = drop_thresh(drop_p);
+  const bool full = L == Lp && AM_LEAN;
+  auto kern = full ? (th ? attn_bwd_mfma_kernel<D, NW, true, true> : attn_bwd_mfma_kernel<D, NW, true, false>)
+                   : (th ? attn_bwd_mfma_kernel<D, NW, false, true> : attn_bwd_mfma_kernel<D, NW, false, false>);
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { uc2_set_error(__FILE__, __LINE__, hipGetErrorString(e)); return (int)e; }
@@ -571,7 +673,7 @@ static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, 
     queue = nullptr;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, L, nh, (const bf16*)qkv, mask, scale,
-                     drop_thresh(drop_p), 1.0f / (1.0f - drop_p), seed_ptr, seed_imm, (const bf16*)ctx,
+                     th, 1.0f / (1.0f - drop_p), seed_ptr, seed_imm, (const bf16*)ctx,
                      (const bf16*)dctx, lse, (bf16*)dqkv, dbias, nbh, hpw, queue, ilv);
   UC2_LAUNCH_CHECK();
   return 0;
