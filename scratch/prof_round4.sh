@@ -17,6 +17,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_
 python3 tests/pmc_summarize.py 4 $O/pmc_fetch $O/pmc_write $O/pmc_sq "gemm_bf16_pp16_kernel<true, true, true, 0, 2>" "gemm_bf16_pp16_kernel<false, false, true, 5, 2>" "gemm_bf16_pp16_kernel<false, false, true, 6, 2>" "gemm_bf16_pp16_kernel<false, false, true, 3, 2>" "gemm_bf16_pp16_kernel<false, false, true, 0, 2>" attn_bwd_mfma attn_fwd_mfma ln_bwd_kernel ln_fwd16_kernel adamw_kernel > $O/pmc_summary.json
 unset UC2_WGRAD_SIDE
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_1024 -- python3 bench.py --batch 1024 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/trace_1024.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_2048 -- python3 bench.py --batch 2048 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/trace_2048.log 2>&1
 python3 scratch/regime_step.py itm 8 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_regime -- python3 scratch/regime_step.py itm 8 > $O/trace_regime.log 2>&1
 find $O -name "*kernel_trace.csv" -delete

@@ -431,7 +431,7 @@ extern "C" int uc2_ln_bwd_partial(int dtype, int M, int H, const void* dy, const
 // second stage: dgamma / dbeta / dbias += the column sums of the partial rows a uc2_ln_bwd_partial of the same (dtype, M, H) left
 // in ws.  Nothing in the backward chain reads these three vectors, so the caller may run this on another stream (ordered after
 // the first stage): next to a persistent GEMM of a concurrent stream this small kernel otherwise waits ~100 us for a free CU
-// with the whole input-gradient chain queued behind it (profiles/r04_bench_n1_kernel_stats.csv: 121 us against 5.6 us alone).
+// with the whole input-gradient chain queued behind it (profiles/r04_2048pairs_bench_n1_kernel_stats.csv: 121 us against 5.6 us alone).
 extern "C" int uc2_ln_bwd_reduce(int dtype, int M, int H, const void* ws, float* dgamma, float* dbeta, float* dbias,
                                  void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
@@ -448,7 +448,7 @@ extern "C" int uc2_ln_bwd_reduce(int dtype, int M, int H, const void* ws, float*
 
 // The second stage of up to UC2_LN_BATCH_MAX LayerNorm backwards in ONE launch (blockIdx.z = item).  At the reference's micro-batch
 // (9 984 tokens) a backward pass runs 28 of these 5.7 us reductions, each a launch of its own on the input-gradient chain
-// (profiles/r04_regime_itm_kernel_stats.csv: 1.7 % of the step); nothing reads dgamma / dbeta / dbias before the end of the pass,
+// (profiles/r04_2048pairs_regime_itm_kernel_stats.csv: 1.7 % of the step); nothing reads dgamma / dbeta / dbias before the end of the pass,
 // so uc2_amd/ops.py collects the partial-sum workspaces and reduces them together at the end of the backward pass.
 #define UC2_LN_BATCH_MAX 32
 struct LnReduceBatch {
