@@ -127,6 +127,41 @@ __device__ __forceinline__ void gelu_and_dgelu_bf(float x, float& g, float& d) {
   g = x * ph;
   d = fmaf(xc * sp, t, ph);
 }
+// The same arithmetic on a PAIR of values, written on 2-vectors so that hipcc emits v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32
+// (two values per full-rate issue slot) instead of v_fmaak / v_fmamk / v_mul per value: the scalar form's 12 full-rate
+// instructions per value came out as 11 issue slots + one v_mov (operand packing) in the GELU GEMM's epilogue, where the matrix
+// pipe is idle and the vector pipe is the bound; same operations in the same order, bit-identical results.
+typedef float uc2_f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_and_dgelu_bf2(uc2_f2v x, uc2_f2v& g, uc2_f2v& d) {
+  const uc2_f2v xc = {__builtin_amdgcn_fmed3f(x.x, -9.0f, 9.0f), __builtin_amdgcn_fmed3f(x.y, -9.0f, 9.0f)};
+  const uc2_f2v x2 = xc * xc;
+  const uc2_f2v k2 = {-UC2_PHI_C2 * UC2_LOG2E, -UC2_PHI_C2 * UC2_LOG2E}, k1 = {-UC2_PHI_C1 * UC2_LOG2E, -UC2_PHI_C1 * UC2_LOG2E};
+  const uc2_f2v k0 = {-UC2_PHI_C0 * UC2_LOG2E, -UC2_PHI_C0 * UC2_LOG2E};
+  uc2_f2v q = __builtin_elementwise_fma(k2, x2, k1);
+  q = __builtin_elementwise_fma(q, x2, k0);
+  const uc2_f2v y = q * xc;
+  const uc2_f2v e = {__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)};
+  const uc2_f2v one = {1.0f, 1.0f};
+  const uc2_f2v den = one + e;
+  const uc2_f2v ph = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+  const uc2_f2v s5 = {5.0f * UC2_PHI_C2, 5.0f * UC2_PHI_C2}, s3 = {3.0f * UC2_PHI_C1, 3.0f * UC2_PHI_C1}, s0 = {UC2_PHI_C0, UC2_PHI_C0};
+  const uc2_f2v sp = __builtin_elementwise_fma(__builtin_elementwise_fma(s5, x2, s3), x2, s0);
+  const uc2_f2v t = __builtin_elementwise_fma(-ph, ph, ph);                      // Phi (1 - Phi)
+  g = x * ph;
+  d = __builtin_elementwise_fma(xc * sp, t, ph);
+}
+__device__ __forceinline__ uc2_f2v gelu_bf2(uc2_f2v x) {                // gelu_bf on a pair (forward-only epilogues)
+  const uc2_f2v xc = {__builtin_amdgcn_fmed3f(x.x, -9.0f, 9.0f), __builtin_amdgcn_fmed3f(x.y, -9.0f, 9.0f)};
+  const uc2_f2v x2 = xc * xc;
+  const uc2_f2v k2 = {-UC2_PHI_C2 * UC2_LOG2E, -UC2_PHI_C2 * UC2_LOG2E}, k1 = {-UC2_PHI_C1 * UC2_LOG2E, -UC2_PHI_C1 * UC2_LOG2E};
+  const uc2_f2v k0 = {-UC2_PHI_C0 * UC2_LOG2E, -UC2_PHI_C0 * UC2_LOG2E};
+  uc2_f2v q = __builtin_elementwise_fma(k2, x2, k1);
+  q = __builtin_elementwise_fma(q, x2, k0);
+  const uc2_f2v y = q * xc;
+  const uc2_f2v one = {1.0f, 1.0f};
+  const uc2_f2v den = one + uc2_f2v{__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)};
+  return x * uc2_f2v{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+}
 __device__ __forceinline__ float tanh_bf(float x) {                     // 1 - 2/(1 + exp(2x)); saturates correctly at +-inf
   return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * (2.0f * UC2_LOG2E))), 1.0f);
 }

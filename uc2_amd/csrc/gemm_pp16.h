@@ -106,6 +106,9 @@ __device__ __forceinline__ float colsum_butterfly16(float (&v)[16], int lane) {
 // A half hh, 16-column block nb; a 32-row output block (hh, i) is the block pair mb = 2 i, 2 i + 1.  Piece k = 4 mbl + nb of
 // the lane = row 16 mbl + (lane & 15) of the 32-row block, columns 16 nb + 4 g .. + 3 = half (g & 1) of 16-byte chunk
 // 2 nb + (g >> 1) of the 128-byte row in the transposition buffer: (q0 ^ (nb << 5)) + mbl * 2048.
+#ifndef UC2_GELU_PACKED
+#define UC2_GELU_PACKED 1
+#endif
 template <int EPI>
 __device__ __forceinline__ void pp16_epi_compute_q(const GemmArgs& p, const f32x4 (&acc)[2][4][4], PpOut& out, int mb0, int nb0,
                                                    int lane, const TpAddr& ta) {
@@ -161,9 +164,26 @@ __device__ __forceinline__ void pp16_epi_compute_q(const GemmArgs& p, const f32x
 #pragma unroll
               for (int e = 0; e < 4; ++e) pre[k][e] = (bf16)v[e];
             }
+#if UC2_GELU_PACKED
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+              const uc2_f2v gg = gelu_bf2(uc2_f2v{v[e], v[e + 1]});
+              v[e] = gg.x; v[e + 1] = gg.y;
+            }
+#else
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_bf(v[e]);
+#endif
           } else if (EPI == EPI_GELU_D) {
+#if UC2_GELU_PACKED
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {              // pairs: packed fp32 arithmetic (common.h, gelu_and_dgelu_bf2)
+              uc2_f2v gg, dd;
+              gelu_and_dgelu_bf2(uc2_f2v{v[e], v[e + 1]}, gg, dd);
+              pre[k][e] = (bf16)dd.x; pre[k][e + 1] = (bf16)dd.y;
+              v[e] = gg.x; v[e + 1] = gg.y;
+            }
+#else
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float gg, dd;
@@ -171,13 +191,14 @@ __device__ __forceinline__ void pp16_epi_compute_q(const GemmArgs& p, const f32x
               pre[k][e] = (bf16)dd;
               v[e] = gg;
             }
+#endif
           } else if (EPI == EPI_DGELU || EPI == EPI_MUL) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= (EPI == EPI_MUL) ? (float)axq[k][e] : dgelu_bf((float)axq[k][e]);
-            if (want_cs) {
+            // (unconditional: under the run-time `want_cs` hipcc emitted a packed add AND a select per value -- 128 v_cndmask per
+            //  tile and wave; the sums are simply not used when no column-sum output was asked for)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) cs[4 * nb + e] += v[e];
-            }
+            for (int e = 0; e < 4; ++e) cs[4 * nb + e] += v[e];
           } else if (EPI == EPI_ADD) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += (float)axq[k][e];
