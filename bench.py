@@ -428,6 +428,8 @@ def main():
     beat()
     st.sync_shadow()
     st.auto_sync = False            # AdamW rewrites the bf16 copies in its own pass from here on
+    from uc2_amd.utils import distributed as _D
+    tail_mode = "bf16" if _D._tail_bf16(st) else "fp32"      # dtype the exposed embedding / head tail of the gradient all-reduce travels in
 
     def opt_step(micro_batches, task):
         """one optimizer step over `micro_batches` (gradients summed, pretrain.py:553-559); the all-reduce is armed
@@ -474,6 +476,11 @@ def main():
         return dt, out
 
     # ------------------------------------------------------------------ headline: --task at --batch pairs per step
+    free_b, _tot_b = torch.cuda.mem_get_info(dev)
+    need_b = (31.5 * a.batch / 1024.0 * (a.layers / 12.0) + 12.0) * 2 ** 30     # saved activations (30.7 GB per 1024 pairs at 12 layers) + model, optimizer, workspaces
+    if free_b < need_b:
+        raise SystemExit("bench.py: --batch %d needs about %.0f GB of free HBM on %s, %.0f GB are free (another process on the device?); "
+                         "use a smaller --batch" % (a.batch, need_b / 2 ** 30, dev, free_b / 2 ** 30))
     batches = [synth_batch(a.batch, a.task, 1000 * (rank + 1) + i, dev) for i in range(2)]
     # (untimed, before the W warm-up steps: the caching allocator's pool -- ~190 GB of hipMalloc at the default batch -- and the
     #  GEMM plans of any untuned shape settle in the first two steps of a process; with --warmup 1 they would otherwise fall into
@@ -487,6 +494,9 @@ def main():
     fence()
     ops.GEMM_TIMER, ops.HBM_TIMER = gtimer, htimer
     ms0 = torch.cuda.memory_stats(dev)
+    from uc2_amd.utils import distributed as D
+    D.COMM_TIMER = comm_events = []     # HIP events around what is left of the gradient all-reduce when backward has ended (exposed)
+    ops.gemm_fallbacks(reset=True)
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = opt_step([batches[(a.warmup + i) % 2]], a.task)
@@ -494,6 +504,9 @@ def main():
     dt = time.perf_counter() - t0
     ms1 = torch.cuda.memory_stats(dev)
     # device allocations (hipMalloc calls of the caching allocator) inside the timed region: 0 in a settled run
+    D.COMM_TIMER = None
+    comm_exposed_ms = sum(e0.elapsed_time(e1) for e0, e1 in comm_events) / max(a.steps, 1)
+    gemm_fallbacks = ops.gemm_fallbacks()          # GEMM calls of the timed region whose ping-pong plan another kernel ran (0 expected)
     dev_allocs = int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0))
     dev_alloc_mb = (ms1.get("reserved_bytes.all.peak", 0) - ms0.get("reserved_bytes.all.current", 0)) / 2 ** 20
     ops.GEMM_TIMER, ops.HBM_TIMER = None, None
@@ -653,7 +666,9 @@ def main():
                        "pairs_per_gpu_per_step": a.batch, "global_batch": a.batch * world,
                        "seq_len": T_TXT + N_REG, "parallelism": "dp%d" % world, "final_loss": round(lossv, 4), "replicas_in_sync": in_sync,
                        "gradient_allreduce": comm_path, "rccl_ranks": rccl_ranks, "rccl_version": rccl_version,
-                       "gemm_item_queue": bool(ops.GEMM_QUEUE),
+                       "gemm_item_queue": bool(ops.GEMM_QUEUE), "gemm_fallbacks": gemm_fallbacks,
+                       "comm_exposed_ms_per_step": round(comm_exposed_ms, 3),
+                       "allreduce_tail": tail_mode,
                        "device_allocations_in_timed_region": dev_allocs, "reserved_growth_in_timed_region_MB": round(dev_alloc_mb, 1),
                        "untimed_settle_steps_before_warmup": settle,
                        "peak_device_memory_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
@@ -666,6 +681,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kname,
                          "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_algorithmic": round(gtimer.bytes_per_launch().get(kname, 0.0)),
                          "launches": n_l, "avg_us": round(sec / max(n_l, 1) * 1e6, 2),
                          "all_gemm_kernels": {"achieved": round(all_f / all_t / 1e12, 1) if all_t > 0 else 0.0,
                                               "share_of_step_time": round(all_t / kdt, 3),

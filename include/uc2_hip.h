@@ -54,6 +54,7 @@ int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, const voi
  *              kernel (any shape/alignment); 0..12 = one specific kernel (0-2 LDS-DMA rings, 6/7 wave-specialised
  *              rings, 8 = persistent ping-pong 256x256 on v_mfma_f32_32x32x16_bf16, 9 = the same with 192-row tiles, 12 = the same
  *              schedule on v_mfma_f32_16x16x32_bf16 (less energy per flop: +4..8 % on X W^T and dY W; calls 12 does not cover run as 8);
+ *              13 = the same tile on one wave per SIMD, 128 x 128 per wave (gemm_p1.hip; k-contiguous operands, calls it does not cover run as 12);
  *              10 and 11 were round-3 experiment kernels -- rolling epilogue, two phases per k-tile: scratch/kernels/ -- and are
  *              argument errors now, like every other number not listed).  A variant that does not
  *              support the shape falls back to the generic kernel.  uc2_amd/ops.py::gemm_plan picks it per shape.
@@ -61,11 +62,14 @@ int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, const voi
  *              gradients: partial tiles are stored plainly and reduced in a second pass instead of fp32 atomics
  *              (bit-reproducible); NULL = atomics.
  *   flags      UC2_GEMM_DEFER_REDUCE: stop after the partial tiles, the caller runs uc2_gemm_splitk_reduce itself
- *              (lets a profiler time the two passes separately); UC2_GEMM_AUX_DERIV: the GELU epilogue saves
+ *              (lets a profiler time the two passes separately; the head-interleaved q|k|v weight gradient reduces with
+ *              uc2_gemm_splitk_reduce_qkv).  Only the two-stage split-K path of variants 8 / 12 can honour it: a call that
+ *              cannot take that path (shape, alignment, an operand of 4 GiB or more, no / short workspace) returns -1 and
+ *              launches NOTHING -- it never falls back to a kernel that accumulates into C directly; UC2_GEMM_AUX_DERIV: the GELU epilogue saves
  *              gelu'(pre) instead of pre in aux_out and the DGELU epilogue multiplies by aux_in as it is (the
  *              derivative comes almost free beside the forward's Phi(x); the backward GEMM loses its transcendental
  *              epilogue); a forward/backward pair must agree on it; UC2_GEMM_SKEW(n): ping-pong start skew between phase
- *              groups, n * ~8k cycles; UC2_GEMM_DIAG(m): diagnostic launch modes (tests/bench_pp.py), 0 in production. */
+ *              groups, n * ~8k cycles; UC2_GEMM_DIAG(m): diagnostic launch modes (tools/bench_pp.py), 0 in production. */
 enum { UC2_GEMM_AUTO = -2, UC2_GEMM_GENERIC = 99 };
 enum { UC2_GEMM_DEFER_REDUCE = 1, UC2_GEMM_AUX_DERIV = 2 };
 #define UC2_GEMM_SKEW(n) (((n) & 15) << 4)
@@ -84,6 +88,10 @@ int uc2_gemm_queued(int dtype, int trans_a, int trans_b, int M, int N, int K, co
                     void* queue, void* stream);
 int uc2_gemm_splitk_reduce(int M, int N, void* C, int ldc, int split_k, int accumulate, const void* workspace,
                            size_t workspace_bytes, void* stream);
+/* Diagnostics: number of uc2_gemm / uc2_gemm_queued calls since load (or since the last reset != 0) that named a ping-pong kernel
+ * (variant 8 / 9 / 12 / 13) and were run by another kernel because the shape, an alignment or the 32-bit staging-offset limit
+ * (an operand of 4 GiB or more) did not qualify.  bench.py prints it as config.gemm_fallbacks; nothing selects a kernel from it. */
+long long uc2_gemm_fallback_count(int reset);
 /* Grouped weight gradients: dW_i[n_out_i, n_in_i] (fp32) += dY_i[rows, n_out_i]^T X_i[rows, n_in_i] for up to four linear
  * layers that share the token axis -- the four dense layers of one BertLayer (model/layer.py:75-156; autograd issues their
  * weight gradients one GEMM at a time) -- as ONE launch of the persistent ping-pong kernel over all (tile, k-split) items

@@ -71,7 +71,7 @@ def test_argument_errors_do_not_need_a_gpu():
         _lib.check(rc)
     # a gemm variant the library does not know is an argument error, not a silent fall-back
     # (10 and 11 were round-3 experiment kernels, retired from the shipped library: scratch/kernels/)
-    for bad in (13, 10, 11):
+    for bad in (15, 10, 11):
         rc = lib.uc2_gemm(1, 0, 0, 256, 256, 256, 16, 256, 16, 256, 16, 256, 0, None, 0, None, None, 0, 0, 1, bad, None, 0, 0, None)
         assert rc < 0 and b"variant" in lib.uc2_last_error()
     # the IPOT kernel keeps 3 T R floats in LDS: 128 x 128 (196 KB) does not fit a workgroup and must be rejected as an

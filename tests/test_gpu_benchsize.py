@@ -1,0 +1,103 @@
+"""Correctness at the size bench.py TIMES (missing #6 / next #2): 6144 pairs = 589 824 tokens per step on one GPU.
+
+The golden-vector and oracle comparisons stop at 176 pairs (the oracle is a CPU program); what can be checked at the bench size are
+size-independent properties through the very kernels, plans and routes the headline runs on:
+  (a) every encoder GEMM of that token count ran on the persistent ping-pong family its plan names -- the library counts the calls
+      it re-routed (uc2_gemm_fallback_count: shape, alignment, or an operand of 4 GiB or more, the 32-bit staging-offset limit);
+  (b) chunk consistency of the forward: the first 176 pairs of the 6144-pair evaluation forward against the same pairs alone;
+  (c) chunk consistency of the backward: dropout-off gradients of the 6144-pair step against the fp32-arena sum of six 1024-pair
+      steps on the same pairs (gradient accumulation is `+=` into the arena: reference pretrain.py:553-559).
+Reference: model/layer.py:159-170 (BertLayer), model/model.py:495-596 (heads)."""
+import pytest
+import torch
+
+from oracle import uc2_oracle as O
+from uc2_amd import ops
+from uc2_amd.model.model import VLXLMRConfig, VLXLMRForPretraining
+from uc2_amd.store import set_compute_dtype, store_of
+from uc2_amd.utils import synth
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+PAIRS, CHUNK, SMALL = 6144, 1024, 176
+T_TXT, N_REG = 60, 36
+
+
+def _batch(B, seed):
+    return {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in synth.make_batch(250002, B, T_TXT, N_REG, task="itm", seed=seed).items()
+            if not k.startswith("_")}
+
+
+def _rows(batch, lo, hi, B):
+    return {k: (v[lo:hi].contiguous() if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B else v) for k, v in batch.items()}
+
+
+def test_bench_size_routes_and_chunk_consistency():
+    torch.cuda.empty_cache()
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 215 * 2 ** 30:
+        pytest.skip("needs ~210 GB of free HBM (bench.py's default step), %.0f GB free" % (free_b / 2 ** 30))
+    d = dict(hidden_act="gelu", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, max_position_embeddings=514,
+             type_vocab_size=2, initializer_range=0.02, layer_norm_eps=1e-5, pad_token_id=1)
+    d.update(O.BASE)
+    model = VLXLMRForPretraining(VLXLMRConfig.from_dict(d), img_dim=2048, img_label_dim=1601)
+    synth.det_init_(model)
+    model.to(DEV).train()
+    set_compute_dtype(model, torch.bfloat16)
+    st = store_of(model)
+    M = PAIRS * (T_TXT + N_REG)
+    # the plans of the timed token count name the ping-pong family for every encoder GEMM (forward, input gradient, weight gradient)
+    for (ta, tb, m, n, k, wg) in [(False, False, M, 2304, 768, False), (False, False, M, 768, 768, False), (False, False, M, 3072, 768, False),
+                                  (False, False, M, 768, 3072, False), (False, False, M, 768, 2304, False),
+                                  (True, True, 2304, 768, M, True), (True, True, 768, 768, M, True), (True, True, 3072, 768, M, True),
+                                  (True, True, 768, 3072, M, True)]:
+        v, sp = ops.gemm_plan(torch.bfloat16, ta, tb, m, n, k, wg)
+        assert v in (8, 9, 12, 13, 14), (ta, tb, m, n, k, v)
+    big = _batch(PAIRS, 21)
+    # ---- (b) forward chunk consistency, evaluation mode
+    model.eval()
+    with torch.no_grad():
+        s_big = model(big, "itm", compute_loss=False)
+        s_small = model(_rows(big, 0, SMALL, PAIRS), "itm", compute_loss=False)
+    s_big = s_big[0] if isinstance(s_big, tuple) else s_big
+    s_small = s_small[0] if isinstance(s_small, tuple) else s_small
+    assert torch.isfinite(s_big).all()
+    dmax = float((s_big[:SMALL].float() - s_small.float()).abs().max())
+    print("bench size: logits of pairs 0..%d inside the %d-pair forward vs alone: max |diff| %.3e" % (SMALL - 1, PAIRS, dmax))
+    assert dmax < 2e-2 and torch.equal(s_big[:SMALL].argmax(-1), s_small.argmax(-1))
+    del s_big, s_small
+    # ---- (a) + (c) the training step's forward + backward at the bench size, dropout off
+    model.train()
+    names = ("roberta.encoder.layer.0.attention.self.query.weight", "roberta.encoder.layer.11.output.dense.weight",
+             "roberta.encoder.layer.5.intermediate.dense.weight", "roberta.img_embeddings.img_linear.weight",
+             "roberta.embeddings.LayerNorm.weight", "roberta.encoder.layer.3.attention.output.dense.bias")
+    params = dict(model.named_parameters())
+    st.zero_grad()
+    ops.gemm_fallbacks(reset=True)
+    loss = model(big, "itm", compute_loss=True)
+    loss = loss[0] if isinstance(loss, tuple) else loss
+    (loss.sum() / PAIRS).backward()
+    torch.cuda.synchronize()
+    fb = ops.gemm_fallbacks()
+    routes = dict(ops.DGRAD_ROUTES)
+    print("bench size: GEMM calls re-routed off their ping-pong plan in one %d-pair forward + backward: %d; input-gradient routes %s"
+          % (PAIRS, fb, sorted(set(v for k, v in routes.items() if k[0] == M))))
+    assert fb == 0
+    assert all(v == "W^T" for k, v in routes.items() if k[0] == M), routes
+    assert torch.isfinite(loss).all()
+    g_big = {n: params[n].grad.detach().float().clone() for n in names}
+    del loss
+    st.zero_grad()
+    torch.cuda.empty_cache()
+    for c in range(PAIRS // CHUNK):
+        lc = model(_rows(big, c * CHUNK, (c + 1) * CHUNK, PAIRS), "itm", compute_loss=True)
+        lc = lc[0] if isinstance(lc, tuple) else lc
+        (lc.sum() / PAIRS).backward()
+    torch.cuda.synchronize()
+    for n in names:
+        e = rel_err(g_big[n], params[n].grad.detach().float())
+        print("bench size: grad %-58s L2 rel (one %d-pair step vs %d x %d-pair steps summed in fp32) %.3e" % (n.split("roberta.")[1], PAIRS, PAIRS // CHUNK, CHUNK, e))
+        assert e < 1e-2, (n, e)
+    del model, big, g_big
+    torch.cuda.empty_cache()

@@ -123,6 +123,15 @@ def test_native_rccl_communicator_single_rank():
             for p, r in zip(m.parameters(), ref):       # adjacent parameters travel as one span: all of it rounds to bf16 once
                 want = (r.to(torch.bfloat16).float() if tail_bf16 else r) / 2.0
                 assert torch.allclose(p.grad, want, rtol=1e-6, atol=0)
+        # default mode "auto": once the store keeps bf16 compute copies (throughput mode) the exposed tail is reduced as bf16
+        st.sync_shadow()
+        for p in m.parameters():
+            st.grad_buf(p).copy_(torch.randn_like(p))
+        ref = [p.grad.clone() for p in m.parameters()]
+        all_reduce_and_rescale_tensors([p.grad.data for p in m.parameters()], 1.0)
+        torch.cuda.synchronize()
+        for p, r in zip(m.parameters(), ref):
+            assert torch.allclose(p.grad, r.to(torch.bfloat16).float(), rtol=1e-6, atol=0)
         broadcast_tensors([p.data for p in m.parameters()], 0)
         torch.cuda.synchronize()
     finally:

@@ -1,7 +1,7 @@
 """diagnostic (not a test): per-parameter bf16 error of one BertLayer against the CPU oracle"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from collections import OrderedDict
 import torch
 from oracle import uc2_oracle as O

@@ -1,4 +1,4 @@
-"""average rocprofv3 --pmc counters per kernel (not a test): python tests/pmc_dump.py <dir> [kernel-substring]"""
+"""average rocprofv3 --pmc counters per kernel (not a test): python tools/pmc_dump.py <dir> [kernel-substring]"""
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):

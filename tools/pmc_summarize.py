@@ -1,6 +1,6 @@
 """Build profiles/rNN_pmc_summary.json from three rocprofv3 --pmc passes (not a test).
 
-    python tests/pmc_summarize.py <round> <dir FETCH_SIZE> <dir WRITE_SIZE> <dir SQ counters> <kernel-substring> [...]
+    python tools/pmc_summarize.py <round> <dir FETCH_SIZE> <dir WRITE_SIZE> <dir SQ counters> <kernel-substring> [...]
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and
 WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads and is doubled.

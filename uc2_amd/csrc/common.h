@@ -95,7 +95,7 @@ __device__ __forceinline__ float dgelu_f(float x) {
 // GELU is ~130 evaluations per lane and output tile, executed with the matrix pipe idle; ocml's erff costs ~45
 // VALU instructions per value (more than the whole K = 768 main loop), this form 9:
 //     Phi(x) ~= sigmoid(x * (c0 + c1 x^2 + c2 x^4)),  |x| clamped to 9 inside the polynomial,
-// an odd-polynomial fit of logit(Phi) (tests/fit_gelu.py): max |Phi error| 4.2e-5, max |gelu error| 2.9e-5 over all
+// an odd-polynomial fit of logit(Phi) (tools/fit_gelu.py): max |Phi error| 4.2e-5, max |gelu error| 2.9e-5 over all
 // x, i.e. ~1/100 of a bf16 ulp at |y| ~ 1.  The fp32 (parity) kernels keep erff / tanhf.
 #define UC2_PHI_C0 1.5951192f
 #define UC2_PHI_C1 0.0739306293f

@@ -411,13 +411,21 @@ extern "C" int uc2_gemm_wgrad_group(int dtype, int n, const Uc2WgradItem* items,
   return 0;
 }
 
+// Calls that named a ping-pong kernel (variant 8 / 9 / 12 / 13) and were run by another one because the shape, an alignment or the
+// 32-bit staging-offset limit (an operand of 4 GiB or more) did not qualify.  Diagnostics only: nothing reads it to select a kernel.
+#include <atomic>
+static std::atomic<long long> g_pp_fallbacks{0};
+extern "C" long long uc2_gemm_fallback_count(int reset) {
+  return reset ? g_pp_fallbacks.exchange(0, std::memory_order_relaxed) : g_pp_fallbacks.load(std::memory_order_relaxed);
+}
+
 static int gemm_impl(int dtype, int trans_a, int trans_b, int M, int N, int K,
                      const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_is_f32,
                      const float* bias, int epilogue, const void* aux_in, void* aux_out, int ldaux,
                      int accumulate, int split_k, int variant, void* workspace, size_t workspace_bytes, int flags,
                      void* queue, void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
-  UC2_CHECK_ARG(variant == -2 || variant == 99 || (variant >= 0 && variant <= 9) || variant == 12);
+  UC2_CHECK_ARG(variant == -2 || variant == 99 || (variant >= 0 && variant <= 9) || variant == 12 || variant == 13 || variant == 14);
   UC2_CHECK_ARG(M >= 0 && N >= 0 && K >= 0);
   UC2_CHECK_ARG(epilogue >= EPI_NONE && epilogue <= EPI_TANH);
   UC2_CHECK_ARG(!((epilogue == EPI_DGELU || epilogue == EPI_ADD) && aux_in == nullptr));
@@ -447,6 +455,7 @@ static int gemm_impl(int dtype, int trans_a, int trans_b, int M, int N, int K,
   p.b_vec = (((uintptr_t)B & 15) == 0) && ((ldb & 7) == 0);
   hipStream_t st = (hipStream_t)stream;
   if (K == 0) { UC2_CHECK_ARG(accumulate); return 0; }
+  UC2_CHECK_ARG(!(p.defer && (dtype == 0 || variant == 99)));    // the fp32 and generic kernels have no two-stage split-K path
   if (dtype == 0) {
     if (!trans_a && !trans_b) launch_f32<false, false>(p, st);
     else if (!trans_a && trans_b) launch_f32<false, true>(p, st);
@@ -455,6 +464,13 @@ static int gemm_impl(int dtype, int trans_a, int trans_b, int M, int N, int K,
   } else {
     const bool want_colsum = (epilogue == EPI_DGELU && aux_out != nullptr);
     const int fast = variant == 99 ? 0 : uc2_gemm_bf16_fast_try(p, trans_a, trans_b, st);
+    if (fast < 0 || (p.defer && fast != 2)) {
+      uc2_set_error(__FILE__, __LINE__, "UC2_GEMM_DEFER_REDUCE: this call cannot leave split-K partial tiles in the workspace (shape / "
+                    "variant / 4 GiB operand limit / workspace); nothing was launched");
+      return -1;
+    }
+    // diagnostic counter (uc2_gemm_fallback_count): an explicit ping-pong plan (variants 8 / 9 / 12 / 13) that another kernel ran
+    if ((variant == 8 || variant == 9 || variant == 12 || variant == 13 || variant == 14) && fast != 2) g_pp_fallbacks.fetch_add(1, std::memory_order_relaxed);
     if (fast) {
       UC2_LAUNCH_CHECK();
       if (want_colsum && fast != 2) return uc2_colsum_accum(1, M, N, C, ldc, nullptr, reinterpret_cast<float*>(aux_out), stream);

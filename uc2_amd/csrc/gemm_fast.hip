@@ -361,6 +361,10 @@ bool uc2_gemm_pp_supported(int trans_a, int trans_b, int c_f32, int epi, int til
 void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st, int tile_rows);
 bool uc2_gemm_pp16_supported(const GemmArgs& p, int trans_a, int trans_b);                       // gemm_pp16.hip
 void uc2_gemm_pp16_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st);
+bool uc2_gemm_p1_supported(const GemmArgs& p, int trans_a, int trans_b);                         // gemm_p1.hip
+void uc2_gemm_p1_launch(const GemmArgs& p, hipStream_t st);
+bool uc2_gemm_p2_supported(const GemmArgs& p, int trans_a, int trans_b);                         // gemm_p2.hip
+void uc2_gemm_p2_launch(const GemmArgs& p, hipStream_t st);
 void uc2_splitk_reduce(const GemmArgs& p, hipStream_t st);                                        // gemm.hip
 
 // ------------------------------------------------------------------------------------------------------
@@ -402,8 +406,31 @@ int uc2_gemm_fp8_launch(const GemmArgs& p8, hipStream_t st) {
   return 0;
 }
 
-// returns 1 if the shape qualifies and the kernel was launched, 0 if the caller must use the generic kernel
+// returns 1 (ring kernel) / 2 (ping-pong family) if the shape qualifies and the kernel was launched, 0 if the caller must use the
+// generic kernel, -1 (nothing launched) if UC2_GEMM_DEFER_REDUCE was asked for and the two-stage split-K path cannot take the call
+static int fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st);
 int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st) {
+  if (p.defer) {
+    // The caller will run the reduction pass itself (uc2_gemm_splitk_reduce / _qkv) on the partial tiles in its workspace: that is
+    // only meaningful when THIS call leaves them there.  Anything else -- a shape the ping-pong kernels do not take, the 32-bit
+    // staging-offset limit, a missing or short workspace -- used to fall through to a kernel that accumulates into C directly, and
+    // the caller's reduction then added stale workspace contents on top.  Refuse instead of computing something else.
+    const int v = p.variant;
+    const bool pp = v == 8 || v == 12 || v == 13 || v == 14;
+    const int ktiles = p.K / 64, per = ((ktiles + p.split_k - 1) / p.split_k + 1) & ~1;
+    const unsigned long long ea = 2ull * (trans_a ? p.K : p.M) * p.lda, eb = 2ull * (trans_b ? p.K : p.N) * p.ldb;
+    const size_t need = (size_t)p.split_k * p.M * p.N * sizeof(float);
+    const bool ok = pp && p.K >= 64 && (p.K % 64) == 0 && p.a_vec && p.b_vec && !(ktiles & 1) && ktiles - (p.split_k - 1) * per >= 2 &&
+                    (p.M % 256) == 0 && (p.N & 255) == 0 && ea < (1ull << 32) && eb < (1ull << 32) &&
+                    (trans_a ? (p.M & 7) == 0 : true) && (trans_b ? (p.N & 7) == 0 : true) &&
+                    p.c_f32 && p.split_k > 1 && p.ws && need <= p.ws_bytes && (p.N & 3) == 0 && (p.ldc & 3) == 0 &&
+                    ((uintptr_t)p.C & 15) == 0 && ((uintptr_t)p.ws & 15) == 0 &&
+                    (uc2_gemm_pp_supported(trans_a, trans_b, p.c_f32, p.epi, 256) || (v != 8 && uc2_gemm_pp16_supported(p, trans_a, trans_b)));
+    if (!ok) return -1;
+  }
+  return fast_try(p, trans_a, trans_b, st);
+}
+static int fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st) {
   if (p.K < 64 || (p.K % 64) != 0) return 0;
   if (!p.a_vec || !p.b_vec) return 0;
   if (trans_a ? ((p.M & 7) != 0 || p.M < 8) : (p.M < 1)) return 0;
@@ -413,7 +440,9 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
   // (variants 10 = rolling epilogue and 11 = two phases per k-tile were measured in round 3, never selected by a plan, and
   //  live under scratch/kernels/ with their result table in DESIGN.md; uc2_gemm rejects the numbers)
   const bool want_pp16 = variant == 12;              // ping-pong kernel on the 16x16x32 MFMA (gemm_pp16.hip)
-  if (want_pp16) variant = 8;
+  const bool want_p1 = variant == 13;                // one wave per SIMD, 128 x 128 per wave (gemm_p1.hip): falls back to variant 12
+  const bool want_p2 = variant == 14;                // ... with the epilogue in the next item's MFMA gaps (gemm_p2.hip): falls back to 12
+  if (want_pp16 || want_p1 || want_p2) variant = 8;
   if (variant == 8 || variant == 9) {
     // ping-pong kernel: whole 256x256 (variant 9: 192x256) tiles, >= 2 k-tiles per split, and (bf16 output) an epilogue
     // made of whole 16-byte accesses; anything else runs on the ring kernels above / the generic kernel
@@ -426,7 +455,7 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
       if (ea >= (1ull << 32) || eb >= (1ull << 32)) return 0;
     }
     if (!uc2_gemm_pp_supported(trans_a, trans_b, p.c_f32, p.epi, rows) &&
-        !(want_pp16 && !p.c_f32 && uc2_gemm_pp16_supported(p, trans_a, trans_b))) return 0;
+        !((want_pp16 || want_p1 || want_p2) && !p.c_f32 && uc2_gemm_pp16_supported(p, trans_a, trans_b))) return 0;
     if (!p.c_f32 && (p.accumulate || (p.ldc & 7) || (p.ldaux & 7) || ((uintptr_t)p.C & 15) ||
                      ((uintptr_t)p.aux_in & 15) || ((uintptr_t)p.aux_out & 15) || ((uintptr_t)p.bias & 15)))
       return 0;
@@ -442,11 +471,13 @@ int uc2_gemm_bf16_fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStrea
     if (p.c_f32 && p.split_k > 1 && p.ws && need <= p.ws_bytes && (p.N & 3) == 0 && (p.ldc & 3) == 0 &&
         ((uintptr_t)p.C & 15) == 0 && ((uintptr_t)p.ws & 15) == 0) {
       pd.partial = p.ws;                             // two-stage: plain partial stores, then one reduction pass
-      if (want_pp16 && uc2_gemm_pp16_supported(pd, trans_a, trans_b)) uc2_gemm_pp16_launch(pd, trans_a, trans_b, st);
+      if ((want_pp16 || want_p1 || want_p2) && uc2_gemm_pp16_supported(pd, trans_a, trans_b)) uc2_gemm_pp16_launch(pd, trans_a, trans_b, st);
       else uc2_gemm_pp_launch(pd, trans_a, trans_b, st, 256);
       if (!p.defer) uc2_splitk_reduce(pd, st);
     } else {
-      if (want_pp16 && uc2_gemm_pp16_supported(pd, trans_a, trans_b)) uc2_gemm_pp16_launch(pd, trans_a, trans_b, st);
+      if (want_p1 && uc2_gemm_p1_supported(pd, trans_a, trans_b)) uc2_gemm_p1_launch(pd, st);
+      else if (want_p2 && uc2_gemm_p2_supported(pd, trans_a, trans_b)) uc2_gemm_p2_launch(pd, st);
+      else if ((want_pp16 || want_p1 || want_p2) && uc2_gemm_pp16_supported(pd, trans_a, trans_b)) uc2_gemm_pp16_launch(pd, trans_a, trans_b, st);
       else uc2_gemm_pp_launch(pd, trans_a, trans_b, st, 256);
     }
     return 2;                                         // (2: the kernel also produced the EPI_DGELU column sums)

@@ -39,7 +39,7 @@
 #include "gemm_pp.h"
 
 #ifndef UC2_PP_DIAG
-#define UC2_PP_DIAG 0            /* 1: build the main-loop diagnostics 0x100 / 0x200 (tests/bench_pp.py) */
+#define UC2_PP_DIAG 0            /* 1: build the main-loop diagnostics 0x100 / 0x200 (tools/bench_pp.py) */
 #endif
 
 template <bool TA, bool TB, bool TACC, int EPI, int HI>

@@ -12,7 +12,7 @@
 #include "gemm_pp16.h"
 
 #ifndef UC2_PP_DIAG
-#define UC2_PP_DIAG 0            /* 1: build the main-loop diagnostics 0x100 / 0x200 (tests/bench_pp.py) */
+#define UC2_PP_DIAG 0            /* 1: build the main-loop diagnostics 0x100 / 0x200 (tools/bench_pp.py) */
 #endif
 
 #ifndef PP16_AUX_TOUCH

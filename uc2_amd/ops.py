@@ -26,9 +26,17 @@ class GemmTimer:
 
     def __init__(self):
         self.groups = {}
+        self.bytes = {}
 
-    def add(self, key, flops, e0, e1):
+    def add(self, key, flops, e0, e1, nbytes=0.0):
+        """nbytes: ALGORITHMIC HBM bytes of the launch -- every operand read once, every result written once (fp32 partial tiles
+        of a split-K launch included; the reduction pass is another kernel)"""
         self.groups.setdefault(key, []).append((flops, e0, e1))
+        self.bytes[key] = self.bytes.get(key, 0.0) + nbytes
+
+    def bytes_per_launch(self):
+        """{kernel name: algorithmic bytes per launch, averaged over the group's launches}"""
+        return {self.kernel_name(k): self.bytes.get(k, 0.0) / max(len(v), 1) for k, v in self.groups.items()}
 
     @staticmethod
     def kernel_name(key):
@@ -39,6 +47,8 @@ class GemmTimer:
         tacc = b(not atomic)
         if variant == 12:
             return "gemm_bf16_pp16_kernel<%s, %s, true, %d, 2>" % (b(ta), b(tb), epi)
+        if variant == 13:
+            return "gemm_bf16_p1_kernel<%d>" % epi
         if variant in (8, 9):
             return "gemm_bf16_pp_kernel<%s, %s, %s, %d, %d>" % (b(ta), b(tb), b(not atomic), epi, 2 if variant == 8 else 1)
         if variant == 99:
@@ -271,12 +281,17 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
         else:
             call("uc2_gemm_splitk_reduce", M, N, ptr(out), ldc, split_k, int(accumulate), ptr(ws), ws.numel(), stream())
     if e0 is not None:
-        if variant in (8, 9, 12):  # ping-pong kernels: transposed accumulators unless fp32 atomics; the epilogue kind is a template argument
+        if variant in (8, 9, 12, 13):  # ping-pong kernels: transposed accumulators unless fp32 atomics; the epilogue kind is a template argument
             epi_t = int(epi) + 4 if (flags & GEMM_AUX_DERIV and epi in (EPI_GELU, EPI_DGELU)) else int(epi)   # EPI_GELU_D = 5, EPI_MUL = 6
             key = (bool(ta), bool(tb), variant, bool(c_f32 and not two_stage), epi_t)
         else:
             key = (bool(ta), bool(tb), variant, bool(c_f32 and split_k > 1), 0)
-        timer.add(key, 2.0 * M * N * K, e0, e1)
+        esz = a.element_size()
+        nbytes = esz * (M * K + N * K) + out.element_size() * M * N * (split_k if two_stage else (2 if accumulate else 1))
+        for x in (aux_in, aux_out):
+            if x is not None:
+                nbytes += x.element_size() * x.numel()
+        timer.add(key, 2.0 * M * N * K, e0, e1, float(nbytes))
     return out
 
 
@@ -312,6 +327,12 @@ def _wgrad_split(dtype, n_out, n_in, rows):
 # ---- per-shape kernel selection: measured once per (layout, shape) on the device, then cached ----------
 AUTOTUNE = True
 _TUNE = {}
+_BORROWED = {}            # shapes without a measured plan that run on the plan of the nearest tuned token count (linear_dgrad)
+
+
+def gemm_fallbacks(reset=False):
+    """calls since load (or the last reset) whose plan named a ping-pong kernel but ran on another one (library counter)"""
+    return int(_lib.load().uc2_gemm_fallback_count(int(bool(reset))))
 _MAX_TUNED = 256          # cap on tuned shapes (each tuning costs ~30 candidates x 7 launches + a host sync)
 
 
@@ -325,10 +346,15 @@ def _plan_fits(plan, key):
     """can the kernel of `plan` run the shape `key` (else the library would silently take its generic kernel)"""
     v, sp = plan
     ta, tb, M, N, K, wgrad = key
-    if v in (8, 9, 12):
+    if v in (8, 9, 12, 13):
         rows = 192 if v == 9 else 256
         kt = K // 64
         per = ((kt + sp - 1) // sp + 1) & ~1
+        # 32-bit staging offsets: an operand of 4 GiB or more does not run on the ping-pong kernels (gemm_fast.hip); contiguous
+        # operands assumed here -- the library re-checks with the real leading dimensions, counts what it re-routes
+        # (uc2_gemm_fallback_count) and refuses a UC2_GEMM_DEFER_REDUCE call it cannot honour
+        if 2 * M * K >= 1 << 32 or 2 * N * K >= 1 << 32:
+            return False
         return M % rows == 0 and N % 256 == 0 and K % 128 == 0 and kt - (sp - 1) * per >= 2
     if wgrad and sp * 1024 > K:
         return False
@@ -576,7 +602,7 @@ def linear_dgrad(dy2, w, epi=EPI_NONE, aux_in=None, colsum_out=None, flags=0, wt
     route = "W"
     if wt is not None:
         key = (False, False, M, K, N, False)
-        hit = _TUNE.get(key) or _TUNE.get(_bucket_key(key))
+        hit = _TUNE.get(key) or _TUNE.get(_bucket_key(key)) or _BORROWED.get(key)
         if hit is None and M >= DGRAD_WT_MIN_ROWS:
             # no plan for this token count: take the plan of the nearest tuned token count of the same (N, K) -- above the
             # threshold the choice between the kernels does not depend on M any more (every committed plan there is variant 12)
@@ -584,13 +610,15 @@ def linear_dgrad(dy2, w, epi=EPI_NONE, aux_in=None, colsum_out=None, flags=0, wt
                     and k[2] >= DGRAD_WT_MIN_ROWS]
             if near:
                 hit = min(near, key=lambda t: t[0])[1]
-                _TUNE[key] = hit
+                _BORROWED[key] = hit                    # not a measured plan: kept out of _TUNE (save_plans, bench.py's gemm_plans)
         if hit is not None and hit[0] == 12 and _plan_fits(hit, key):
             route = "W^T"
     if wt is not None:
         DGRAD_ROUTES[(M, K, N, int(epi))] = route
     if route == "W^T":
-        return gemm(dy2, wt, M, K, N, split_k=1, variant=12, epi=epi, aux_in=aux_in, aux_out=colsum_out, flags=flags)
+        if PP_SKEW:
+            flags |= (PP_SKEW.get(epi, 0) & 15) << 4
+        return gemm(dy2, wt, M, K, N, split_k=1, variant=hit[0], epi=epi, aux_in=aux_in, aux_out=colsum_out, flags=flags)
     return _gemm_planned(dy2, w, M, K, N, False, True, epi=epi, aux_in=aux_in, aux_out=colsum_out, flags=flags)
 
 

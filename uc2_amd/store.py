@@ -327,6 +327,11 @@ def compute_dtype_of(module):
     return module.__dict__.get("compute_dtype", torch.float32)
 
 
+def compute_dtype_of_store(st):
+    """bfloat16 once the store keeps bf16 compute copies of its parameters (throughput mode), float32 otherwise (parity mode)"""
+    return torch.bfloat16 if st.shadow is not None else torch.float32
+
+
 def set_fp8(module, on=True):
     """fp8 (e4m3) operands for the forward and input-gradient GEMMs of every BertLayer under `module` (bf16 compute
     dtype required; weight gradients, attention, LayerNorm and the heads stay bf16 / fp32): BASELINE.json configs[4]"""

@@ -17,12 +17,25 @@ import torch.distributed as dist
 
 from .. import _lib
 
-# The gradient tail (embeddings + heads: 0.77 GB of fp32, final only when backward ends, so its all-reduce is exposed)
-# CAN be reduced as bf16 on the GPU data paths (UC2_ALLREDUCE_TAIL=bf16) -- the reference reduces fp16 gradients too (apex
-# O2 + Horovod, pretrain.py:557-566) -- but bf16 carries three mantissa bits fewer than fp16, and no run with more than
-# one rank has compared it with the fp32 reduction yet: the default is the fp32 reduction, bf16 is opt-in.
-# Encoder-layer buckets overlap with backward and are always fp32.
-TAIL_BF16 = os.environ.get("UC2_ALLREDUCE_TAIL", "fp32") == "bf16"
+# The gradient tail (embeddings + heads: 0.77 GB of fp32, final only when backward ends, so its all-reduce is exposed) is
+# reduced as bf16 on the GPU data paths when the model COMPUTES in bf16 (UC2_ALLREDUCE_TAIL=auto, the default): half the bytes
+# of the one collective nothing overlaps.  The reference reduces fp16 gradients throughout (apex O2 + Horovod, pretrain.py:557-566);
+# here only the tail is rounded (8 significant bits; the sum over ranks is taken by RCCL in bf16, the result is cast back and
+# the fp32 master gradients of the encoder layers are never rounded), and only in the mode whose activations and weight copies
+# are bf16 anyway.  fp32 parity mode always reduces fp32; UC2_ALLREDUCE_TAIL=fp32 / bf16 force either.  No run with more than
+# one rank has compared the two yet (one GPU per lease): INTEGRATION.md, behavioural notes.
+_TAIL_MODE = os.environ.get("UC2_ALLREDUCE_TAIL", "auto")
+TAIL_BF16 = _TAIL_MODE == "bf16"                 # (kept as a module attribute: tests and tools flip it)
+COMM_TIMER = None                # bench.py: a list that receives (start, end) HIP events around the EXPOSED part of the gradient all-reduce
+
+
+def _tail_bf16(st):
+    if _TAIL_MODE == "auto" and not TAIL_BF16:
+        from ..store import compute_dtype_of_store
+        return compute_dtype_of_store(st) == torch.bfloat16
+    return TAIL_BF16
+
+
 _TAIL_MIN = 1 << 20              # elements; smaller spans are not worth two cast passes
 
 
@@ -267,9 +280,18 @@ def all_reduce_and_rescale_tensors(tensors, rescale_denom):
         if sync is not None:
             sync.merge_into(red)
             views.extend(sync.take_views())
+    timer = COMM_TIMER
+    if timer is not None and tensors[0].is_cuda:
+        # from here on nothing of this step's compute is left to overlap with: what the stream waits for below is exposed
+        e_exp0, e_exp1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e_exp0.record()
+    else:
+        e_exp0 = None
     if W > 1 or NativeComm.active:
+        tail_half = any(_tail_bf16(st) for st, _ in by_store.values())
+
         def half(v):
-            return TAIL_BF16 and v.is_cuda and v.numel() >= _TAIL_MIN and \
+            return tail_half and v.is_cuda and v.numel() >= _TAIL_MIN and \
                 (NativeComm.active or dist.get_backend() == "nccl")
         n_half = sum((v.numel() + 63) // 64 * 64 for v in todo if half(v))
         stage = _tail_stage(todo[0].device, n_half) if n_half else None
@@ -296,6 +318,9 @@ def all_reduce_and_rescale_tensors(tensors, rescale_denom):
     red.finish(1.0)
     for v, h in staged:
         _lib.call("uc2_cast", 1, 0, v.numel(), _lib.ptr(h), _lib.ptr(v), _lib.stream())
+    if e_exp0 is not None:
+        e_exp1.record()
+        timer.append((e_exp0, e_exp1))
     scale = 1.0 / rescale_denom
     for v in views:
         _scale_(v, scale)
