@@ -103,6 +103,12 @@ def start_watchdog(n_gpus):
                 sys.stderr.write("bench.py rank %s: no progress for %.0f s -- giving up\n" % (os.environ.get("RANK", "0"), limit))
                 faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
                 sys.stderr.flush()
+                try:                                   # abort, never destroy, a communicator whose peers may sit in a collective
+                    from uc2_amd.utils.distributed import NativeComm
+                    NativeComm.mark_failed()
+                    NativeComm.abort()
+                except Exception:                      # noqa: BLE001
+                    pass
                 os._exit(3)
     threading.Thread(target=watch, daemon=True).start()
     return beat
@@ -697,6 +703,12 @@ def main():
                                             if gtimer_tr.summary() else 0.0)) if overlapped else "the timed region"},
             "workloads": workloads,
         }
+        # the headline configuration of rounds 1-3 (1024 pairs per step) at top level too: round-over-round comparable
+        w1024 = workloads.get("%s_1024_pairs_per_step" % a.task)
+        if a.batch == 1024:
+            out["value_at_1024_pairs_per_step"] = {"pairs_per_s": out["value"], "mfma_frac_encoder": out["mfma_frac_encoder"]}
+        elif w1024:
+            out["value_at_1024_pairs_per_step"] = {"pairs_per_s": w1024["pairs_per_s"], "mfma_frac_encoder": w1024["mfma_frac_encoder"]}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.layers)
         print(json.dumps(out), flush=True)

@@ -65,7 +65,7 @@ def test_bench_size_routes_and_chunk_consistency():
     assert torch.isfinite(s_big).all()
     dmax = float((s_big[:SMALL].float() - s_small.float()).abs().max())
     print("bench size: logits of pairs 0..%d inside the %d-pair forward vs alone: max |diff| %.3e" % (SMALL - 1, PAIRS, dmax))
-    assert dmax < 2e-2 and torch.equal(s_big[:SMALL].argmax(-1), s_small.argmax(-1))
+    assert dmax < 2e-3 and torch.equal(s_big[:SMALL].argmax(-1), s_small.argmax(-1))      # measured: 0.0 (both sizes run the same kernels; rows are independent)
     del s_big, s_small
     # ---- (a) + (c) the training step's forward + backward at the bench size, dropout off
     model.train()
@@ -98,6 +98,6 @@ def test_bench_size_routes_and_chunk_consistency():
     for n in names:
         e = rel_err(g_big[n], params[n].grad.detach().float())
         print("bench size: grad %-58s L2 rel (one %d-pair step vs %d x %d-pair steps summed in fp32) %.3e" % (n.split("roberta.")[1], PAIRS, PAIRS // CHUNK, CHUNK, e))
-        assert e < 1e-2, (n, e)
+        assert e < 1e-4, (n, e)            # measured 6e-8 .. 8e-7: the two differ only in the fp32 summation order of the weight gradients
     del model, big, g_big
     torch.cuda.empty_cache()

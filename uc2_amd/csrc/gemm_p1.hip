@@ -112,6 +112,42 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_p1_kernel(GemmArgs p) {
 #define P1_RD(DST, FBASE, BUF, UNIT, G, ON)                                                                     \
   do { if (ON) { if (((G) >> 2) == 0) pp16_read<false, (G) & 3, 0, (UNIT) * PP_UNIT>(DST[(G) & 3][0], FBASE[BUF][0]);          \
                  else pp16_read<false, (G) & 3, 1, (UNIT) * PP_UNIT>(DST[(G) & 3][1], FBASE[BUF][1]); } } while (0)
+#ifndef P1_READS_EARLY
+#define P1_READS_EARLY 1
+#endif
+  // two MFMAs then one fragment read (first half of a phase: the reads have 16 MFMAs to come back before the next phase's wait)
+#define P1_PAIR(I, AH, BH, AREG, BREG, RD)                                                                      \
+  do {                                                                                                         \
+    P1_MF(AH, BH, AREG, BREG, I); P1_MF(AH, BH, AREG, BREG, (I) + 1);                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    RD;                                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  } while (0)
+  // four MFMAs then one LDS-DMA piece (second half)
+#define P1_QUAD(I, AH, BH, AREG, BREG, DM)                                                                      \
+  do {                                                                                                         \
+    P1_MF(AH, BH, AREG, BREG, I); P1_MF(AH, BH, AREG, BREG, (I) + 1); P1_MF(AH, BH, AREG, BREG, (I) + 2); P1_MF(AH, BH, AREG, BREG, (I) + 3); \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    DM;                                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  } while (0)
+#if P1_READS_EARLY
+#define P1_PHASE(AH, BH, AREG, BREG, RDST, RBASE, RBUF, RUNIT, RON, DU, DBUF, DKOFF, DON)                         \
+  do {                                                                                                         \
+    P1_PAIR(0, AH, BH, AREG, BREG, P1_RD(RDST, RBASE, RBUF, RUNIT, 0, RON));                                    \
+    P1_PAIR(2, AH, BH, AREG, BREG, P1_RD(RDST, RBASE, RBUF, RUNIT, 1, RON));                                    \
+    P1_PAIR(4, AH, BH, AREG, BREG, P1_RD(RDST, RBASE, RBUF, RUNIT, 2, RON));                                    \
+    P1_PAIR(6, AH, BH, AREG, BREG, P1_RD(RDST, RBASE, RBUF, RUNIT, 3, RON));                                    \
+    P1_PAIR(8, AH, BH, AREG, BREG, P1_RD(RDST, RBASE, RBUF, RUNIT, 4, RON));                                    \
+    P1_PAIR(10, AH, BH, AREG, BREG, P1_RD(RDST, RBASE, RBUF, RUNIT, 5, RON));                                   \
+    P1_PAIR(12, AH, BH, AREG, BREG, P1_RD(RDST, RBASE, RBUF, RUNIT, 6, RON));                                   \
+    P1_PAIR(14, AH, BH, AREG, BREG, P1_RD(RDST, RBASE, RBUF, RUNIT, 7, RON));                                   \
+    P1_QUAD(16, AH, BH, AREG, BREG, do { if (DON) P1_DMA(DU, 0, DBUF, DKOFF); } while (0));                      \
+    P1_QUAD(20, AH, BH, AREG, BREG, do { if (DON) P1_DMA(DU, 1, DBUF, DKOFF); } while (0));                      \
+    P1_QUAD(24, AH, BH, AREG, BREG, do { if (DON) P1_DMA(DU, 2, DBUF, DKOFF); } while (0));                      \
+    P1_QUAD(28, AH, BH, AREG, BREG, do { if (DON) P1_DMA(DU, 3, DBUF, DKOFF); } while (0));                      \
+  } while (0)
+#else
 #define P1_PHASE(AH, BH, AREG, BREG, RDST, RBASE, RBUF, RUNIT, RON, DU, DBUF, DKOFF, DON)                         \
   do {                                                                                                         \
     P1_GROUP(0, AH, BH, AREG, BREG, P1_RD(RDST, RBASE, RBUF, RUNIT, 0, RON), (void)0);                           \
@@ -123,6 +159,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_p1_kernel(GemmArgs p) {
     P1_GROUP(6, AH, BH, AREG, BREG, P1_RD(RDST, RBASE, RBUF, RUNIT, 6, RON), (void)0);                           \
     P1_GROUP(7, AH, BH, AREG, BREG, P1_RD(RDST, RBASE, RBUF, RUNIT, 7, RON), do { if (DON) P1_DMA(DU, 3, DBUF, DKOFF); } while (0)); \
   } while (0)
+#endif
 #define P1_LGKM0() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define P1_BARRIER() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 
@@ -263,6 +300,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_p1_kernel(GemmArgs p) {
 #undef P1_DMA
 #undef P1_MF
 #undef P1_GROUP
+#undef P1_PAIR
+#undef P1_QUAD
 #undef P1_RD
 #undef P1_RD8
 #undef P1_PHASE

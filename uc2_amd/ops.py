@@ -1153,7 +1153,13 @@ class BertLayerFn(torch.autograd.Function):
             # four dW GEMMs.  The hook's all-reduce waits for both streams itself (ops.pending_side_stream ->
             # uc2_comm_allreduce_bucket_after); joining the side stream into the main stream here (round 3) serialised every
             # layer boundary of the main stream behind that layer's weight-gradient GEMMs exactly when N > 1.
-            flush_ln_reductions(end_of_pass=False)      # (small batches: the layer's LayerNorm sums are still pending)
+            # (small batches: the layer's LayerNorm sums are still pending -- but only flush them per layer when the hook is about to
+            #  start a reduction: with an unarmed GradSync, or one rank and no communicator, that would undo the one-launch batching
+            #  of every non-final micro-step)
+            owner = getattr(hook, "__self__", None)
+            will = getattr(owner, "will_reduce", None)
+            if will is None or will():
+                flush_ln_reductions(end_of_pass=False)
             hook(ctx.layer)
         return (dx, None, None, None) + (None,) * len(ctx.params)
 

@@ -86,6 +86,14 @@ class NativeComm:
     _failing = False
 
     @classmethod
+    def mark_failed(cls):
+        """call on ANY abnormal way out of the training loop (non-zero sys.exit, a watchdog, SIGTERM handler, an exception caught
+        and re-raised in a worker thread): the exit handler then aborts the communicator (ncclCommAbort) instead of destroying it --
+        ncclCommDestroy can block for ever while peers sit in a collective.  sys.excepthook alone only sees uncaught exceptions of
+        the main thread.  Nothing is re-executed; the process still ends with the caller's exit code."""
+        cls._failing = True
+
+    @classmethod
     def _at_exit(cls):
         if cls._failing:
             cls.abort()
@@ -379,8 +387,12 @@ class GradSync:
         self.armed = True
         self._red, self._views, self._done = _Reducer(), [], []
 
+    def will_reduce(self):
+        """True when the next layer-done hook starts an all-reduce (armed, and there is somebody to reduce with)"""
+        return self.armed and (_world() > 1 or NativeComm.active)
+
     def _on_layer_done(self, layer):
-        if not self.armed or (_world() == 1 and not NativeComm.active):
+        if not self.will_reduce():
             return
         st = self.st
         ps = list(layer.parameters())
