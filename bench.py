@@ -50,12 +50,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=6144, help="pairs per GPU per step.  Round 4: 6144 = 589 824 tokens, 187 GB of the 288 GB "
-                                                            "(30.7 GB of saved activations per 1024 pairs).  The optimizer pass over 280 M "
-                                                            "parameters, the split-K reductions, the weight copies and ~450 launch gaps are per "
-                                                            "step, not per pair (~5.6 ms): same box, 2048 / 3072 / 4096 / 6144 / 8192 pairs: "
-                                                            "0.369 / 0.373 / 0.378 / 0.382 / 0.329 of the bf16 peak (8192 = 267 GB reserved: the "
-                                                            "allocator starts to struggle)")
+    ap.add_argument("--batch", type=int, default=6144, help="pairs per GPU per step.  6144 = 589 824 tokens, 187 GB of the 288 GB (30.7 GB of saved "
+                                                            "activations per 1024 pairs).  The optimizer pass over 280 M parameters, the split-K "
+                                                            "reductions, the weight copies and ~450 launch gaps are per step, not per pair (~5.6 ms): "
+                                                            "same box, 2048 / 3072 / 4096 / 6144 pairs: 0.369 / 0.373 / 0.378 / 0.382 of the bf16 peak.  "
+                                                            "8192 pairs (0.329) is NOT an allocator effect as round 4 wrote: at 786 432 tokens the "
+                                                            "[tokens, 3072] bf16 operands are 4.8 GB, past the ping-pong kernels' 32-bit staging offsets, "
+                                                            "and those GEMMs run on the ring / generic kernels -- config.gemm_fallbacks counts such calls "
+                                                            "(0 at the default)")
     ap.add_argument("--task", default="itm", choices=["itm", "mlm"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the MLM and reference-regime workloads")
