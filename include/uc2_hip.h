@@ -112,8 +112,11 @@ int uc2_gemm_wgrad_group(int dtype, int n, const Uc2WgradItem* items, int rows, 
  *   per-tensor power-of-two scales, all on the device: amax (zero the 4-byte cell first; several tensors may share it)
  *   -> scale = 2^floor(log2(448/amax)) -> x8 = sat_e4m3(x * scale) [transpose != 0: out[c][r], the k-contiguous copy of
  *   W^T for dX = dY W] -> C = epi((A8 . B8^T) / (*scale_a * *scale_b) + bias) in bf16, fp32 accumulation on
- *   v_mfma_scale_f32_32x32x64_f8f6f4.  A8 [M,K], B8 [N,K], K % 128 == 0, lda/ldb % 16 == 0.  Weight gradients stay
- *   bf16 (uc2_gemm).  flags: UC2_GEMM_AUX_DERIV as for uc2_gemm. */
+ *   v_mfma_scale_f32_16x16x128_f8f6f4 (whole 256 x 256 tiles, K % 256 == 0: the persistent ping-pong schedule of variant 12 on
+ *   e4m3 operands, gemm_pp8.hip) or v_mfma_scale_f32_32x32x64_f8f6f4 (any shape: the LDS-DMA ring kernel).  A8 [M,K], B8 [N,K],
+ *   K % 128 == 0, lda/ldb % 16 == 0.  Weight gradients stay bf16 (uc2_gemm).  flags: UC2_GEMM_AUX_DERIV as for uc2_gemm;
+ *   UC2_GEMM_FP8_RING forces the ring kernel. */
+enum { UC2_GEMM_FP8_RING = 4 };
 int uc2_fp8_amax(int dtype, size_t n, const void* x, void* amax_bits, void* stream);
 int uc2_fp8_scale(const void* amax_bits, float* scale, void* stream);
 int uc2_fp8_quant(int dtype, int rows, int cols, const void* x, int ldx, const float* scale, void* out, int ldo,
@@ -121,6 +124,19 @@ int uc2_fp8_quant(int dtype, int rows, int cols, const void* x, int ldx, const f
 /* the same with the scale derived from the amax cell inside the kernel and written to *scale_out (one launch less per tensor) */
 int uc2_fp8_quant_amax(int dtype, int rows, int cols, const void* x, int ldx, const void* amax_bits, float* scale_out,
                        void* out, int ldo, int transpose, void* stream);
+/* delayed scaling, ONE pass over x: quantise with half the scale of *amax_prev (the maximum this tensor role had at its previous use;
+ * twice that maximum stays representable, e4m3 saturates beyond) while accumulating max |x| into *amax_next for the next use, and
+ * clear *amax_clear for the use after that -- three distinct 4-byte cells the caller rotates per tensor role. */
+int uc2_fp8_quant_delayed(int dtype, int rows, int cols, const void* x, int ldx, const void* amax_prev, void* amax_next,
+                          void* amax_clear, float* scale_out, void* out, int ldo, void* stream);
+/* uc2_gemm_fp8 whose epilogue also writes the e4m3 copy of its OUTPUT for the GEMM that consumes it (FFN1 -> FFN2: gelu(.); the input
+ * gradients FFN2 -> FFN1: dY W x gelu') with delayed scaling as uc2_fp8_quant_delayed -- no quantisation pass over the [rows, 4H] tensor.
+ * Ping-pong kernel only: returns -2 (nothing launched) for shapes it does not take and for epilogues other than GELU / DGELU with
+ * UC2_GEMM_AUX_DERIV; the caller then runs uc2_gemm_fp8 and a quantisation pass. */
+int uc2_gemm_fp8_q(int M, int N, int K, const void* A8, int lda, const void* B8, int ldb, const float* scale_a,
+                   const float* scale_b, void* C, int ldc, const float* bias, int epilogue, const void* aux_in, void* aux_out,
+                   int ldaux, int flags, void* q_out, int ldq, const void* amax_prev, void* amax_next, void* amax_clear,
+                   float* q_scale_out, void* stream);
 int uc2_gemm_fp8(int M, int N, int K, const void* A8, int lda, const void* B8, int ldb, const float* scale_a,
                  const float* scale_b, void* C, int ldc, const float* bias, int epilogue, const void* aux_in, void* aux_out,
                  int ldaux, int flags, void* stream);

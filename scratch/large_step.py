@@ -19,8 +19,9 @@ st = store_of(model); st.sync_shadow(); st.auto_sync = False
 uc2_amd.set_fp8(model, sys.argv[1] == "fp8")
 b = bench.synth_batch(256, "itm", 3, dev, 80, 50)
 import time
-for i in range(6):
-    if i == 3:
+N = int(os.environ.get("STEPS", "8"))
+for i in range(N + 4):
+    if i == 4:
         torch.cuda.synchronize(); t0 = time.perf_counter()
     loss = model(b, "itm", compute_loss=True)
     loss = loss[0] if isinstance(loss, tuple) else loss
@@ -28,4 +29,4 @@ for i in range(6):
     _, coef = clip_grad_norm_([p for p in model.parameters() if p.grad is not None], 5.0, fused=True)
     opt.step(grad_scale=coef, zero_grad=True)
 torch.cuda.synchronize()
-print(sys.argv[1], "ms/step", (time.perf_counter() - t0) / 3 * 1e3)
+print(sys.argv[1], "delayed=%s" % os.environ.get("UC2_FP8_DELAYED", "1"), "ms/step %.2f" % ((time.perf_counter() - t0) / N * 1e3), "loss %.4f" % float(loss.mean()))

@@ -1152,3 +1152,98 @@ def test_gemm_operand_of_4_gib_is_rerouted_counted_and_correct():
     assert torch.equal(out2[:512].view(torch.int16), ops.gemm(a[:512], b, 512, N, K, bias=bias, variant=12).view(torch.int16))
     del a, out, out2
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (512, 768, 1024), (33280 // 256 * 256, 3072, 1024), (4096, 1024, 4096), (2048, 4096, 1024)])
+@pytest.mark.parametrize("epi", ["none", "gelu_d", "add", "mul"])
+def test_gemm_fp8_pingpong_vs_dequantised_reference_and_ring_kernel(M, N, K, epi):
+    """gemm_pp8.hip: the persistent ping-pong schedule on v_mfma_scale_f32_16x16x128_f8f6f4 (whole 256 x 256 tiles, K % 256 == 0; what
+    uc2_gemm_fp8 runs for the uc2-large shapes) against a float matmul of the dequantised operands -- operand byte layout, the
+    de-scaling (accumulators start at bias / alpha), every fused epilogue with its second stream / aux tile / column sums -- and
+    against the ring kernel (UC2_GEMM_FP8_RING) on the same bytes.  NaN-filled outputs, two launches (race screen)."""
+    x = rnd((M, K), 1, 1.3, dtype=torch.bfloat16)
+    w = rnd((N, K), 2, 0.03, dtype=torch.bfloat16)
+    bias = rnd((N,), 3) if epi in ("none", "gelu_d") else None
+    aux = rnd((M, N), 4, dtype=torch.bfloat16)
+    x8, sx = ops.fp8_quantize(x)
+    w8, sw = ops.fp8_quantize(w)
+    pre = (x8.view(torch.float8_e4m3fn).float() / sx) @ (w8.view(torch.float8_e4m3fn).float() / sw).t() + (0 if bias is None else bias)
+    code = {"none": ops.EPI_NONE, "gelu_d": ops.EPI_GELU, "add": ops.EPI_ADD, "mul": ops.EPI_DGELU}[epi]
+    fl = ops.GEMM_AUX_DERIV if epi in ("gelu_d", "mul") else 0
+
+    def run(extra):
+        second = None
+        if epi == "gelu_d":
+            second = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        elif epi == "mul":
+            second = torch.zeros(N, dtype=torch.float32, device=DEV)
+        out = ops.gemm_fp8(x8, sx, w8, sw, bias=bias, epi=code, aux_in=aux if epi in ("add", "mul") else None, aux_out=second, flags=fl | extra)
+        return out, second
+    ring, ring2 = run(4)                                   # UC2_GEMM_FP8_RING
+    first = None
+    for _ in range(2):
+        out, second = run(0)
+        assert torch.isfinite(out.float()).all()
+        if first is None:
+            first = out
+        else:
+            assert torch.equal(out.view(torch.int16), first.view(torch.int16))
+        assert rel_err(out.float(), ring.float()) < 3e-3
+    if epi == "none":
+        want, want2 = pre, None
+    elif epi == "gelu_d":
+        p_ = pre.clone().requires_grad_(True)
+        want = torch.nn.functional.gelu(p_)
+        want.sum().backward()
+        want, want2 = want.detach(), p_.grad
+    elif epi == "add":
+        want, want2 = pre + aux.float(), None
+    else:
+        want = pre * aux.float()
+        want2 = want.sum(0)
+    assert rel_err(out.float(), want) < 4e-3
+    if want2 is not None:
+        assert rel_err(second.float(), want2) < (4e-3 if epi == "gelu_d" else 2e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 512, 256), (16640, 4096, 1024), (16640, 1024, 4096)])
+@pytest.mark.parametrize("epi", ["gelu_d", "mul"])
+def test_gemm_fp8_fused_e4m3_output_stream(M, N, K, epi):
+    """uc2_gemm_fp8_q: the ping-pong e4m3 GEMM whose epilogue also writes the e4m3 copy of its output for the next GEMM (delayed
+    scaling): q8 / scale equals the bf16 output to e4m3 resolution, the scale is half the just-in-time scale of the previous maximum,
+    the next-maximum cell receives max |output|, the third cell is cleared; the bf16 outputs equal the plain call's bit for bit."""
+    from uc2_amd import _lib
+    x = rnd((M, K), 1, 1.3, dtype=torch.bfloat16)
+    w = rnd((N, K), 2, 0.03, dtype=torch.bfloat16)
+    bias = rnd((N,), 3) if epi == "gelu_d" else None
+    aux = rnd((M, N), 4, dtype=torch.bfloat16)
+    x8, sx = ops.fp8_quantize(x)
+    w8, sw = ops.fp8_quantize(w)
+    code = ops.EPI_GELU if epi == "gelu_d" else ops.EPI_DGELU
+
+    def second():
+        return torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV) if epi == "gelu_d" else torch.zeros(N, dtype=torch.float32, device=DEV)
+    s_plain = second()
+    plain = ops.gemm_fp8(x8, sx, w8, sw, bias=bias, epi=code, aux_in=aux if epi == "mul" else None, aux_out=s_plain, flags=ops.GEMM_AUX_DERIV)
+    amax_true = float(plain.float().abs().max())
+    key = ("test", M, N, K, epi)
+    cells = torch.zeros(3, dtype=torch.int32, device=DEV)
+    cells[0] = torch.tensor(amax_true * 0.7, device=DEV).view(torch.int32)        # "previous maximum": 0.7 of the real one
+    cells[2] = 12345                                                            # must be cleared
+    ops._FP8_HIST[key] = [cells, 0]
+    s_q = second()
+    r = ops.gemm_fp8_q(x8, sx, w8, sw, key, bias=bias, epi=code, aux_in=aux if epi == "mul" else None, aux_out=s_q, flags=ops.GEMM_AUX_DERIV)
+    assert r is not None
+    out, (q8, qs) = r
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), plain.view(torch.int16))
+    assert rel_err(s_q.float(), s_plain.float()) < (1e-6 if epi == "gelu_d" else 1e-4)
+    want_scale = 2.0 ** math.floor(math.log2(448.0 / (amax_true * 0.7))) * 0.5
+    assert float(qs) == want_scale
+    deq = q8.view(torch.float8_e4m3fn).float() / qs
+    assert rel_err(deq, out.float()) < 0.04                                    # 3 mantissa bits
+    assert float(deq.abs().max()) <= 448.0 / want_scale
+    got_next = float(cells[1:2].view(torch.float32))
+    assert abs(got_next - amax_true) <= 1e-2 * amax_true
+    assert int(cells[2]) == 0 and ops._FP8_HIST[key][1] == 1
+    del ops._FP8_HIST[key]

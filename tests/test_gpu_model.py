@@ -676,6 +676,42 @@ def test_large_geometry_fp8_vs_golden():
     torch.cuda.empty_cache()
 
 
+def test_large_geometry_fp8_pingpong_kernels_and_delayed_scaling_vs_bf16():
+    """configs[4] at a token count where the e4m3 GEMMs run on the ping-pong kernel (128 pairs x 130 = 16 640 = 65 x 256 tokens;
+    gemm_pp8.hip) -- first step with just-in-time scales, second and third with delayed scaling (one-pass quantisation with half the
+    scale of the previous use's maximum, uc2_fp8_quant_delayed) -- against the bf16 path on the same weights and batch: mean loss,
+    ITM labels, last-layer gradient.  fp8 resolution (3 mantissa bits per operand): the bounds are those of the golden-vector test."""
+    model = build_pretrain(O.LARGE, torch.bfloat16)
+    batch = to_dev(synth.make_batch(250002, 128, 80, 50, task="itm", seed=3))
+    name = "roberta.encoder.layer.23.output.dense.weight"
+    P = dict(model.named_parameters())
+    st = uc2_amd.store.store_of(model)
+
+    def step():
+        st.zero_grad()
+        loss, scores = None, None
+        out = model(batch, "itm", compute_loss=False)
+        scores = out[0] if isinstance(out, tuple) else out
+        loss = model(batch, "itm", compute_loss=True)
+        loss = loss[0] if isinstance(loss, tuple) else loss
+        loss.mean().backward()
+        torch.cuda.synchronize()
+        return float(loss.mean()), scores.float().argmax(-1).cpu(), P[name].grad.detach().float().clone()
+    l16, lab16, g16 = step()
+    uc2_amd.set_fp8(model, True)
+    n_hist = len(ops._FP8_HIST)
+    for i in range(3):
+        l8, lab8, g8 = step()
+        e_l, e_g = abs(l8 - l16) / abs(l16), rel_err(g8, g16)
+        agree = float((lab8 == lab16).float().mean())
+        print("large fp8 (ping-pong kernels, %s scales) vs bf16 at 128 pairs: mean-loss rel %.3g, ITM label agreement %.3f, last-layer grad L2 rel %.3g"
+              % ("just-in-time" if i == 0 else "delayed", e_l, agree, e_g))
+        assert e_l < 3e-2 and agree >= 0.97 and e_g < 0.35
+    assert len(ops._FP8_HIST) > n_hist            # the tensor roles have a history: steps 2 and 3 took the one-pass route
+    del model
+    torch.cuda.empty_cache()
+
+
 def test_submodule_forwards_compose_to_the_fused_layer():
     """BertSelfAttention / BertSelfOutput / BertAttention / BertIntermediate / BertOutput have working forward()s
     (model/layer.py:75-156); composed the reference's way they reproduce the fused BertLayerFn node bit for bit in

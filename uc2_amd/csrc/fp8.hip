@@ -83,6 +83,51 @@ __global__ __launch_bounds__(256) void fp8_quant_t_kernel(int rows, int cols, co
   }
 }
 
+// Delayed scaling, one pass: x8 = sat_e4m3(x * scale(amax_prev) / 2) while max |x| of THIS tensor is accumulated into amax_next
+// (one atomic per workgroup) for the next use of the same tensor role, and a third cell is cleared for the use after that (nobody
+// else touches it during this launch).  Half the just-in-time scale: values up to twice the previous maximum stay representable
+// (e4m3 saturates beyond).  Replaces the amax pass + the quantisation pass (two reads of x) by one read.
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_quant_delayed_kernel(int rows, int cols, const T* __restrict__ x, int ldx,
+                                                                const unsigned* __restrict__ amax_prev, unsigned* __restrict__ amax_next,
+                                                                unsigned* __restrict__ amax_clear, float* __restrict__ scale_out,
+                                                                uint8_t* __restrict__ out, int ldo) {
+  const float s = fp8_scale_of(*amax_prev) * 0.5f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *scale_out = s; *amax_clear = 0u; }
+  const int c4 = cols >> 2;
+  const size_t total = (size_t)rows * c4;
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / c4), c = (int)(i - (size_t)r * c4) * 4;
+    float v[4];
+    Vec4<T>::load(x + (size_t)r * ldx + c, v);
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= s;
+    *reinterpret_cast<unsigned*>(out + (size_t)r * ldo + c) = pack4_e4m3(v);
+  }
+  __shared__ float wm[4];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(amax_next, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+}
+extern "C" int uc2_fp8_quant_delayed(int dtype, int rows, int cols, const void* x, int ldx, const void* amax_prev, void* amax_next,
+                                     void* amax_clear, float* scale_out, void* out, int ldo, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  if (rows <= 0 || cols <= 0) return 0;
+  UC2_CHECK_ARG(x && amax_prev && amax_next && amax_clear && scale_out && out);
+  UC2_CHECK_ARG(amax_prev != amax_next && amax_next != amax_clear && amax_prev != amax_clear);
+  UC2_CHECK_ARG((cols & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0);
+  const size_t blocks = ((size_t)rows * (cols / 4) + 255) / 256;
+  const int grid = (int)(blocks > 2048 ? 2048 : blocks);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0) hipLaunchKernelGGL(fp8_quant_delayed_kernel<float>, dim3(grid), dim3(256), 0, st, rows, cols, (const float*)x, ldx, (const unsigned*)amax_prev, (unsigned*)amax_next, (unsigned*)amax_clear, scale_out, (uint8_t*)out, ldo);
+  else hipLaunchKernelGGL(fp8_quant_delayed_kernel<bf16>, dim3(grid), dim3(256), 0, st, rows, cols, (const bf16*)x, ldx, (const unsigned*)amax_prev, (unsigned*)amax_next, (unsigned*)amax_clear, scale_out, (uint8_t*)out, ldo);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
 // amax_bits must be zeroed by the caller (uc2_fp8_amax accumulates a maximum, so several tensors can share one scale)
 extern "C" int uc2_fp8_amax(int dtype, size_t n, const void* x, void* amax_bits, void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
@@ -133,6 +178,8 @@ extern "C" int uc2_fp8_quant_amax(int dtype, int rows, int cols, const void* x, 
 }
 
 int uc2_gemm_fp8_launch(const GemmArgs& p8, hipStream_t st);      // gemm_fast.hip
+bool uc2_gemm_pp8_supported(const GemmArgs& p);                   // gemm_pp8.hip (takes the "bf16 view": K, lda, ldb halved)
+void uc2_gemm_pp8_launch(const GemmArgs& p, hipStream_t st);
 extern "C" int uc2_colsum_accum(int dtype, int M, int N, const void* X, int ldx, const uint8_t* rowmask, float* out, void* stream);
 
 // C[M,N] (bf16) = epi( (sum_k A8(m,k) B8(n,k)) / (*scale_a * *scale_b) + bias[n] ); A8 [M,K], B8 [N,K] e4m3, k-contiguous
@@ -149,12 +196,42 @@ extern "C" int uc2_gemm_fp8(int M, int N, int K, const void* A8, int lda, const 
   p.A = A8; p.B = B8; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux ? ldaux : ldc;
   p.epi = epilogue; p.c_f32 = 0; p.accumulate = 0; p.split_k = 1; p.atomic = 0; p.partial = nullptr;
-  p.a_vec = 1; p.b_vec = 1; p.variant = 1; p.aux_deriv = (flags >> 1) & 1; p.alpha = 1.0f;
+  p.a_vec = 1; p.b_vec = 1; p.aux_deriv = (flags >> 1) & 1; p.alpha = 1.0f;
+  p.variant = (flags & 4) ? 1 : 0;                    // UC2_GEMM_FP8_RING: the LDS-DMA ring kernel even where the ping-pong kernel would take the shape
   p.alpha_dev = scale_a; p.alpha_dev2 = scale_b;
-  uc2_gemm_fp8_launch(p, (hipStream_t)stream);
+  const int route = uc2_gemm_fp8_launch(p, (hipStream_t)stream);
   UC2_LAUNCH_CHECK();
-  if (epilogue == EPI_DGELU && aux_out != nullptr) {
+  if (epilogue == EPI_DGELU && aux_out != nullptr && route != 2) {       // (the ping-pong kernel's epilogue produced the column sums)
     return uc2_colsum_accum(1, M, N, C, ldc, nullptr, reinterpret_cast<float*>(aux_out), stream);
   }
+  return 0;
+}
+
+// uc2_gemm_fp8 whose epilogue ALSO writes the e4m3 copy of its output that the next GEMM reads (FFN1 -> FFN2 forward: gelu(.);
+// FFN2 -> FFN1 input gradients: dY W x gelu') -- no separate quantisation pass over the [rows, 4H] tensor.  Delayed scaling like
+// uc2_fp8_quant_delayed: q_out = sat_e4m3(out * scale(*amax_prev) / 2), max |out| -> *amax_next, *amax_clear = 0, the scale used ->
+// *q_scale_out.  Only the ping-pong kernel has this epilogue: returns -2 (nothing launched) for shapes it does not take and for
+// epilogues other than GELU / DGELU with UC2_GEMM_AUX_DERIV -- the caller then runs uc2_gemm_fp8 + a quantisation pass.
+extern "C" int uc2_gemm_fp8_q(int M, int N, int K, const void* A8, int lda, const void* B8, int ldb, const float* scale_a,
+                              const float* scale_b, void* C, int ldc, const float* bias, int epilogue, const void* aux_in,
+                              void* aux_out, int ldaux, int flags, void* q_out, int ldq, const void* amax_prev, void* amax_next,
+                              void* amax_clear, float* q_scale_out, void* stream) {
+  UC2_CHECK_ARG(M > 0 && N > 0 && K > 0 && (K % 128) == 0);
+  UC2_CHECK_ARG(A8 && B8 && C && scale_a && scale_b && q_out && amax_prev && amax_next && amax_clear && q_scale_out);
+  UC2_CHECK_ARG(amax_prev != amax_next && amax_next != amax_clear && amax_prev != amax_clear);
+  UC2_CHECK_ARG((lda % 16) == 0 && (ldb % 16) == 0 && (((uintptr_t)A8 | (uintptr_t)B8) & 15) == 0);
+  UC2_CHECK_ARG((ldq % 16) == 0 && ((uintptr_t)q_out & 15) == 0);
+  if (!((epilogue == EPI_GELU || epilogue == EPI_DGELU) && (flags & 2))) return -2;
+  UC2_CHECK_ARG(!(epilogue == EPI_DGELU && aux_in == nullptr) && !(epilogue == EPI_GELU && aux_out == nullptr));
+  GemmArgs p{};
+  p.A = A8; p.B = B8; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out;
+  p.M = M; p.N = N; p.K = K / 2; p.lda = lda / 2; p.ldb = ldb / 2; p.ldc = ldc; p.ldaux = ldaux ? ldaux : ldc;
+  p.epi = epilogue; p.split_k = 1; p.a_vec = 1; p.b_vec = 1; p.aux_deriv = 1; p.alpha = 1.0f;
+  p.alpha_dev = scale_a; p.alpha_dev2 = scale_b;
+  p.q_out = q_out; p.ldq = ldq; p.q_amax_prev = (const unsigned*)amax_prev; p.q_amax_next = (unsigned*)amax_next;
+  p.q_amax_clear = (unsigned*)amax_clear; p.q_scale_out = q_scale_out;
+  if (!uc2_gemm_pp8_supported(p)) return -2;
+  uc2_gemm_pp8_launch(p, (hipStream_t)stream);
+  UC2_LAUNCH_CHECK();
   return 0;
 }

@@ -41,6 +41,10 @@ struct GemmArgs {
   int* queue;            // ping-pong kernel: caller-owned item queue (9 zeroed ints: next-item counter per XCD + exit count), or null = static partition
   int ngroup, grp_items; // EPI_GROUP: problems and total work items of the launch
   GemmProb grp[UC2_GEMM_MAX_GROUP];
+  // fp8 ping-pong kernel (gemm_pp8.hip), optional: an e4m3 copy of the MAIN output for the next GEMM (delayed scaling: quantised with
+  // half the scale of *q_amax_prev; max |output| accumulated into *q_amax_next; *q_amax_clear zeroed; the scale used -> *q_scale_out)
+  void* q_out; int ldq;
+  const unsigned* q_amax_prev; unsigned* q_amax_next; unsigned* q_amax_clear; float* q_scale_out;
 };
 
 // ------------------------------------------------------------------------------------------

@@ -393,9 +393,14 @@ static void gf_launch2(const GemmArgs& p, int variant, hipStream_t st) {
 
 // fp8 (e4m3) x fp8 -> bf16, both operands k-contiguous: the operands are handed to the ring kernel as "bf16" matrices of
 // half the width (same bytes).  M, N arbitrary (row clamping + guarded epilogue), K % 128 == 0.
+bool uc2_gemm_pp8_supported(const GemmArgs& p);                                                     // gemm_pp8.hip
+void uc2_gemm_pp8_launch(const GemmArgs& p, hipStream_t st);
 int uc2_gemm_fp8_launch(const GemmArgs& p8, hipStream_t st) {
   GemmArgs p = p8;
   p.K = p8.K / 2; p.lda = p8.lda / 2; p.ldb = p8.ldb / 2;
+  // whole 256 x 256 tiles and an even number of k-tiles: the persistent ping-pong schedule on v_mfma_scale_f32_16x16x128_f8f6f4
+  // (p.variant == 1 forces the ring kernel below: tests, A/B)
+  if (p8.variant != 1 && uc2_gemm_pp8_supported(p)) { uc2_gemm_pp8_launch(p, st); return 2; }
   constexpr int BM = 256, BK = 64, NSTAGE = 3;
   constexpr int smem = NSTAGE * (BM * BK * 2 + GF_BN * BK * 2);
   auto kern = gemm_bf16_fast_kernel<false, false, true, BM, BK, NSTAGE, true>;

@@ -22,9 +22,11 @@ __device__ __forceinline__ i32x8p pp8_cat(const bf16x8& lo, const bf16x8& hi) {
 // A half hh, 16-column block nb; a 32-row output block (hh, i) is the block pair mb = 2 i, 2 i + 1.  Piece k = 4 mbl + nb of
 // the lane = row 16 mbl + (lane & 15) of the 32-row block, columns 16 nb + 4 g .. + 3 = half (g & 1) of 16-byte chunk
 // 2 nb + (g >> 1) of the 128-byte row in the transposition buffer: (q0 ^ (nb << 5)) + mbl * 2048.
-template <int EPI>
+// QOUT: also an e4m3 copy of the main output (x qs, saturating) as whole 64-byte row segments qo[A half][i][it] (row 16 it + (lane >> 2)
+// of the 32-row block, bytes 16 (lane & 3) .. + 15 of the wave's 64 columns), and the running maximum of |output| in qmax
+template <int EPI, bool QOUT = false>
 __device__ __forceinline__ void pp8_epi_compute_q(const GemmArgs& p, const f32x4 (&acc)[2][4][4], PpOut& out, int mb0, int nb0,
-                                                  int lane, const TpAddr& ta, float alpha) {
+                                                  int lane, const TpAddr& ta, float alpha, float qs, float& qmax) {
   const int g = lane >> 4, r15 = lane & 15, lr = lane >> 3, lc = lane & 7;
   constexpr bool has_aux = (EPI == EPI_DGELU || EPI == EPI_ADD || EPI == EPI_MUL);
   constexpr bool two = (EPI == EPI_GELU || EPI == EPI_GELU_D);
@@ -64,6 +66,7 @@ __device__ __forceinline__ void pp8_epi_compute_q(const GemmArgs& p, const f32x4
         __builtin_amdgcn_sched_barrier(0);
       }
       bf16x4 pre[8];
+      unsigned qv[8];
 #pragma unroll
       for (int mbl = 0; mbl < 2; ++mbl)
 #pragma unroll
@@ -125,6 +128,13 @@ __device__ __forceinline__ void pp8_epi_compute_q(const GemmArgs& p, const f32x4
           const unsigned qa = q0 ^ (unsigned)(nb << 5);
           if (mbl == 0) asm volatile("ds_write_b64 %0, %1" :: "v"(qa), "v"(o) : "memory");
           else asm volatile("ds_write_b64 %0, %1 offset:2048" :: "v"(qa), "v"(o) : "memory");
+          if (QOUT) {
+            qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            unsigned r = 0;
+            r = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * qs, v[1] * qs, r, false);
+            r = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * qs, v[3] * qs, r, true);
+            qv[k] = r;
+          }
         }
       tp_read_o<0>(out.o[hh][i][0], ta.line); tp_read_o<1024>(out.o[hh][i][1], ta.line);
       tp_read_o<2048>(out.o[hh][i][2], ta.line); tp_read_o<3072>(out.o[hh][i][3], ta.line);
@@ -135,11 +145,45 @@ __device__ __forceinline__ void pp8_epi_compute_q(const GemmArgs& p, const f32x4
           if (k < 4) asm volatile("ds_write_b64 %0, %1" :: "v"(qa), "v"(pre[k]) : "memory");
           else asm volatile("ds_write_b64 %0, %1 offset:2048" :: "v"(qa), "v"(pre[k]) : "memory");
         }
-        tp_read_o<0>(out.pre[hh][i][0], ta.line); tp_read_o<1024>(out.pre[hh][i][1], ta.line);
-        tp_read_o<2048>(out.pre[hh][i][2], ta.line); tp_read_o<3072>(out.pre[hh][i][3], ta.line);
-        TP_WAIT4(out.pre[hh][i][0], out.pre[hh][i][1], out.pre[hh][i][2], out.pre[hh][i][3]);
+        if (QOUT) {
+          // (with the e4m3 stream the second stream leaves at once, block by block: three streams held to the end do not fit the
+          //  register file -- 80 spilled registers; the stores are counted by the kernel either way)
+          bf16x8 pl[4];
+          tp_read_o<0>(pl[0], ta.line); tp_read_o<1024>(pl[1], ta.line); tp_read_o<2048>(pl[2], ta.line); tp_read_o<3072>(pl[3], ta.line);
+          TP_WAIT4(pl[0], pl[1], pl[2], pl[3]);
+          bf16* a0 = reinterpret_cast<bf16*>(p.aux_out) + (size_t)(mb0 + hh * 64 + i * 32 + lr) * p.ldaux + nb0 + 8 * lc;
+#pragma unroll
+          for (int it = 0; it < 4; ++it) __builtin_nontemporal_store(pl[it], reinterpret_cast<bf16x8*>(a0 + (size_t)(8 * it) * p.ldaux));
+        } else {
+          tp_read_o<0>(out.pre[hh][i][0], ta.line); tp_read_o<1024>(out.pre[hh][i][1], ta.line);
+          tp_read_o<2048>(out.pre[hh][i][2], ta.line); tp_read_o<3072>(out.pre[hh][i][3], ta.line);
+          TP_WAIT4(out.pre[hh][i][0], out.pre[hh][i][1], out.pre[hh][i][2], out.pre[hh][i][3]);
+        }
       }
       TP_WAIT4(out.o[hh][i][0], out.o[hh][i][1], out.o[hh][i][2], out.o[hh][i][3]);
+      if (QOUT) {
+        // the e4m3 block through the same buffer (every read of it above has completed): 32 rows x 64 bytes, dword 4 nb + g of row
+        // 16 mbl + r15 at 4 (nb ^ ((r15 >> 2) & 3)) + g -- conflict-free for the 32-bit writes and for the 16-byte row reads
+        const unsigned wq = tb + (unsigned)r15 * 64u + 4u * (unsigned)g;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const unsigned a_ = wq + (unsigned)(((k & 3) ^ ((r15 >> 2) & 3)) << 4);
+          if (k < 4) asm volatile("ds_write_b32 %0, %1" :: "v"(a_), "v"(qv[k]) : "memory");
+          else asm volatile("ds_write_b32 %0, %1 offset:1024" :: "v"(a_), "v"(qv[k]) : "memory");
+        }
+        const int qr = lane >> 2, qc = lane & 3;
+        const unsigned rq = tb + (unsigned)qr * 64u + (unsigned)((qc ^ ((qr >> 2) & 3)) << 4);
+        bf16x8 q0_, q1_;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(q0_) : "v"(rq) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(q1_) : "v"(rq) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0_), "+v"(q1_) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // stored at once (64-byte row segments; 8 stores per wave and item -- the kernel's counted vmcnt knows): holding four blocks of
+        // them until the other streams' stores spilled 98 registers in the GELU + gelu' instantiation
+        unsigned char* d = reinterpret_cast<unsigned char*>(p.q_out) + (size_t)(mb0 + hh * 64 + i * 32 + qr) * p.ldq + nb0 + 16 * qc;
+        __builtin_nontemporal_store(q0_, reinterpret_cast<bf16x8*>(d));
+        __builtin_nontemporal_store(q1_, reinterpret_cast<bf16x8*>(d + (size_t)16 * p.ldq));
+      }
     }
   if (EPI == EPI_DGELU || EPI == EPI_MUL) {
     if (want_cs) {                                     // (wave-uniform) one 64-lane atomic per wave and tile
@@ -150,3 +194,11 @@ __device__ __forceinline__ void pp8_epi_compute_q(const GemmArgs& p, const f32x4
   }
 }
 
+
+// the power-of-two scale that maps `amax` just below the e4m3 maximum (fp8.hip fp8_scale_of)
+__device__ __forceinline__ float pp8_scale_of(unsigned amax_bits) {
+  const float a = __uint_as_float(amax_bits);
+  float s = 1.0f;
+  if (a > 0.f && a < INFINITY) s = exp2f(floorf(log2f(448.0f / a)));
+  return fminf(fmaxf(s, 1.0f / 16777216.0f), 16777216.0f);
+}

@@ -18,11 +18,16 @@
 #ifndef PP16_AUX_TOUCH
 #define PP16_AUX_TOUCH 1     // touch the lines of the epilogue's aux_in tile two k-tiles ahead (residual-add / gelu'-multiply / dGELU kinds)
 #endif
-template <bool TA, bool TB, bool TACC, int EPI, int HI>
+template <bool TA, bool TB, bool TACC, int EPI, int HI, bool QOUT = false>
 __global__ __launch_bounds__(512, 2) void gemm_fp8_pp8_kernel(GemmArgs p) {
   static_assert(HI == 2 && TACC && !TA && !TB, "256-row tiles, transposed accumulators, k-contiguous e4m3 operands");
   const float sab = p.alpha_dev ? p.alpha_dev[0] * p.alpha_dev2[0] : 1.0f / p.alpha;       // scale_a scale_b (wave-uniform)
   const float alpha = 1.0f / sab;
+  // QOUT: an e4m3 copy of the main output for the GEMM that consumes it (delayed scaling: half the scale of the previous use's maximum)
+  const float qs = QOUT ? pp8_scale_of(*p.q_amax_prev) * 0.5f : 0.f;
+  float qmax = 0.f;
+  if (QOUT && blockIdx.x == 0 && threadIdx.x == 0) { *p.q_scale_out = qs; *p.q_amax_clear = 0u; }
+  constexpr int NQ = QOUT ? 8 : 0;                         // stores of the e4m3 stream per wave and item
   constexpr int RW = 64 + 32 * HI, RT = 2 * RW;           // rows per wave row / per tile (128 / 256, or 96 / 192)
   constexpr int GA1 = HI == 2 ? 2 : 1;                      // LDS-DMA instructions per wave for unit A1
   constexpr int GKT = 6 + GA1;                             // ... per k-tile
@@ -349,6 +354,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_pp8_kernel(GemmArgs p) {
       if (younger == GKT) { if (HI == 2) wait_vmcnt<8>(); else wait_vmcnt<7>(); }
       else if (younger == GKT + NST) { if (HI == 2) wait_vmcnt<24>(); else wait_vmcnt<19>(); }
       else if (younger == GKT + 2 * NST) { if (HI == 2) wait_vmcnt<40>(); else wait_vmcnt<31>(); }
+      else if (QOUT && younger == GKT + NST + 8) wait_vmcnt<32>();
+      else if (QOUT && younger == GKT + 2 * NST + 8) wait_vmcnt<48>();
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
     };
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_pp8_kernel(GemmArgs p) {
       asm volatile("" : "+v"(ln));
       {
         const TpAddr tpa = tp_addr(lds0 + 131072u + (unsigned)w * 4096u, ln);
-        pp8_epi_compute_q<EPI>(p, acc, out, em0, en0, ln, tpa, alpha);
+        pp8_epi_compute_q<EPI, QOUT>(p, acc, out, em0, en0, ln, tpa, alpha, qs, qmax);
       }
       if (PP16_AUX_TOUCH && AUXK) asm volatile("" :: "v"(aux_t0), "v"(aux_t1));      // (the touch loads are older than the aux loads just consumed)
       // pin the finished outputs here: hipcc must not sink the aux-dependent arithmetic into the store sequence below
@@ -437,20 +444,25 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_pp8_kernel(GemmArgs p) {
           for (int it = 0; it < 4; ++it)
             if (!(hh == 1 && i >= HI)) {
               asm volatile("" : "+v"(out.o[hh][i][it]));
-              if (EPI == EPI_GELU || EPI == EPI_GELU_D) asm volatile("" : "+v"(out.pre[hh][i][it]));
+              if (!QOUT && (EPI == EPI_GELU || EPI == EPI_GELU_D)) asm volatile("" : "+v"(out.pre[hh][i][it]));
             }
       PP_STAMP(2);
       ticket_ready(); ticket_publish();
       PP_STAMP(3);
       asm volatile("" : "+v"(ln));
-      pp_epi_store<EPI, HI>(p, out, em0, en0, ln);
+      if (QOUT) pp_epi_store<EPI_NONE, HI>(p, out, em0, en0, ln);       // (the second stream and the e4m3 stream left block by block)
+      else pp_epi_store<EPI, HI>(p, out, em0, en0, ln);
       PP_STAMP(4);
-      younger = GKT + ((EPI == EPI_GELU || EPI == EPI_GELU_D) ? 2 * NST : NST);     // stores issued after the DMA
+      younger = GKT + ((EPI == EPI_GELU || EPI == EPI_GELU_D) ? 2 * NST : NST) + NQ;     // stores issued after the DMA
     }
     ++nitem_done;
     if (!more) break;
   }
   queue_leave();
+  if (QOUT) {                                          // one atomic per wave and launch: the maximum for the next use of this tensor role
+    const float m = wave_max(qmax);
+    if (lane == 0) atomicMax(p.q_amax_next, __float_as_uint(m));
+  }
   if (dbg) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) {
@@ -479,10 +491,10 @@ static int pp8_num_cus() {
   return n;
 }
 
-template <int EPI>
+template <int EPI, bool QOUT = false>
 static void pp8_launch0(const GemmArgs& p, hipStream_t st) {
   constexpr int smem = 131072 + 8 * 4096;
-  auto kern = gemm_fp8_pp8_kernel<false, false, true, EPI, 2>;
+  auto kern = gemm_fp8_pp8_kernel<false, false, true, EPI, 2, QOUT>;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
   const int nitems = (p.N / 256) * (p.M / 256);
@@ -513,6 +525,11 @@ void uc2_gemm_pp8_launch(const GemmArgs& p0, hipStream_t st) {
     int cg = nbx;
     if (nbx > 6) { cg = 1; for (int d = 6; d >= 2; --d) if (nbx % d == 0) { cg = d; break; } if (cg == 1) cg = 6; }
     p.col_group = cg;
+  }
+  if (p.q_out) {                                       // (uc2_gemm_fp8_q has checked: GELU + gelu' or x gelu' kinds only)
+    if (p.epi == EPI_GELU) pp8_launch0<EPI_GELU_D, true>(p, st);
+    else pp8_launch0<EPI_MUL, true>(p, st);
+    return;
   }
   if (p.epi == EPI_GELU) pp8_launch0<EPI_GELU_D>(p, st);
   else if (p.epi == EPI_DGELU) pp8_launch0<EPI_MUL>(p, st);

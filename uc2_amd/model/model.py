@@ -376,6 +376,11 @@ class VLXLMRForPretraining(VLXLMRPreTrainedModel):
     # ------------------------------------------------------------------ dispatch
     def forward(self, batch, task, compute_loss=True):
         store_of(self)                      # one arena for the whole model
+        # fp8 mode: delayed activation scales are kept per task (the gradient magnitudes of two tasks differ by orders of magnitude:
+        # their losses average over different counts -- the reference keeps one amp loss scaler per task for the same reason,
+        # pretrain.py:462-465)
+        from .. import ops as _ops
+        _ops.FP8_TAG = (task, bool(compute_loss))
         batch = defaultdict(lambda: None, batch)
         input_ids = batch['input_ids']
         position_ids = batch['position_ids'] if task == 'tlm' else None

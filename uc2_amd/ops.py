@@ -521,6 +521,34 @@ def fp8_quantize(x2, transpose=False, amax=None):
     return out, scale
 
 
+FP8_DELAYED = os.environ.get("UC2_FP8_DELAYED", "1") != "0"      # activations: delayed scaling (one pass) from the second use of a tensor role on
+_FP8_HIST = {}             # tensor role -> [three amax cells (int32), index of the cell holding the previous maximum]
+FP8_TAG = None             # set by the model's forward (task name, loss or scores): part of every role key, saved by BertLayerFn for its backward
+
+
+def fp8_quantize_act(x2, key=None):
+    """e4m3 copy + scale of an activation.  key = the tensor's role (store, layer, name): the first use computes the maximum just in
+    time (two passes); every later use quantises with half the scale of the PREVIOUS use's maximum while accumulating its own for the
+    next one -- one pass, no amax launch (uc2_fp8_quant_delayed)."""
+    if key is None or not FP8_DELAYED or torch.cuda.is_current_stream_capturing():
+        return fp8_quantize(x2)
+    h = _FP8_HIST.get(key)
+    if h is None:
+        cells = torch.zeros(3, dtype=torch.int32, device=x2.device)
+        x8, scale = fp8_quantize(x2, amax=fp8_amax(x2, cells[0:1]))
+        _FP8_HIST[key] = [cells, 0]
+        return x8, scale
+    cells, i = h
+    rows, cols = x2.shape
+    assert x2.is_contiguous()
+    scale = _fp8_cell(x2.device)[1]
+    out = torch.empty((rows, cols), dtype=torch.uint8, device=x2.device)
+    call("uc2_fp8_quant_delayed", dt(x2.dtype), rows, cols, ptr(x2), x2.stride(0), ptr(cells[i:i + 1]), ptr(cells[(i + 1) % 3:(i + 1) % 3 + 1]),
+         ptr(cells[(i + 2) % 3:(i + 2) % 3 + 1]), ptr(scale), ptr(out), out.stride(0), stream())
+    h[1] = (i + 1) % 3
+    return out, scale
+
+
 def gemm_fp8(a8, sa, b8, sb, bias=None, epi=EPI_NONE, aux_in=None, aux_out=None, flags=0):
     """bf16 C[M,N] = epi((A8 . B8^T) / (sa * sb) + bias); A8 [M,K], B8 [N,K] e4m3 bytes, K % 128 == 0"""
     M, K = a8.shape
@@ -543,6 +571,40 @@ def gemm_fp8(a8, sa, b8, sb, bias=None, epi=EPI_NONE, aux_in=None, aux_out=None,
     return out
 
 
+def gemm_fp8_q(a8, sa, b8, sb, q_key, bias=None, epi=EPI_NONE, aux_in=None, aux_out=None, flags=0):
+    """gemm_fp8 whose epilogue also writes the e4m3 copy of its output for the next GEMM (uc2_gemm_fp8_q; delayed scaling on the
+    history of the CONSUMER's tensor role q_key).  -> (out, (q8, scale)), or None when that role has no history yet (its first use
+    initialises it just in time, fp8_quantize_act) or the ping-pong kernel does not take the call."""
+    h = _FP8_HIST.get(q_key) if (FP8_DELAYED and q_key is not None and not torch.cuda.is_current_stream_capturing()) else None
+    if h is None:
+        return None
+    M, K = a8.shape
+    N = b8.shape[0]
+    cells, i = h
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=a8.device)
+    q8 = torch.empty((M, N), dtype=torch.uint8, device=a8.device)
+    scale = _fp8_cell(a8.device)[1]
+    ldaux = 0
+    for x in (aux_in, aux_out):
+        if x is not None and x.dim() == 2:
+            ldaux = x.stride(0)
+    timer = GEMM_TIMER
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _lib.load().uc2_gemm_fp8_q(M, N, K, ptr(a8), a8.stride(0), ptr(b8), b8.stride(0), ptr(sa), ptr(sb), ptr(out), out.stride(0),
+                                    ptr(bias), epi, ptr(aux_in), ptr(aux_out), ldaux, flags, ptr(q8), q8.stride(0), ptr(cells[i:i + 1]),
+                                    ptr(cells[(i + 1) % 3:(i + 1) % 3 + 1]), ptr(cells[(i + 2) % 3:(i + 2) % 3 + 1]), ptr(scale), stream())
+    if rc == -2:
+        return None
+    _lib.check(rc)
+    if timer is not None:
+        e1.record()
+        timer.add(("fp8", int(epi)), 2.0 * M * N * K, e0, e1)
+    h[1] = (i + 1) % 3
+    return out, (q8, scale)
+
+
 def _fp8_weight(st, p_first, p_last, shape, transpose):
     """e4m3 copy (+ scale) of a weight span, re-quantised when the parameters change (AdamW step, load_state_dict)"""
     cache = st.__dict__.setdefault("_fp8_cache", {})
@@ -561,16 +623,24 @@ def _fp8_weight(st, p_first, p_last, shape, transpose):
     return w8, sc
 
 
-def linear_fwd_fp8(x2, st, p_first, p_last, shape, bias, epi=EPI_NONE, aux_out=None, flags=0):
+def linear_fwd_fp8(x2, st, p_first, p_last, shape, bias, epi=EPI_NONE, aux_out=None, flags=0, role=None, tag=None, pre_q=None, q_key=None):
+    """pre_q: (x8, scale) already produced by the GEMM that made x2 (its fused e4m3 stream); q_key: the consumer's tensor role of THIS
+    GEMM's output -- returns (y, (y8, scale) or None) then"""
     w8, sw = _fp8_weight(st, p_first, p_last, shape, False)
-    x8, sx = fp8_quantize(x2)
+    x8, sx = pre_q if pre_q is not None else fp8_quantize_act(x2, None if role is None else (id(st), st.offsets[id(p_first)], "fwd", role, tag))
+    if q_key is not None:
+        r = gemm_fp8_q(x8, sx, w8, sw, q_key, bias=bias, epi=epi, aux_out=aux_out, flags=flags)
+        return r if r is not None else (gemm_fp8(x8, sx, w8, sw, bias=bias, epi=epi, aux_out=aux_out, flags=flags), None)
     return gemm_fp8(x8, sx, w8, sw, bias=bias, epi=epi, aux_out=aux_out, flags=flags)
 
 
-def linear_dgrad_fp8(dy2, st, p_first, p_last, shape, epi=EPI_NONE, aux_in=None, colsum_out=None, flags=0):
+def linear_dgrad_fp8(dy2, st, p_first, p_last, shape, epi=EPI_NONE, aux_in=None, colsum_out=None, flags=0, role=None, tag=None, pre_q=None, q_key=None):
     """dX = epi(dY W): the k-contiguous operand is the transposed e4m3 copy of W ([in, out])"""
     wt8, sw = _fp8_weight(st, p_first, p_last, shape, True)
-    d8, sd = fp8_quantize(dy2)
+    d8, sd = pre_q if pre_q is not None else fp8_quantize_act(dy2, None if role is None else (id(st), st.offsets[id(p_first)], "bwd", role, tag))
+    if q_key is not None:
+        r = gemm_fp8_q(d8, sd, wt8, sw, q_key, epi=epi, aux_in=aux_in, aux_out=colsum_out, flags=flags)
+        return r if r is not None else (gemm_fp8(d8, sd, wt8, sw, epi=epi, aux_in=aux_in, aux_out=colsum_out, flags=flags), None)
     return gemm_fp8(d8, sd, wt8, sw, epi=epi, aux_in=aux_in, aux_out=colsum_out, flags=flags)
 
 
@@ -1042,12 +1112,14 @@ class BertLayerFn(torch.autograd.Function):
         pre = torch.empty((M, I_), dtype=dtype, device=x.device)
         if fp8:
             # e4m3 operands for the four forward GEMMs (per-tensor scales computed on the device), bf16 outputs
-            qkv = linear_fwd_fp8(x2, st, P["qw"], P["vw"], (3 * H, H), bqkv)
+            qkv = linear_fwd_fp8(x2, st, P["qw"], P["vw"], (3 * H, H), bqkv, role="x", tag=FP8_TAG)
             ctxv, lse = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn)
-            o1 = linear_fwd_fp8(ctxv, st, P["ow"], P["ow"], (H, H), P["ob"].data)
+            o1 = linear_fwd_fp8(ctxv, st, P["ow"], P["ow"], (H, H), P["ob"].data, role="ctx", tag=FP8_TAG)
             a, mean1, rstd1 = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, s_ln1)
-            u = linear_fwd_fp8(a, st, P["iw"], P["iw"], (I_, H), P["ib"].data, EPI_GELU, pre, flags=GEMM_AUX_DERIV)
-            o2 = linear_fwd_fp8(u, st, P["fw"], P["fw"], (H, I_), P["fb"].data)
+            # (the FFN1 GEMM's epilogue writes the e4m3 copy of u that FFN2 reads: no quantisation pass over [tokens, 4H])
+            u, uq = linear_fwd_fp8(a, st, P["iw"], P["iw"], (I_, H), P["ib"].data, EPI_GELU, pre, flags=GEMM_AUX_DERIV, role="a", tag=FP8_TAG,
+                                   q_key=(id(st), st.offsets[id(P["fw"])], "fwd", "u", FP8_TAG))
+            o2 = linear_fwd_fp8(u, st, P["fw"], P["fw"], (H, I_), P["fb"].data, role="u", tag=FP8_TAG, pre_q=uq)
         else:
             qkv = linear_fwd(x2, wqkv, bqkv)
             ctxv, lse = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn, ilv=ilv is not None)
@@ -1061,7 +1133,7 @@ class BertLayerFn(torch.autograd.Function):
 
         ctx.save_for_backward(x2, mask2d, qkv, ctxv, lse, o1, mean1, rstd1, a, pre, u, o2, mean2, rstd2, seed)
         ctx.layer, ctx.cfg, ctx.shape, ctx.p = layer, cfg, (B, L, H, nh, D), (p_h, p_a, (s_attn, s_ln1, s_ln2))
-        ctx.params, ctx.fp8 = params, fp8
+        ctx.params, ctx.fp8, ctx.fp8_tag = params, fp8, FP8_TAG
         ctx.ilv_plan = ilv[1] if ilv is not None else None
         return y.view(B, L, H)
 
@@ -1093,20 +1165,21 @@ class BertLayerFn(torch.autograd.Function):
         wgrad = (lambda dyv, xv, dwv: grouped.append((dyv, xv, dwv))) if grouped is not None else (lambda dyv, xv, dwv: linear_wgrad(dyv, xv, dwv, None))
         wgrad(d_o2, u, G(P["fw"]))
         if fp8:
-            d_pre = linear_dgrad_fp8(d_o2, st, P["fw"], P["fw"], (H, I_), EPI_DGELU, pre, colsum_out=G(P["ib"]), flags=GEMM_AUX_DERIV)
+            d_pre, dq = linear_dgrad_fp8(d_o2, st, P["fw"], P["fw"], (H, I_), EPI_DGELU, pre, colsum_out=G(P["ib"]), flags=GEMM_AUX_DERIV, role="d_o2",
+                                         tag=ctx.fp8_tag, q_key=(id(st), st.offsets[id(P["iw"])], "bwd", "d_pre", ctx.fp8_tag))
         else:
             d_pre = linear_dgrad(d_o2, st.compute(P["fw"], dtype), EPI_DGELU, pre, colsum_out=G(P["ib"]),
                                  flags=GEMM_AUX_DERIV, wt=WT(P["fw"]))                         # + d(intermediate bias)
         wgrad(d_pre, a, G(P["iw"]))
         if fp8:
-            da = linear_dgrad_fp8(d_pre, st, P["iw"], P["iw"], (I_, H), EPI_ADD, dz2)
+            da = linear_dgrad_fp8(d_pre, st, P["iw"], P["iw"], (I_, H), EPI_ADD, dz2, role="d_pre", tag=ctx.fp8_tag, pre_q=dq)
         else:
             da = linear_dgrad(d_pre, st.compute(P["iw"], dtype), EPI_ADD, dz2, wt=WT(P["iw"]))
         # LN1, output projection, attention, fused QKV
         d_o1, dz1 = ln_bwd(da, o1, x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, s_ln1,
                            dbias=G(P["ob"]))
         wgrad(d_o1, ctxv, G(P["ow"]))
-        dctx = linear_dgrad_fp8(d_o1, st, P["ow"], P["ow"], (H, H)) if fp8 else linear_dgrad(d_o1, st.compute(P["ow"], dtype), wt=WT(P["ow"]))
+        dctx = linear_dgrad_fp8(d_o1, st, P["ow"], P["ow"], (H, H), role="d_o1", tag=ctx.fp8_tag) if fp8 else linear_dgrad(d_o1, st.compute(P["ow"], dtype), wt=WT(P["ow"]))
         dwqkv = st.grad_span(P["qw"], P["vw"], (3 * H, H))
         dbqkv = st.grad_span(P["qb"], P["vb"], (3 * H,))
         # d(q|k|v bias) comes out of attn_bwd: column sums of the dQ/dK/dV accumulators, added up per workgroup in LDS and
@@ -1135,7 +1208,7 @@ class BertLayerFn(torch.autograd.Function):
             dx = None
             if ctx.needs_input_grad[0]:
                 if fp8:
-                    dx = linear_dgrad_fp8(dqkv, st, P["qw"], P["vw"], (3 * H, H), EPI_ADD, dz1).view(B, L, H)
+                    dx = linear_dgrad_fp8(dqkv, st, P["qw"], P["vw"], (3 * H, H), EPI_ADD, dz1, role="dqkv", tag=ctx.fp8_tag).view(B, L, H)
                 else:
                     dx = linear_dgrad(dqkv, st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype), EPI_ADD, dz1,
                                       wt=WT(P["qw"], P["vw"], (3 * H, H))).view(B, L, H)
