@@ -124,9 +124,12 @@ int uc2_fp8_quant(int dtype, int rows, int cols, const void* x, int ldx, const f
 /* the same with the scale derived from the amax cell inside the kernel and written to *scale_out (one launch less per tensor) */
 int uc2_fp8_quant_amax(int dtype, int rows, int cols, const void* x, int ldx, const void* amax_bits, float* scale_out,
                        void* out, int ldo, int transpose, void* stream);
-/* delayed scaling, ONE pass over x: quantise with half the scale of *amax_prev (the maximum this tensor role had at its previous use;
- * twice that maximum stays representable, e4m3 saturates beyond) while accumulating max |x| into *amax_next for the next use, and
- * clear *amax_clear for the use after that -- three distinct 4-byte cells the caller rotates per tensor role. */
+/* delayed scaling, ONE pass over x: quantise with half the scale of the previous maximum (the maximum this tensor role had at its
+ * previous use; twice that maximum stays representable, e4m3 saturates beyond) while accumulating max |x| for the next use, and clear
+ * the cells of the use after that.  amax_prev / amax_next / amax_clear: three distinct groups of UC2_AMAX_CELLS (16) 4-byte cells the
+ * caller rotates per tensor role; a maximum = the maximum over a group (producers spread their atomics over the cells; uc2_fp8_amax
+ * writing cell 0 of a zeroed group is a valid group). */
+enum { UC2_AMAX_CELLS = 16 };
 int uc2_fp8_quant_delayed(int dtype, int rows, int cols, const void* x, int ldx, const void* amax_prev, void* amax_next,
                           void* amax_clear, float* scale_out, void* out, int ldo, void* stream);
 /* uc2_gemm_fp8 whose epilogue also writes the e4m3 copy of its OUTPUT for the GEMM that consumes it (FFN1 -> FFN2: gelu(.); the input
@@ -164,6 +167,18 @@ int uc2_ln_bwd_partial(int dtype, int M, int H, const void* dy, const void* x, c
                        const float* mean, const float* rstd, float drop_p, int drop_after, const uint64_t* seed_ptr,
                        uint64_t seed_imm, void* dx, void* dres, int want_dbias, void* ws, void* stream);
 int uc2_ln_bwd_reduce(int dtype, int M, int H, const void* ws, float* dgamma, float* dbeta, float* dbias, void* stream);
+/* fp8 mode (BASELINE.json configs[4]): the LayerNorm kernels also write the e4m3 copy of their output that the next GEMM reads --
+ * uc2_ln_fwd_q: q_out = sat_e4m3(y * scale) (the layer's LN outputs feed the QKV and FFN1 GEMMs); uc2_ln_bwd_partial_q: q_out =
+ * sat_e4m3(dx * scale) (dx feeds the dense layer's input-gradient GEMM) -- with delayed scaling and the cell groups of
+ * uc2_fp8_quant_delayed: no quantisation pass over these tensors.  bf16 only (forward: H % 8 == 0, H <= 1024, 16-byte aligned):
+ * -2 and nothing launched otherwise. */
+int uc2_ln_fwd_q(int dtype, int M, int H, const void* x, const void* residual, const float* gamma, const float* beta, float eps,
+                 float drop_p, int drop_after, const uint64_t* seed_ptr, uint64_t seed_imm, void* y, float* mean, float* rstd,
+                 void* q_out, const void* amax_prev, void* amax_next, void* amax_clear, float* q_scale_out, void* stream);
+int uc2_ln_bwd_partial_q(int dtype, int M, int H, const void* dy, const void* x, const void* residual, const float* gamma,
+                         const float* mean, const float* rstd, float drop_p, int drop_after, const uint64_t* seed_ptr,
+                         uint64_t seed_imm, void* dx, void* dres, int want_dbias, void* ws, void* q_out, const void* amax_prev,
+                         void* amax_next, void* amax_clear, float* q_scale_out, void* stream);
 /* the second stage of up to 32 LayerNorm backwards of the same H in one launch (items: M and ws of the uc2_ln_bwd_partial call,
  * and where its sums go; any of dgamma / dbeta / dbias may be NULL): the micro-batch regime's 28 five-microsecond reductions per
  * backward pass become one kernel at the end of the pass */

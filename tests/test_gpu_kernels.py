@@ -1227,9 +1227,10 @@ def test_gemm_fp8_fused_e4m3_output_stream(M, N, K, epi):
     plain = ops.gemm_fp8(x8, sx, w8, sw, bias=bias, epi=code, aux_in=aux if epi == "mul" else None, aux_out=s_plain, flags=ops.GEMM_AUX_DERIV)
     amax_true = float(plain.float().abs().max())
     key = ("test", M, N, K, epi)
-    cells = torch.zeros(3, dtype=torch.int32, device=DEV)
-    cells[0] = torch.tensor(amax_true * 0.7, device=DEV).view(torch.int32)        # "previous maximum": 0.7 of the real one
-    cells[2] = 12345                                                            # must be cleared
+    C = ops.AMAX_CELLS
+    cells = torch.zeros(3 * C, dtype=torch.int32, device=DEV)
+    cells[3] = torch.tensor(amax_true * 0.7, device=DEV).view(torch.int32)        # "previous maximum" (in any cell of group 0): 0.7 of the real one
+    cells[2 * C:] = 12345                                                       # group 2 must be cleared
     ops._FP8_HIST[key] = [cells, 0]
     s_q = second()
     r = ops.gemm_fp8_q(x8, sx, w8, sw, key, bias=bias, epi=code, aux_in=aux if epi == "mul" else None, aux_out=s_q, flags=ops.GEMM_AUX_DERIV)
@@ -1243,7 +1244,64 @@ def test_gemm_fp8_fused_e4m3_output_stream(M, N, K, epi):
     deq = q8.view(torch.float8_e4m3fn).float() / qs
     assert rel_err(deq, out.float()) < 0.04                                    # 3 mantissa bits
     assert float(deq.abs().max()) <= 448.0 / want_scale
-    got_next = float(cells[1:2].view(torch.float32))
+    got_next = float(cells[C:2 * C].max().view(torch.float32))                  # (non-negative floats order like their bit patterns)
     assert abs(got_next - amax_true) <= 1e-2 * amax_true
-    assert int(cells[2]) == 0 and ops._FP8_HIST[key][1] == 1
+    assert int(cells[2 * C:].abs().max()) == 0 and ops._FP8_HIST[key][1] == 1
+    del ops._FP8_HIST[key]
+
+
+@pytest.mark.parametrize("M,H", [(260, 768), (1031, 1024)])
+def test_layernorm_fused_e4m3_outputs(M, H):
+    """fp8 mode: uc2_ln_fwd_q / uc2_ln_bwd_partial_q write, beside their bf16 outputs (bit-identical to the plain entry points), the
+    e4m3 copy the next GEMM reads -- delayed scaling on the role's previous maximum, the new maximum accumulated over the cell
+    group, the third group cleared.  Dropout on (same masks: same seed and site)."""
+    C = ops.AMAX_CELLS
+    x = rnd((M, H), 1, dtype=torch.bfloat16)
+    res = rnd((M, H), 2, dtype=torch.bfloat16)
+    gamma, beta = 1.0 + 0.1 * rnd((H,), 3), 0.1 * rnd((H,), 4)
+    seed = torch.tensor([1234], dtype=torch.int64, device=DEV)
+    y0, mean0, rstd0 = ops.ln_fwd(x, res, gamma, beta, 1e-12, 0.1, seed, 7)
+    amax_y = float(y0.float().abs().max())
+    key = ("test-ln-fwd", M, H)
+    cells = torch.zeros(3 * C, dtype=torch.int32, device=DEV)
+    cells[5] = torch.tensor(amax_y * 0.8, device=DEV).view(torch.int32)
+    cells[2 * C:] = 777
+    ops._FP8_HIST[key] = [cells, 0]
+    y1, mean1, rstd1, q = ops.ln_fwd(x, res, gamma, beta, 1e-12, 0.1, seed, 7, q_key=key)
+    torch.cuda.synchronize()
+    assert q is not None
+    y8, sc = q
+    assert torch.equal(y1.view(torch.int16), y0.view(torch.int16)) and torch.equal(mean1, mean0) and torch.equal(rstd1, rstd0)
+    want_scale = 2.0 ** math.floor(math.log2(448.0 / (amax_y * 0.8))) * 0.5
+    assert float(sc) == want_scale
+    assert rel_err(y8.view(torch.float8_e4m3fn).float() / sc, y0.float()) < 0.04
+    assert abs(float(cells[C:2 * C].max().view(torch.float32)) - amax_y) <= 1e-2 * amax_y
+    assert int(cells[2 * C:].abs().max()) == 0
+    del ops._FP8_HIST[key]
+    # backward
+    dy = rnd((M, H), 5, dtype=torch.bfloat16)
+
+    def bwd(q_key):
+        dg, db, dbias = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+        r = ops.ln_bwd(dy, x, res, gamma, mean0, rstd0, dg, db, 0.1, seed, 7, dbias=dbias, q_key=q_key)
+        ops.flush_ln_reductions()
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        return r, dg, db, dbias
+    (dx0, dres0), dg0, db0, dbias0 = bwd(None)
+    amax_d = float(dx0.float().abs().max())
+    key = ("test-ln-bwd", M, H)
+    cells = torch.zeros(3 * C, dtype=torch.int32, device=DEV)
+    cells[0] = torch.tensor(amax_d * 1.3, device=DEV).view(torch.int32)
+    cells[2 * C:] = 777
+    ops._FP8_HIST[key] = [cells, 0]
+    (dx1, dres1, q), dg1, db1, dbias1 = bwd(key)
+    assert q is not None
+    d8, sc = q
+    assert torch.equal(dx1.view(torch.int16), dx0.view(torch.int16)) and torch.equal(dres1.view(torch.int16), dres0.view(torch.int16))
+    assert rel_err(dg1, dg0) < 1e-5 and rel_err(db1, db0) < 1e-5 and rel_err(dbias1, dbias0) < 1e-5
+    assert float(sc) == 2.0 ** math.floor(math.log2(448.0 / (amax_d * 1.3))) * 0.5
+    assert rel_err(d8.view(torch.float8_e4m3fn).float() / sc, dx0.float()) < 0.04
+    assert abs(float(cells[C:2 * C].max().view(torch.float32)) - amax_d) <= 1e-2 * amax_d
+    assert int(cells[2 * C:].abs().max()) == 0
     del ops._FP8_HIST[key]

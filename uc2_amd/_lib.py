@@ -40,6 +40,8 @@ SIGNATURES = {
     "uc2_ln_bwd": (I, [I, I, I, P, P, P, P, P, P, F, I, P, U64, P, P, P, P, P, P, P]),
     "uc2_ln_bwd_partial": (I, [I, I, I, P, P, P, P, P, P, F, I, P, U64, P, P, I, P, P]),
     "uc2_ln_bwd_reduce": (I, [I, I, I, P, P, P, P, P]),
+    "uc2_ln_fwd_q": (I, [I, I, I, P, P, P, P, F, F, I, P, U64, P, P, P, P, P, P, P, P, P]),
+    "uc2_ln_bwd_partial_q": (I, [I, I, I, P, P, P, P, P, P, F, I, P, U64, P, P, I, P, P, P, P, P, P, P]),
     "uc2_ln_bwd_reduce_batch": (I, [I, I, P, I, P]),
     "uc2_attn_fwd": (I, [I, I, I, I, I, I, P, P, F, F, P, U64, P, P, P]),
     "uc2_attn_bwd": (I, [I, I, I, I, I, I, P, P, F, F, P, U64, P, P, P, P, P, P]),

@@ -172,6 +172,26 @@ template <> __device__ __forceinline__ float dgelu_t<bf16>(float x) { return dge
 template <typename T> __device__ __forceinline__ float tanh_t(float x) { return tanhf(x); }
 template <> __device__ __forceinline__ float tanh_t<bf16>(float x) { return tanh_bf(x); }
 
+// ---- running maximum of |x| for the fp8 delayed scaling: UC2_AMAX_CELLS 4-byte cells per tensor role and use (a producer's
+// workgroups spread their one atomic each over the cells: thousands of atomics on ONE address serialise at ~12 ns each; readers
+// take the maximum over the cells; non-negative floats order like their bit patterns)
+#define UC2_AMAX_CELLS 16
+__device__ __forceinline__ unsigned amax_cells_read(const unsigned* __restrict__ cells) {       // uniform address: scalar loads
+  unsigned m = 0;
+#pragma unroll
+  for (int i = 0; i < UC2_AMAX_CELLS; ++i) m = max(m, cells[i]);
+  return m;
+}
+// the power-of-two scale that maps `amax` just below the e4m3 maximum (448)
+__device__ __forceinline__ float fp8_scale_of(unsigned amax_bits) {
+  const float a = __uint_as_float(amax_bits);
+  float s = 1.0f;
+  if (a > 0.f && a < INFINITY) s = exp2f(floorf(log2f(448.0f / a)));
+  return fminf(fmaxf(s, 1.0f / 16777216.0f), 16777216.0f);
+}
+// delayed scaling: half the just-in-time scale of the previous use's maximum (twice that maximum stays representable)
+__device__ __forceinline__ float fp8_delayed_scale(const unsigned* __restrict__ prev_cells) { return fp8_scale_of(amax_cells_read(prev_cells)) * 0.5f; }
+
 // ---- counter-based dropout RNG: keep(seed, idx) is a pure function, regenerated in backward ----
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;

@@ -27,13 +27,6 @@ __global__ __launch_bounds__(256) void fp8_amax_kernel(size_t n, const T* __rest
   if (threadIdx.x == 0)
     atomicMax(amax_bits, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));   // non-negative floats order like their bit patterns
 }
-// the power-of-two scale that maps `amax` just below the e4m3 maximum (448)
-__device__ __forceinline__ float fp8_scale_of(unsigned amax_bits) {
-  const float a = __uint_as_float(amax_bits);
-  float s = 1.0f;
-  if (a > 0.f && a < INFINITY) s = exp2f(floorf(log2f(448.0f / a)));
-  return fminf(fmaxf(s, 1.0f / 16777216.0f), 16777216.0f);
-}
 __global__ void fp8_scale_kernel(const unsigned* __restrict__ amax_bits, float* __restrict__ scale) { *scale = fp8_scale_of(*amax_bits); }
 __device__ __forceinline__ unsigned pack4_e4m3(const float (&v)[4]) {
   unsigned r = 0;
@@ -84,16 +77,17 @@ __global__ __launch_bounds__(256) void fp8_quant_t_kernel(int rows, int cols, co
 }
 
 // Delayed scaling, one pass: x8 = sat_e4m3(x * scale(amax_prev) / 2) while max |x| of THIS tensor is accumulated into amax_next
-// (one atomic per workgroup) for the next use of the same tensor role, and a third cell is cleared for the use after that (nobody
-// else touches it during this launch).  Half the just-in-time scale: values up to twice the previous maximum stay representable
+// (one atomic per workgroup, spread over UC2_AMAX_CELLS cells) for the next use of the same tensor role, and a third group of cells
+// is cleared for the use after that (nobody else touches it during this launch).  amax_prev / amax_next / amax_clear: UC2_AMAX_CELLS
+// (16) unsigned each; a maximum = the maximum over a group's cells.  Half the just-in-time scale: values up to twice the previous maximum stay representable
 // (e4m3 saturates beyond).  Replaces the amax pass + the quantisation pass (two reads of x) by one read.
 template <typename T>
 __global__ __launch_bounds__(256) void fp8_quant_delayed_kernel(int rows, int cols, const T* __restrict__ x, int ldx,
                                                                 const unsigned* __restrict__ amax_prev, unsigned* __restrict__ amax_next,
                                                                 unsigned* __restrict__ amax_clear, float* __restrict__ scale_out,
                                                                 uint8_t* __restrict__ out, int ldo) {
-  const float s = fp8_scale_of(*amax_prev) * 0.5f;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { *scale_out = s; *amax_clear = 0u; }
+  const float s = fp8_delayed_scale(amax_prev);
+  if (blockIdx.x == 0 && threadIdx.x < UC2_AMAX_CELLS) { amax_clear[threadIdx.x] = 0u; if (threadIdx.x == 0) *scale_out = s; }
   const int c4 = cols >> 2;
   const size_t total = (size_t)rows * c4;
   float m = 0.f;
@@ -110,7 +104,7 @@ __global__ __launch_bounds__(256) void fp8_quant_delayed_kernel(int rows, int co
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) atomicMax(amax_next, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+  if (threadIdx.x == 0) atomicMax(amax_next + (blockIdx.x & (UC2_AMAX_CELLS - 1)), __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
 }
 extern "C" int uc2_fp8_quant_delayed(int dtype, int rows, int cols, const void* x, int ldx, const void* amax_prev, void* amax_next,
                                      void* amax_clear, float* scale_out, void* out, int ldo, void* stream) {

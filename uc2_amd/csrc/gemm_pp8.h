@@ -195,10 +195,3 @@ __device__ __forceinline__ void pp8_epi_compute_q(const GemmArgs& p, const f32x4
 }
 
 
-// the power-of-two scale that maps `amax` just below the e4m3 maximum (fp8.hip fp8_scale_of)
-__device__ __forceinline__ float pp8_scale_of(unsigned amax_bits) {
-  const float a = __uint_as_float(amax_bits);
-  float s = 1.0f;
-  if (a > 0.f && a < INFINITY) s = exp2f(floorf(log2f(448.0f / a)));
-  return fminf(fmaxf(s, 1.0f / 16777216.0f), 16777216.0f);
-}

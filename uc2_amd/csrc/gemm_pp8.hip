@@ -24,9 +24,9 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_pp8_kernel(GemmArgs p) {
   const float sab = p.alpha_dev ? p.alpha_dev[0] * p.alpha_dev2[0] : 1.0f / p.alpha;       // scale_a scale_b (wave-uniform)
   const float alpha = 1.0f / sab;
   // QOUT: an e4m3 copy of the main output for the GEMM that consumes it (delayed scaling: half the scale of the previous use's maximum)
-  const float qs = QOUT ? pp8_scale_of(*p.q_amax_prev) * 0.5f : 0.f;
+  const float qs = QOUT ? fp8_delayed_scale(p.q_amax_prev) : 0.f;
   float qmax = 0.f;
-  if (QOUT && blockIdx.x == 0 && threadIdx.x == 0) { *p.q_scale_out = qs; *p.q_amax_clear = 0u; }
+  if (QOUT && blockIdx.x == 0 && threadIdx.x < UC2_AMAX_CELLS) { p.q_amax_clear[threadIdx.x] = 0u; if (threadIdx.x == 0) *p.q_scale_out = qs; }
   constexpr int NQ = QOUT ? 8 : 0;                         // stores of the e4m3 stream per wave and item
   constexpr int RW = 64 + 32 * HI, RT = 2 * RW;           // rows per wave row / per tile (128 / 256, or 96 / 192)
   constexpr int GA1 = HI == 2 ? 2 : 1;                      // LDS-DMA instructions per wave for unit A1
@@ -459,9 +459,18 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_pp8_kernel(GemmArgs p) {
     if (!more) break;
   }
   queue_leave();
-  if (QOUT) {                                          // one atomic per wave and launch: the maximum for the next use of this tensor role
+  if (QOUT) {                                          // one atomic per WORKGROUP and launch (2048 per-wave atomics on one address cost ~25 us)
     const float m = wave_max(qmax);
-    if (lane == 0) atomicMax(p.q_amax_next, __float_as_uint(m));
+    float* red = reinterpret_cast<float*>(smem + 131072);          // (the transposition buffers are free now)
+    __syncthreads();
+    if (lane == 0) red[w] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float mm = red[0];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) mm = fmaxf(mm, red[i]);
+      atomicMax(p.q_amax_next + (blockIdx.x & (UC2_AMAX_CELLS - 1)), __float_as_uint(mm));
+    }
   }
   if (dbg) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

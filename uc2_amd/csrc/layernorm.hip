@@ -95,14 +95,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int H, const T* __re
 // backward.  dz = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 //   dres = dz ;  dx = dz * keep / (1-p)
 //   dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy   (per-workgroup partials -> ws, then reduced)
-template <typename T, int NC>
+template <typename T, int NC, bool Q = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __restrict__ dy, const T* __restrict__ x,
                                                      const T* __restrict__ res, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      uint32_t thresh, float keep_scale, const uint64_t* __restrict__ seed_ptr,
                                                      uint64_t seed_imm, T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ ws, int want_dbias,
-                                                     int drop_after) {
+                                                     int drop_after, uint8_t* __restrict__ qo, const unsigned* __restrict__ q_prev,
+                                                     unsigned* __restrict__ q_next, unsigned* __restrict__ q_clear, float* __restrict__ q_scale_out) {
   __shared__ float red[4][NC * 4 * 64];
+  // Q: also an e4m3 copy of dx (the gradient the dense layer's input-gradient GEMM reads) -- fp8 mode, delayed scaling (common.h)
+  const float qs = Q ? fp8_delayed_scale(q_prev) : 0.f;
+  float qmax = 0.f;
+  if (Q && blockIdx.x == 0 && threadIdx.x < UC2_AMAX_CELLS) { q_clear[threadIdx.x] = 0u; if (threadIdx.x == 0) *q_scale_out = qs; }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nch = H >> 2;
   const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
@@ -191,6 +196,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
           dbx[i][e] += dxv[e];
         }
         if (dx) Vec4<T>::store(dx + off, dxv);
+        if (Q) {
+          qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(dxv[0]), fabsf(dxv[1])), fmaxf(fabsf(dxv[2]), fabsf(dxv[3]))));
+          unsigned r = 0;
+          r = __builtin_amdgcn_cvt_pk_fp8_f32(dxv[0] * qs, dxv[1] * qs, r, false);
+          r = __builtin_amdgcn_cvt_pk_fp8_f32(dxv[2] * qs, dxv[3] * qs, r, true);
+          *reinterpret_cast<unsigned*>(qo + off) = r;
+        }
         if (dres) Vec4<T>::store_nt(dres + off, dz);           // the residual-path gradient is read several kernels later (EPI_ADD of a dgrad GEMM)
       }
     }
@@ -209,6 +221,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
     for (int col = threadIdx.x; col < H; col += 256)       // red index == column (c*4 + e, c = lane + 64*i)
       ws[(size_t)blockIdx.x * 3 * H + which * H + col] = red[0][col] + red[1][col] + red[2][col] + red[3][col];
   }
+  if (Q) {                                             // max |dx| of this workgroup's rows -> one atomic, spread over the cells
+    __syncthreads();
+    qmax = wave_max(qmax);
+    if (lane == 0) red[0][wv] = qmax;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      atomicMax(q_next + (blockIdx.x & (UC2_AMAX_CELLS - 1)), __float_as_uint(fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]))));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -226,12 +246,18 @@ __device__ __forceinline__ void bf8_to_f(const bf16x8& v, float (&o)[8]) {
   for (int e = 0; e < 8; ++e) o[e] = (float)v[e];
 }
 
-template <int NC8>
+// Q: also an e4m3 copy of y for the GEMM that consumes it (fp8 mode, delayed scaling: half the scale of the previous use's maximum,
+// max |y| accumulated for the next use -- common.h; one atomic per workgroup, spread over the UC2_AMAX_CELLS cells)
+struct LnQ { uint8_t* q; const unsigned* amax_prev; unsigned* amax_next; unsigned* amax_clear; float* scale_out; };
+template <int NC8, bool Q = false>
 __global__ __launch_bounds__(256) void ln_fwd16_kernel(int M, int H, const bf16* __restrict__ x, const bf16* __restrict__ res,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float eps, uint32_t thresh, float keep_scale, const uint64_t* __restrict__ seed_ptr,
                                                        uint64_t seed_imm, bf16* __restrict__ y, float* __restrict__ mean_o,
-                                                       float* __restrict__ rstd_o, int drop_after) {
+                                                       float* __restrict__ rstd_o, int drop_after, LnQ lq) {
+  const float qs = Q ? fp8_delayed_scale(lq.amax_prev) : 0.f;
+  float qmax = 0.f;
+  if (Q && blockIdx.x == 0 && threadIdx.x < UC2_AMAX_CELLS) { lq.amax_clear[threadIdx.x] = 0u; if (threadIdx.x == 0) *lq.scale_out = qs; }
   const int l32 = threadIdx.x & 31;
   const int row_raw = blockIdx.x * 8 + (threadIdx.x >> 5);
   const bool row_ok = row_raw < M;
@@ -308,7 +334,25 @@ __global__ __launch_bounds__(256) void ln_fwd16_kernel(int M, int H, const bf16*
 #pragma unroll
       for (int e = 0; e < 8; ++e) ov[e] = (bf16)o[e];
       *reinterpret_cast<bf16x8*>(y + (size_t)row * H + c * 8) = ov;
+      if (Q) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qmax = fmaxf(qmax, fabsf(o[e]));
+        unsigned r0 = 0, r1 = 0;
+        r0 = __builtin_amdgcn_cvt_pk_fp8_f32(o[0] * qs, o[1] * qs, r0, false);
+        r0 = __builtin_amdgcn_cvt_pk_fp8_f32(o[2] * qs, o[3] * qs, r0, true);
+        r1 = __builtin_amdgcn_cvt_pk_fp8_f32(o[4] * qs, o[5] * qs, r1, false);
+        r1 = __builtin_amdgcn_cvt_pk_fp8_f32(o[6] * qs, o[7] * qs, r1, true);
+        *reinterpret_cast<uint2*>(lq.q + (size_t)row * H + c * 8) = make_uint2(r0, r1);
+      }
     }
+  }
+  if (Q) {
+    __shared__ float wm[4];
+    qmax = wave_max(qmax);
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = qmax;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      atomicMax(lq.amax_next + (blockIdx.x & (UC2_AMAX_CELLS - 1)), __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
   }
 }
 
@@ -340,9 +384,9 @@ static int ln_bwd_blocks(int M) {                       // (an upper bound for b
   return nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
 }
 
-extern "C" int uc2_ln_fwd(int dtype, int M, int H, const void* x, const void* residual, const float* gamma,
-                          const float* beta, float eps, float drop_p, int drop_after, const uint64_t* seed_ptr, uint64_t seed_imm,
-                          void* y, float* mean, float* rstd, void* stream) {
+static int ln_fwd_impl(int dtype, int M, int H, const void* x, const void* residual, const float* gamma,
+                       const float* beta, float eps, float drop_p, int drop_after, const uint64_t* seed_ptr, uint64_t seed_imm,
+                       void* y, float* mean, float* rstd, const LnQ* lqp, void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
   UC2_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= LN_MAXC * 256);
   UC2_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
@@ -356,10 +400,15 @@ extern "C" int uc2_ln_fwd(int dtype, int M, int H, const void* x, const void* re
   if (v16) {
     const dim3 g8((M + 7) / 8);
     const int nc8 = (H / 8 + 31) / 32;
-#define LN_FWD16(NCC) hipLaunchKernelGGL((ln_fwd16_kernel<NCC>), g8, block, 0, st, M, H, (const bf16*)x, (const bf16*)residual, gamma, \
-                                         beta, eps, th, ks, seed_ptr, seed_imm, (bf16*)y, mean, rstd, drop_after)
+    const LnQ lq0 = lqp ? *lqp : LnQ{nullptr, nullptr, nullptr, nullptr, nullptr};
+#define LN_FWD16(NCC) do { if (lqp) hipLaunchKernelGGL((ln_fwd16_kernel<NCC, true>), g8, block, 0, st, M, H, (const bf16*)x, (const bf16*)residual, gamma, \
+                                         beta, eps, th, ks, seed_ptr, seed_imm, (bf16*)y, mean, rstd, drop_after, lq0); \
+                           else hipLaunchKernelGGL((ln_fwd16_kernel<NCC, false>), g8, block, 0, st, M, H, (const bf16*)x, (const bf16*)residual, gamma, \
+                                         beta, eps, th, ks, seed_ptr, seed_imm, (bf16*)y, mean, rstd, drop_after, lq0); } while (0)
     if (nc8 == 1) LN_FWD16(1); else if (nc8 == 2) LN_FWD16(2); else if (nc8 == 3) LN_FWD16(3); else LN_FWD16(4);
 #undef LN_FWD16
+  } else if (lqp) {
+    return -2;                                         // only the 16-byte bf16 kernel writes the e4m3 copy
   } else if (dtype == 0)
     hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, st, M, H, (const float*)x, (const float*)residual, gamma,
                        beta, eps, th, ks, seed_ptr, seed_imm, (float*)y, mean, rstd, drop_after);
@@ -368,6 +417,23 @@ extern "C" int uc2_ln_fwd(int dtype, int M, int H, const void* x, const void* re
                        beta, eps, th, ks, seed_ptr, seed_imm, (bf16*)y, mean, rstd, drop_after);
   UC2_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int uc2_ln_fwd(int dtype, int M, int H, const void* x, const void* residual, const float* gamma,
+                          const float* beta, float eps, float drop_p, int drop_after, const uint64_t* seed_ptr, uint64_t seed_imm,
+                          void* y, float* mean, float* rstd, void* stream) {
+  return ln_fwd_impl(dtype, M, H, x, residual, gamma, beta, eps, drop_p, drop_after, seed_ptr, seed_imm, y, mean, rstd, nullptr, stream);
+}
+// uc2_ln_fwd that also writes q_out = sat_e4m3(y * scale) for the fp8 GEMM that reads y (delayed scaling, cell groups as
+// uc2_fp8_quant_delayed).  bf16 rows of H % 8 == 0, H <= 1024, 16-byte aligned; returns -2 (nothing launched) otherwise.
+extern "C" int uc2_ln_fwd_q(int dtype, int M, int H, const void* x, const void* residual, const float* gamma,
+                            const float* beta, float eps, float drop_p, int drop_after, const uint64_t* seed_ptr, uint64_t seed_imm,
+                            void* y, float* mean, float* rstd, void* q_out, const void* amax_prev, void* amax_next, void* amax_clear,
+                            float* q_scale_out, void* stream) {
+  UC2_CHECK_ARG(q_out && amax_prev && amax_next && amax_clear && q_scale_out);
+  UC2_CHECK_ARG(amax_prev != amax_next && amax_next != amax_clear && amax_prev != amax_clear);
+  if (!(dtype == 1 && (H % 8) == 0 && H <= 1024 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual | (uintptr_t)q_out) & 15) == 0)) return -2;
+  const LnQ lq{(uint8_t*)q_out, (const unsigned*)amax_prev, (unsigned*)amax_next, (unsigned*)amax_clear, q_scale_out};
+  return ln_fwd_impl(dtype, M, H, x, residual, gamma, beta, eps, drop_p, drop_after, seed_ptr, seed_imm, y, mean, rstd, &lq, stream);
 }
 
 // The backward kernel is persistent (every workgroup strides over rows with its column sums in registers): launch exactly one
@@ -398,10 +464,10 @@ static int ln_bwd_nblocks(int dtype, int M, int H) {
 }
 
 // first stage only: dx / dres and the per-workgroup partial column sums in ws (want_dbias: also those of dx)
-extern "C" int uc2_ln_bwd_partial(int dtype, int M, int H, const void* dy, const void* x, const void* residual,
-                                  const float* gamma, const float* mean, const float* rstd, float drop_p, int drop_after,
-                                  const uint64_t* seed_ptr, uint64_t seed_imm, void* dx, void* dres, int want_dbias, void* ws,
-                                  void* stream) {
+static int ln_bwd_partial_impl(int dtype, int M, int H, const void* dy, const void* x, const void* residual,
+                               const float* gamma, const float* mean, const float* rstd, float drop_p, int drop_after,
+                               const uint64_t* seed_ptr, uint64_t seed_imm, void* dx, void* dres, int want_dbias, void* ws,
+                               void* q_out, const void* q_prev, void* q_next, void* q_clear, float* q_scale_out, void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
   UC2_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= LN_MAXC * 256);
   UC2_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
@@ -413,9 +479,14 @@ extern "C" int uc2_ln_bwd_partial(int dtype, int M, int H, const void* dy, const
   hipStream_t st = (hipStream_t)stream;
   const int nc = (H + 255) / 256;
 #define LN_BWD_LAUNCH(TT, NCC)                                                                                      \
-  hipLaunchKernelGGL((ln_bwd_kernel<TT, NCC>), dim3(nb), dim3(256), 0, st, M, H, (const TT*)dy, (const TT*)x,        \
+  do {                                                                                                              \
+    if (q_out) hipLaunchKernelGGL((ln_bwd_kernel<TT, NCC, true>), dim3(nb), dim3(256), 0, st, M, H, (const TT*)dy, (const TT*)x, \
                      (const TT*)residual, gamma, mean, rstd, th, ks, seed_ptr, seed_imm, (TT*)dx, (TT*)dres,         \
-                     (float*)ws, want_dbias ? 1 : 0, drop_after)
+                     (float*)ws, want_dbias ? 1 : 0, drop_after, (uint8_t*)q_out, (const unsigned*)q_prev, (unsigned*)q_next, (unsigned*)q_clear, q_scale_out); \
+    else hipLaunchKernelGGL((ln_bwd_kernel<TT, NCC, false>), dim3(nb), dim3(256), 0, st, M, H, (const TT*)dy, (const TT*)x, \
+                     (const TT*)residual, gamma, mean, rstd, th, ks, seed_ptr, seed_imm, (TT*)dx, (TT*)dres,         \
+                     (float*)ws, want_dbias ? 1 : 0, drop_after, (uint8_t*)nullptr, (const unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, (float*)nullptr); \
+  } while (0)
   if (dtype == 0) {
     if (nc == 1) LN_BWD_LAUNCH(float, 1); else if (nc == 2) LN_BWD_LAUNCH(float, 2);
     else if (nc == 3) LN_BWD_LAUNCH(float, 3); else LN_BWD_LAUNCH(float, 4);
@@ -426,6 +497,25 @@ extern "C" int uc2_ln_bwd_partial(int dtype, int M, int H, const void* dy, const
 #undef LN_BWD_LAUNCH
   UC2_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int uc2_ln_bwd_partial(int dtype, int M, int H, const void* dy, const void* x, const void* residual,
+                                  const float* gamma, const float* mean, const float* rstd, float drop_p, int drop_after,
+                                  const uint64_t* seed_ptr, uint64_t seed_imm, void* dx, void* dres, int want_dbias, void* ws,
+                                  void* stream) {
+  return ln_bwd_partial_impl(dtype, M, H, dy, x, residual, gamma, mean, rstd, drop_p, drop_after, seed_ptr, seed_imm, dx, dres, want_dbias,
+                             ws, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+// uc2_ln_bwd_partial that also writes q_out = sat_e4m3(dx * scale): the e4m3 operand of the dense layer's input-gradient GEMM in fp8
+// mode (delayed scaling, cell groups as uc2_fp8_quant_delayed).  bf16 only (-2 otherwise, nothing launched); dx must be given.
+extern "C" int uc2_ln_bwd_partial_q(int dtype, int M, int H, const void* dy, const void* x, const void* residual,
+                                    const float* gamma, const float* mean, const float* rstd, float drop_p, int drop_after,
+                                    const uint64_t* seed_ptr, uint64_t seed_imm, void* dx, void* dres, int want_dbias, void* ws,
+                                    void* q_out, const void* amax_prev, void* amax_next, void* amax_clear, float* q_scale_out, void* stream) {
+  UC2_CHECK_ARG(dx && q_out && amax_prev && amax_next && amax_clear && q_scale_out);
+  UC2_CHECK_ARG(amax_prev != amax_next && amax_next != amax_clear && amax_prev != amax_clear);
+  if (dtype != 1 || ((uintptr_t)q_out & 3)) return -2;
+  return ln_bwd_partial_impl(dtype, M, H, dy, x, residual, gamma, mean, rstd, drop_p, drop_after, seed_ptr, seed_imm, dx, dres, want_dbias,
+                             ws, q_out, amax_prev, amax_next, amax_clear, q_scale_out, stream);
 }
 
 // second stage: dgamma / dbeta / dbias += the column sums of the partial rows a uc2_ln_bwd_partial of the same (dtype, M, H) left

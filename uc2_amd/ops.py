@@ -523,6 +523,18 @@ def fp8_quantize(x2, transpose=False, amax=None):
 
 FP8_DELAYED = os.environ.get("UC2_FP8_DELAYED", "1") != "0"      # activations: delayed scaling (one pass) from the second use of a tensor role on
 _FP8_HIST = {}             # tensor role -> [three amax cells (int32), index of the cell holding the previous maximum]
+AMAX_CELLS = 16            # include/uc2_hip.h UC2_AMAX_CELLS: a maximum is kept in 16 cells (producers spread their atomics), three groups per role
+
+
+def _fp8_rotate(h):
+    """(previous, next, clear) device pointers of a role's three cell groups, and advance the role's history by one use"""
+    cells, i = h
+    base, step = cells.data_ptr(), 4 * AMAX_CELLS
+    h[1] = (i + 1) % 3
+    return base + i * step, base + ((i + 1) % 3) * step, base + ((i + 2) % 3) * step
+
+
+_FP8_PREQ = {}             # data_ptr of a layer output -> (e4m3 copy, scale) written by that layer's last LayerNorm for the next layer's QKV GEMM
 FP8_TAG = None             # set by the model's forward (task name, loss or scores): part of every role key, saved by BertLayerFn for its backward
 
 
@@ -534,18 +546,16 @@ def fp8_quantize_act(x2, key=None):
         return fp8_quantize(x2)
     h = _FP8_HIST.get(key)
     if h is None:
-        cells = torch.zeros(3, dtype=torch.int32, device=x2.device)
+        cells = torch.zeros(3 * AMAX_CELLS, dtype=torch.int32, device=x2.device)
         x8, scale = fp8_quantize(x2, amax=fp8_amax(x2, cells[0:1]))
         _FP8_HIST[key] = [cells, 0]
         return x8, scale
-    cells, i = h
     rows, cols = x2.shape
     assert x2.is_contiguous()
     scale = _fp8_cell(x2.device)[1]
     out = torch.empty((rows, cols), dtype=torch.uint8, device=x2.device)
-    call("uc2_fp8_quant_delayed", dt(x2.dtype), rows, cols, ptr(x2), x2.stride(0), ptr(cells[i:i + 1]), ptr(cells[(i + 1) % 3:(i + 1) % 3 + 1]),
-         ptr(cells[(i + 2) % 3:(i + 2) % 3 + 1]), ptr(scale), ptr(out), out.stride(0), stream())
-    h[1] = (i + 1) % 3
+    prev, nxt, clr = _fp8_rotate(h)
+    call("uc2_fp8_quant_delayed", dt(x2.dtype), rows, cols, ptr(x2), x2.stride(0), prev, nxt, clr, ptr(scale), ptr(out), out.stride(0), stream())
     return out, scale
 
 
@@ -580,7 +590,8 @@ def gemm_fp8_q(a8, sa, b8, sb, q_key, bias=None, epi=EPI_NONE, aux_in=None, aux_
         return None
     M, K = a8.shape
     N = b8.shape[0]
-    cells, i = h
+    if M % 256 or N % 256 or K % 256:                     # (the ping-pong kernel's shapes: do not advance the history for a call that cannot run)
+        return None
     out = torch.empty((M, N), dtype=torch.bfloat16, device=a8.device)
     q8 = torch.empty((M, N), dtype=torch.uint8, device=a8.device)
     scale = _fp8_cell(a8.device)[1]
@@ -592,16 +603,17 @@ def gemm_fp8_q(a8, sa, b8, sb, q_key, bias=None, epi=EPI_NONE, aux_in=None, aux_
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    i_was = h[1]
+    prev, nxt, clr = _fp8_rotate(h)
     rc = _lib.load().uc2_gemm_fp8_q(M, N, K, ptr(a8), a8.stride(0), ptr(b8), b8.stride(0), ptr(sa), ptr(sb), ptr(out), out.stride(0),
-                                    ptr(bias), epi, ptr(aux_in), ptr(aux_out), ldaux, flags, ptr(q8), q8.stride(0), ptr(cells[i:i + 1]),
-                                    ptr(cells[(i + 1) % 3:(i + 1) % 3 + 1]), ptr(cells[(i + 2) % 3:(i + 2) % 3 + 1]), ptr(scale), stream())
+                                    ptr(bias), epi, ptr(aux_in), ptr(aux_out), ldaux, flags, ptr(q8), q8.stride(0), prev, nxt, clr, ptr(scale), stream())
     if rc == -2:
+        h[1] = i_was
         return None
     _lib.check(rc)
     if timer is not None:
         e1.record()
         timer.add(("fp8", int(epi)), 2.0 * M * N * K, e0, e1)
-    h[1] = (i + 1) % 3
     return out, (q8, scale)
 
 
@@ -864,24 +876,49 @@ def colsum_accum(x2, out, rowmask=None):
     call("uc2_colsum_accum", dt(x2.dtype), M, N, ptr(x2), x2.stride(0), ptr(rowmask), ptr(out), stream())
 
 
-def ln_fwd(x2, res2, gamma, beta, eps, drop_p=0.0, seed=None, seed_imm=0, want_stats=True, drop_after=False):
+def _fp8_hist_for(q_key, device):
+    """the history of a tensor role if a producer may fuse its quantisation now (fp8 delayed scaling on, the role has been used)"""
+    if q_key is None or not FP8_DELAYED or torch.cuda.is_current_stream_capturing():
+        return None
+    return _FP8_HIST.get(q_key)
+
+
+def ln_fwd(x2, res2, gamma, beta, eps, drop_p=0.0, seed=None, seed_imm=0, want_stats=True, drop_after=False, q_key=None):
     """y = LN(dropout(x) + res) (drop_after False: the encoder's dense->dropout->LN tails) or
-    y = dropout(LN(x + res)) (drop_after True: the embedding tails, model/model.py:331-333,361-363)"""
+    y = dropout(LN(x + res)) (drop_after True: the embedding tails, model/model.py:331-333,361-363).
+    q_key (fp8 mode): the tensor role of y at the GEMM that reads it -- returns a 4th value, (y8, scale) written by the same kernel
+    (uc2_ln_fwd_q, delayed scaling) or None when that role has no history yet / the kernel does not take the shape"""
     M, H = x2.shape
     y = torch.empty_like(x2)
     mean = torch.empty(M, dtype=torch.float32, device=x2.device) if want_stats else None
     rstd = torch.empty(M, dtype=torch.float32, device=x2.device) if want_stats else None
+    h = _fp8_hist_for(q_key, x2.device) if x2.dtype == torch.bfloat16 and H % 8 == 0 and H <= 1024 else None
+    q = None
     with _Timed("ln_fwd", M * H * x2.element_size() * (3 if res2 is not None else 2)):
-        call("uc2_ln_fwd", dt(x2.dtype), M, H, ptr(x2), ptr(res2), ptr(gamma), ptr(beta), eps, drop_p, int(drop_after),
-             ptr(seed), seed_imm, ptr(y), ptr(mean), ptr(rstd), stream())
-    return y, mean, rstd
+        if h is not None:
+            y8 = torch.empty((M, H), dtype=torch.uint8, device=x2.device)
+            scale = _fp8_cell(x2.device)[1]
+            i_was = h[1]
+            prev, nxt, clr = _fp8_rotate(h)
+            rc = _lib.load().uc2_ln_fwd_q(dt(x2.dtype), M, H, ptr(x2), ptr(res2), ptr(gamma), ptr(beta), eps, drop_p, int(drop_after),
+                                          ptr(seed), seed_imm, ptr(y), ptr(mean), ptr(rstd), ptr(y8), prev, nxt, clr, ptr(scale), stream())
+            if rc == -2:
+                h[1] = i_was
+                h = None
+            else:
+                _lib.check(rc)
+                q = (y8, scale)
+        if h is None:
+            call("uc2_ln_fwd", dt(x2.dtype), M, H, ptr(x2), ptr(res2), ptr(gamma), ptr(beta), eps, drop_p, int(drop_after),
+                 ptr(seed), seed_imm, ptr(y), ptr(mean), ptr(rstd), stream())
+    return (y, mean, rstd, q) if q_key is not None else (y, mean, rstd)
 
 
 LN_REDUCE_SIDE = os.environ.get("UC2_LN_REDUCE_SIDE", "1") != "0"
 
 
 def ln_bwd(dy2, x2, res2, gamma, mean, rstd, dgamma, dbeta, drop_p=0.0, seed=None, seed_imm=0, need_dres=True,
-           dbias=None, drop_after=False):
+           dbias=None, drop_after=False, q_key=None):
     """returns (dx, dres); with drop_p == 0 they are the same tensor.  dbias (optional, fp32 [H]) accumulates
     the column sum of dx: the bias gradient of the dense layer that produced x, for free in the same pass.
     Two kernels: the streaming pass (dx, dres, per-workgroup partial column sums) and a small reduction of the partials into
@@ -895,9 +932,26 @@ def ln_bwd(dy2, x2, res2, gamma, mean, rstd, dgamma, dbeta, drop_p=0.0, seed=Non
     dres = torch.empty_like(x2) if (drop_p > 0.0 and need_dres and not drop_after) else None
     streams = 3 + (1 if res2 is not None else 0) + (1 if dres is not None else 0)     # dy, x, (res) in; dx, (dres) out
     d = dt(x2.dtype)
+    h = _fp8_hist_for(q_key, x2.device) if x2.dtype == torch.bfloat16 else None
+    q = None
     with _Timed("ln_bwd", M * H * x2.element_size() * streams):
-        call("uc2_ln_bwd_partial", d, M, H, ptr(dy2), ptr(x2), ptr(res2), ptr(gamma), ptr(mean), ptr(rstd), drop_p,
-             int(drop_after), ptr(seed), seed_imm, ptr(dx), ptr(dres), int(dbias is not None), ptr(ws), stream())
+        if h is not None:                  # fp8 mode: the same pass writes the e4m3 copy of dx the input-gradient GEMM reads
+            d8 = torch.empty((M, H), dtype=torch.uint8, device=x2.device)
+            scale = _fp8_cell(x2.device)[1]
+            i_was = h[1]
+            prev, nxt, clr = _fp8_rotate(h)
+            rc = lib.uc2_ln_bwd_partial_q(d, M, H, ptr(dy2), ptr(x2), ptr(res2), ptr(gamma), ptr(mean), ptr(rstd), drop_p,
+                                          int(drop_after), ptr(seed), seed_imm, ptr(dx), ptr(dres), int(dbias is not None), ptr(ws),
+                                          ptr(d8), prev, nxt, clr, ptr(scale), stream())
+            if rc == -2:
+                h[1] = i_was
+                h = None
+            else:
+                _lib.check(rc)
+                q = (d8, scale)
+        if h is None:
+            call("uc2_ln_bwd_partial", d, M, H, ptr(dy2), ptr(x2), ptr(res2), ptr(gamma), ptr(mean), ptr(rstd), drop_p,
+                 int(drop_after), ptr(seed), seed_imm, ptr(dx), ptr(dres), int(dbias is not None), ptr(ws), stream())
 
     def reduce():
         call("uc2_ln_bwd_reduce", d, M, H, ptr(ws), ptr(dgamma), ptr(dbeta), ptr(dbias), stream())
@@ -906,6 +960,8 @@ def ln_bwd(dy2, x2, res2, gamma, mean, rstd, dgamma, dbeta, drop_p=0.0, seed=Non
             _on_side_stream(x2.device, reduce, (ws,))
         elif not (LN_REDUCE_BATCH and M < WGRAD_SIDE_MIN_ROWS and _defer_ln_reduction(d, M, H, ws, dgamma, dbeta, dbias)):
             reduce()
+    if q_key is not None:
+        return dx, (dres if dres is not None else dx), q
     return dx, (dres if dres is not None else dx)
 
 
@@ -1112,13 +1168,23 @@ class BertLayerFn(torch.autograd.Function):
         pre = torch.empty((M, I_), dtype=dtype, device=x.device)
         if fp8:
             # e4m3 operands for the four forward GEMMs (per-tensor scales computed on the device), bf16 outputs
-            qkv = linear_fwd_fp8(x2, st, P["qw"], P["vw"], (3 * H, H), bqkv, role="x", tag=FP8_TAG)
+            # tensor roles (keys of the delayed-scaling histories): a role is named by its CONSUMER; the layer input's by the layer id,
+            # so that the layer above can write the e4m3 copy from its last LayerNorm (handed over through _FP8_PREQ)
+            kx = (id(st), ("layer", cfg["layer_id"]), "fwd", "x", FP8_TAG)
+            ky = (id(st), ("layer", cfg["layer_id"] + 1), "fwd", "x", FP8_TAG)
+            ka = (id(st), st.offsets[id(P["iw"])], "fwd", "a", FP8_TAG)
+            xq = _FP8_PREQ.pop(x2.data_ptr(), None)
+            if xq is not None and tuple(xq[0].shape) != (M, H):
+                xq = None
+            w8_, sw_ = _fp8_weight(st, P["qw"], P["vw"], (3 * H, H), False)
+            x8_, sx_ = xq if xq is not None else fp8_quantize_act(x2, kx)
+            qkv = gemm_fp8(x8_, sx_, w8_, sw_, bias=bqkv)
             ctxv, lse = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn)
             o1 = linear_fwd_fp8(ctxv, st, P["ow"], P["ow"], (H, H), P["ob"].data, role="ctx", tag=FP8_TAG)
-            a, mean1, rstd1 = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, s_ln1)
+            a, mean1, rstd1, aq = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, s_ln1, q_key=ka)
             # (the FFN1 GEMM's epilogue writes the e4m3 copy of u that FFN2 reads: no quantisation pass over [tokens, 4H])
             u, uq = linear_fwd_fp8(a, st, P["iw"], P["iw"], (I_, H), P["ib"].data, EPI_GELU, pre, flags=GEMM_AUX_DERIV, role="a", tag=FP8_TAG,
-                                   q_key=(id(st), st.offsets[id(P["fw"])], "fwd", "u", FP8_TAG))
+                                   pre_q=aq, q_key=(id(st), st.offsets[id(P["fw"])], "fwd", "u", FP8_TAG))
             o2 = linear_fwd_fp8(u, st, P["fw"], P["fw"], (H, I_), P["fb"].data, role="u", tag=FP8_TAG, pre_q=uq)
         else:
             qkv = linear_fwd(x2, wqkv, bqkv)
@@ -1129,7 +1195,13 @@ class BertLayerFn(torch.autograd.Function):
             # the forward's Phi(x) there, and the backward's dGELU epilogue becomes a plain multiply
             u = linear_fwd(a, st.compute(P["iw"], dtype), P["ib"].data, EPI_GELU, pre, flags=GEMM_AUX_DERIV)
             o2 = linear_fwd(u, st.compute(P["fw"], dtype), P["fb"].data)
-        y, mean2, rstd2 = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, s_ln2)
+        if fp8:
+            y, mean2, rstd2, yq = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, s_ln2, q_key=ky)
+            _FP8_PREQ.clear()                          # (at most one hand-over alive: the last layer's copy has no fp8 consumer)
+            if yq is not None:
+                _FP8_PREQ[y.data_ptr()] = yq
+        else:
+            y, mean2, rstd2 = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, s_ln2)
 
         ctx.save_for_backward(x2, mask2d, qkv, ctxv, lse, o1, mean1, rstd1, a, pre, u, o2, mean2, rstd2, seed)
         ctx.layer, ctx.cfg, ctx.shape, ctx.p = layer, cfg, (B, L, H, nh, D), (p_h, p_a, (s_attn, s_ln1, s_ln2))
@@ -1152,9 +1224,13 @@ class BertLayerFn(torch.autograd.Function):
         G = st.grad_buf
 
         # LN2 and FFN
-        d_o2, dz2 = ln_bwd(dy2, o2, a, P["g2"].data, mean2, rstd2, G(P["g2"]), G(P["b2"]), p_h, seed, s_ln2,
-                           dbias=G(P["fb"]))
         fp8 = ctx.fp8
+        if fp8:
+            d_o2, dz2, dq2 = ln_bwd(dy2, o2, a, P["g2"].data, mean2, rstd2, G(P["g2"]), G(P["b2"]), p_h, seed, s_ln2, dbias=G(P["fb"]),
+                                    q_key=(id(st), st.offsets[id(P["fw"])], "bwd", "d_o2", ctx.fp8_tag))
+        else:
+            d_o2, dz2 = ln_bwd(dy2, o2, a, P["g2"].data, mean2, rstd2, G(P["g2"]), G(P["b2"]), p_h, seed, s_ln2,
+                               dbias=G(P["fb"]))
         I_ = P["iw"].shape[0]
         # k-contiguous copies W^T for the input-gradient GEMMs (bf16; refreshed once per optimizer step, one launch for all)
         # (from DGRAD_WT_MIN_ROWS tokens)
@@ -1166,7 +1242,7 @@ class BertLayerFn(torch.autograd.Function):
         wgrad(d_o2, u, G(P["fw"]))
         if fp8:
             d_pre, dq = linear_dgrad_fp8(d_o2, st, P["fw"], P["fw"], (H, I_), EPI_DGELU, pre, colsum_out=G(P["ib"]), flags=GEMM_AUX_DERIV, role="d_o2",
-                                         tag=ctx.fp8_tag, q_key=(id(st), st.offsets[id(P["iw"])], "bwd", "d_pre", ctx.fp8_tag))
+                                         tag=ctx.fp8_tag, pre_q=dq2, q_key=(id(st), st.offsets[id(P["iw"])], "bwd", "d_pre", ctx.fp8_tag))
         else:
             d_pre = linear_dgrad(d_o2, st.compute(P["fw"], dtype), EPI_DGELU, pre, colsum_out=G(P["ib"]),
                                  flags=GEMM_AUX_DERIV, wt=WT(P["fw"]))                         # + d(intermediate bias)
@@ -1176,10 +1252,15 @@ class BertLayerFn(torch.autograd.Function):
         else:
             da = linear_dgrad(d_pre, st.compute(P["iw"], dtype), EPI_ADD, dz2, wt=WT(P["iw"]))
         # LN1, output projection, attention, fused QKV
-        d_o1, dz1 = ln_bwd(da, o1, x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, s_ln1,
-                           dbias=G(P["ob"]))
+        if fp8:
+            d_o1, dz1, dq1 = ln_bwd(da, o1, x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, s_ln1, dbias=G(P["ob"]),
+                                    q_key=(id(st), st.offsets[id(P["ow"])], "bwd", "d_o1", ctx.fp8_tag))
+        else:
+            d_o1, dz1 = ln_bwd(da, o1, x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, s_ln1,
+                               dbias=G(P["ob"]))
+            dq1 = None
         wgrad(d_o1, ctxv, G(P["ow"]))
-        dctx = linear_dgrad_fp8(d_o1, st, P["ow"], P["ow"], (H, H), role="d_o1", tag=ctx.fp8_tag) if fp8 else linear_dgrad(d_o1, st.compute(P["ow"], dtype), wt=WT(P["ow"]))
+        dctx = linear_dgrad_fp8(d_o1, st, P["ow"], P["ow"], (H, H), role="d_o1", tag=ctx.fp8_tag, pre_q=dq1) if fp8 else linear_dgrad(d_o1, st.compute(P["ow"], dtype), wt=WT(P["ow"]))
         dwqkv = st.grad_span(P["qw"], P["vw"], (3 * H, H))
         dbqkv = st.grad_span(P["qb"], P["vb"], (3 * H,))
         # d(q|k|v bias) comes out of attn_bwd: column sums of the dQ/dK/dV accumulators, added up per workgroup in LDS and
