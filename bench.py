@@ -356,7 +356,8 @@ def other_configs(dev, timed, steps):
             "mfma_frac_encoder_vs_bf16_peak": round(BL * steps / d * gflop * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
             "note": "BASELINE.json configs[4] geometry on one GPU (24L/1024H/16 heads/4096, 80 tokens + 50 regions), ITM training "
                     "step incl. clip + AdamW; %s" % ("bf16 GEMMs" if tag == "bf16" else
-                    "e4m3 forward and input-gradient GEMMs (per-tensor power-of-two scales, just-in-time quantisation), bf16 weight gradients")}
+                    "e4m3 forward and input-gradient GEMMs on the ping-pong kernel (gemm_pp8.hip; per-tensor power-of-two scales, delayed per task: one-pass "
+                    "quantisation, fused into the LayerNorm kernels and the FFN GEMM epilogues), bf16 weight gradients")}
     del model, opt, lb
     torch.cuda.empty_cache()
     return out

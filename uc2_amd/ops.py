@@ -534,6 +534,18 @@ def _fp8_rotate(h):
     return base + i * step, base + ((i + 1) % 3) * step, base + ((i + 2) % 3) * step
 
 
+_ST_UID = [0]
+
+
+def _st_uid(st):
+    """a number that names this parameter store for the life of the process (id() of a collected store can come back with another model)"""
+    u = st.__dict__.get("_fp8_uid")
+    if u is None:
+        _ST_UID[0] += 1
+        u = st.__dict__["_fp8_uid"] = _ST_UID[0]
+    return u
+
+
 _FP8_PREQ = {}             # data_ptr of a layer output -> (e4m3 copy, scale) written by that layer's last LayerNorm for the next layer's QKV GEMM
 FP8_TAG = None             # set by the model's forward (task name, loss or scores): part of every role key, saved by BertLayerFn for its backward
 
@@ -639,7 +651,7 @@ def linear_fwd_fp8(x2, st, p_first, p_last, shape, bias, epi=EPI_NONE, aux_out=N
     """pre_q: (x8, scale) already produced by the GEMM that made x2 (its fused e4m3 stream); q_key: the consumer's tensor role of THIS
     GEMM's output -- returns (y, (y8, scale) or None) then"""
     w8, sw = _fp8_weight(st, p_first, p_last, shape, False)
-    x8, sx = pre_q if pre_q is not None else fp8_quantize_act(x2, None if role is None else (id(st), st.offsets[id(p_first)], "fwd", role, tag))
+    x8, sx = pre_q if pre_q is not None else fp8_quantize_act(x2, None if role is None else (_st_uid(st), st.offsets[id(p_first)], "fwd", role, tag))
     if q_key is not None:
         r = gemm_fp8_q(x8, sx, w8, sw, q_key, bias=bias, epi=epi, aux_out=aux_out, flags=flags)
         return r if r is not None else (gemm_fp8(x8, sx, w8, sw, bias=bias, epi=epi, aux_out=aux_out, flags=flags), None)
@@ -649,7 +661,7 @@ def linear_fwd_fp8(x2, st, p_first, p_last, shape, bias, epi=EPI_NONE, aux_out=N
 def linear_dgrad_fp8(dy2, st, p_first, p_last, shape, epi=EPI_NONE, aux_in=None, colsum_out=None, flags=0, role=None, tag=None, pre_q=None, q_key=None):
     """dX = epi(dY W): the k-contiguous operand is the transposed e4m3 copy of W ([in, out])"""
     wt8, sw = _fp8_weight(st, p_first, p_last, shape, True)
-    d8, sd = pre_q if pre_q is not None else fp8_quantize_act(dy2, None if role is None else (id(st), st.offsets[id(p_first)], "bwd", role, tag))
+    d8, sd = pre_q if pre_q is not None else fp8_quantize_act(dy2, None if role is None else (_st_uid(st), st.offsets[id(p_first)], "bwd", role, tag))
     if q_key is not None:
         r = gemm_fp8_q(d8, sd, wt8, sw, q_key, epi=epi, aux_in=aux_in, aux_out=colsum_out, flags=flags)
         return r if r is not None else (gemm_fp8(d8, sd, wt8, sw, epi=epi, aux_in=aux_in, aux_out=colsum_out, flags=flags), None)
@@ -1170,9 +1182,9 @@ class BertLayerFn(torch.autograd.Function):
             # e4m3 operands for the four forward GEMMs (per-tensor scales computed on the device), bf16 outputs
             # tensor roles (keys of the delayed-scaling histories): a role is named by its CONSUMER; the layer input's by the layer id,
             # so that the layer above can write the e4m3 copy from its last LayerNorm (handed over through _FP8_PREQ)
-            kx = (id(st), ("layer", cfg["layer_id"]), "fwd", "x", FP8_TAG)
-            ky = (id(st), ("layer", cfg["layer_id"] + 1), "fwd", "x", FP8_TAG)
-            ka = (id(st), st.offsets[id(P["iw"])], "fwd", "a", FP8_TAG)
+            kx = (_st_uid(st), ("layer", cfg["layer_id"]), "fwd", "x", FP8_TAG)
+            ky = (_st_uid(st), ("layer", cfg["layer_id"] + 1), "fwd", "x", FP8_TAG)
+            ka = (_st_uid(st), st.offsets[id(P["iw"])], "fwd", "a", FP8_TAG)
             xq = _FP8_PREQ.pop(x2.data_ptr(), None)
             if xq is not None and tuple(xq[0].shape) != (M, H):
                 xq = None
@@ -1184,7 +1196,7 @@ class BertLayerFn(torch.autograd.Function):
             a, mean1, rstd1, aq = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, s_ln1, q_key=ka)
             # (the FFN1 GEMM's epilogue writes the e4m3 copy of u that FFN2 reads: no quantisation pass over [tokens, 4H])
             u, uq = linear_fwd_fp8(a, st, P["iw"], P["iw"], (I_, H), P["ib"].data, EPI_GELU, pre, flags=GEMM_AUX_DERIV, role="a", tag=FP8_TAG,
-                                   pre_q=aq, q_key=(id(st), st.offsets[id(P["fw"])], "fwd", "u", FP8_TAG))
+                                   pre_q=aq, q_key=(_st_uid(st), st.offsets[id(P["fw"])], "fwd", "u", FP8_TAG))
             o2 = linear_fwd_fp8(u, st, P["fw"], P["fw"], (H, I_), P["fb"].data, role="u", tag=FP8_TAG, pre_q=uq)
         else:
             qkv = linear_fwd(x2, wqkv, bqkv)
@@ -1227,7 +1239,7 @@ class BertLayerFn(torch.autograd.Function):
         fp8 = ctx.fp8
         if fp8:
             d_o2, dz2, dq2 = ln_bwd(dy2, o2, a, P["g2"].data, mean2, rstd2, G(P["g2"]), G(P["b2"]), p_h, seed, s_ln2, dbias=G(P["fb"]),
-                                    q_key=(id(st), st.offsets[id(P["fw"])], "bwd", "d_o2", ctx.fp8_tag))
+                                    q_key=(_st_uid(st), st.offsets[id(P["fw"])], "bwd", "d_o2", ctx.fp8_tag))
         else:
             d_o2, dz2 = ln_bwd(dy2, o2, a, P["g2"].data, mean2, rstd2, G(P["g2"]), G(P["b2"]), p_h, seed, s_ln2,
                                dbias=G(P["fb"]))
@@ -1242,7 +1254,7 @@ class BertLayerFn(torch.autograd.Function):
         wgrad(d_o2, u, G(P["fw"]))
         if fp8:
             d_pre, dq = linear_dgrad_fp8(d_o2, st, P["fw"], P["fw"], (H, I_), EPI_DGELU, pre, colsum_out=G(P["ib"]), flags=GEMM_AUX_DERIV, role="d_o2",
-                                         tag=ctx.fp8_tag, pre_q=dq2, q_key=(id(st), st.offsets[id(P["iw"])], "bwd", "d_pre", ctx.fp8_tag))
+                                         tag=ctx.fp8_tag, pre_q=dq2, q_key=(_st_uid(st), st.offsets[id(P["iw"])], "bwd", "d_pre", ctx.fp8_tag))
         else:
             d_pre = linear_dgrad(d_o2, st.compute(P["fw"], dtype), EPI_DGELU, pre, colsum_out=G(P["ib"]),
                                  flags=GEMM_AUX_DERIV, wt=WT(P["fw"]))                         # + d(intermediate bias)
@@ -1254,7 +1266,7 @@ class BertLayerFn(torch.autograd.Function):
         # LN1, output projection, attention, fused QKV
         if fp8:
             d_o1, dz1, dq1 = ln_bwd(da, o1, x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, s_ln1, dbias=G(P["ob"]),
-                                    q_key=(id(st), st.offsets[id(P["ow"])], "bwd", "d_o1", ctx.fp8_tag))
+                                    q_key=(_st_uid(st), st.offsets[id(P["ow"])], "bwd", "d_o1", ctx.fp8_tag))
         else:
             d_o1, dz1 = ln_bwd(da, o1, x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, s_ln1,
                                dbias=G(P["ob"]))
