@@ -88,6 +88,15 @@ int uc2_gemm_queued(int dtype, int trans_a, int trans_b, int M, int N, int K, co
                     void* queue, void* stream);
 int uc2_gemm_splitk_reduce(int M, int N, void* C, int ldc, int split_k, int accumulate, const void* workspace,
                            size_t workspace_bytes, void* stream);
+/* C[M,N] (bf16) = dropout_p(A[M,K] W[N,K]^T + bias) + residual: the sum that the LayerNorm of BertSelfOutput / BertOutput normalises
+ * (model/layer.py:111-115, :152-156: dense -> dropout -> LayerNorm(hidden + input)), produced in the GEMM's epilogue.  The mask is the
+ * one uc2_ln_fwd / uc2_ln_bwd derive from (seed_imm + *seed_ptr, row * N + column), so the caller follows with uc2_ln_fwd(x = C,
+ * residual = NULL, drop_p = 0) and, in the backward, uc2_ln_bwd*(x = C, residual = NULL, drop_p, drop_after = 2).  bf16 operands, the
+ * ping-pong kernel only: returns -2 with nothing launched unless M % 256 == 0, N % 256 == 0, K % 128 == 0, every pointer 16-byte
+ * aligned, every leading dimension a multiple of 8 and both operands below 4 GiB (the caller then keeps the unfused form). */
+int uc2_gemm_drop_residual(int M, int N, int K, const void* A, int lda, const void* W, int ldw, void* C, int ldc, const float* bias,
+                           const void* residual, int ldres, float p_drop, const uint64_t* seed_ptr, uint64_t seed_imm, int flags,
+                           void* queue, void* stream);
 /* Diagnostics: number of uc2_gemm / uc2_gemm_queued calls since load (or since the last reset != 0) that named a ping-pong kernel
  * (variant 8 / 9 / 12 / 13) and were run by another kernel because the shape, an alignment or the 32-bit staging-offset limit
  * (an operand of 4 GiB or more) did not qualify.  bench.py prints it as config.gemm_fallbacks; nothing selects a kernel from it. */
@@ -148,6 +157,8 @@ int uc2_gemm_fp8(int M, int N, int K, const void* A8, int lda, const void* B8, i
  *      LayerNorm(x + residual) tails at model/layer.py:111-115,152-156; embeddings model/model.py:331,358-362) -----
  *   drop_after == 0: y = LN(dropout(x) + residual) * gamma + beta     (encoder tails, model/layer.py:113-114,154-155)
  *   drop_after == 1: y = dropout(LN(x + residual) * gamma + beta)     (embedding tails, model/model.py:331-333,361-363)
+ *   drop_after == 2 (backward only, residual == NULL): x is already dropout(dense) + residual (uc2_gemm_drop_residual): the mask
+ *                    goes on dx only, dres is the unmasked gradient.
  *   mean/rstd [M] saved for the backward.
  *   backward: dx (grad of x), dres (grad of residual; may be NULL; equals dx when drop_p == 0), dgamma/dbeta
  *   accumulated (+=), and optionally dbias += column-sum(dx) = bias gradient of the dense layer producing x. */

@@ -192,6 +192,21 @@ def test_layernorm_dropout_consistency():
     assert abs(rate - p) < 0.01, rate
     y3, _, _ = ops.ln_fwd(ones, zero, g, b, 1e-12, p, seed, 8)
     assert not torch.equal(y1, y3)                    # another site id -> another mask
+    # the variate is separable (row hash ^ column-piece hash, common.h): neighbours must still drop independently
+    big = torch.ones((8192, H), device=DEV)
+    yb, _, _ = ops.ln_fwd(big, torch.zeros_like(big), g, b, 1e-12, p, seed, 7)
+    d = ~(yb > 0)
+    assert abs(d.float().mean().item() - p) < 2e-3
+    for dc in (1, 2, 3, 4, 7, 191):                   # inside a piece, across pieces, far apart
+        j = (d[:, :-dc] & d[:, dc:]).float().mean().item()
+        assert abs(j - p * p) < 6e-4, (dc, j)
+    for dr in (1, 2, 5, 256):
+        j = (d[:-dr] & d[dr:]).float().mean().item()
+        assert abs(j - p * p) < 6e-4, (dr, j)
+    rect = (d[:-1, :-4] & d[:-1, 4:] & d[1:, :-4] & d[1:, 4:]).float().mean().item()      # the four corners of a (row, piece) rectangle
+    assert abs(rect - p ** 4) < 3e-5, rect
+    rows, cols = d.float().sum(1), d.float().sum(0)
+    assert 0.8 < rows.var().item() / (H * p * (1 - p)) < 1.2 and 0.8 < cols.var().item() / (8192 * p * (1 - p)) < 1.2
     # backward: gradient wrt x is zero exactly where the element was dropped
     y, mean, rstd = ops.ln_fwd(x, zero, g, b, 1e-12, p, seed, 7)
     dy = rnd((M, H), 3)
@@ -199,6 +214,81 @@ def test_layernorm_dropout_consistency():
     dx, dres = ops.ln_bwd(dy, x, zero, g, mean, rstd, dg, db, p, seed, 7)
     assert torch.equal(dx == 0, ~keep)
     assert torch.allclose(dx[keep], dres[keep] / (1 - p), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("M,N,K,p", [(512, 768, 768, 0.1), (768, 768, 3072, 0.1), (256, 1024, 4096, 0.25), (512, 768, 768, 0.0)])
+def test_gemm_drop_residual_epilogue_and_layernorm_of_the_sum(M, N, K, p):
+    """uc2_gemm_drop_residual: s = dropout(x W^T + b) + residual out of the GEMM epilogue, with the mask of the LayerNorm kernels for
+    the same (seed, site) -- then ln_fwd(s) / ln_bwd(.., drop_after=2) against the unfused dense -> ln_fwd(o, residual, p) ->
+    ln_bwd chain (model/layer.py:111-115, :152-156)"""
+    dtype = torch.bfloat16
+    x = rnd((M, K), 1, 0.5, dtype)
+    w = rnd((N, K), 2, 0.03, dtype)
+    bias = rnd((N,), 3, 0.1)
+    res = rnd((M, N), 4, 1.0, dtype)
+    g, b = (1 + 0.1 * rnd((N,), 5)), rnd((N,), 6, 0.1)
+    seed = torch.tensor([4321], dtype=torch.int64, device=DEV)
+    site = 35
+    s = ops.linear_drop_residual(x, w, bias, res, p, seed if p else None, site)
+    assert s is not None and s.dtype == dtype
+    # the keep mask of the LayerNorm kernels for this (seed, site): y = dropout(LN(ones-ish)) is zero exactly at dropped elements
+    if p:
+        probe = rnd((M, N), 7) + 3.0
+        yk, _, _ = ops.ln_fwd(probe, None, torch.ones(N, device=DEV), torch.full((N,), 10.0, device=DEV), 1e-5, p, seed, site, drop_after=True)
+        keep = yk != 0
+        assert abs(1.0 - keep.float().mean().item() - p) < 0.01
+    else:
+        keep = torch.ones((M, N), dtype=torch.bool, device=DEV)
+    o32 = x.float() @ w.float().t() + bias
+    ref = torch.where(keep, o32 / (1 - p), torch.zeros_like(o32)) + res.float()
+    # dropped elements: the sum IS the residual, bit for bit
+    assert torch.equal(s[~keep], res[~keep])
+    assert rel_err(s.float(), ref) < 4e-3
+    assert (s.float() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()          # one bf16 rounding of the sum
+    # the LayerNorm of the sum against the unfused chain
+    o = ops.linear_fwd(x, w, bias)
+    y0, mean0, rstd0 = ops.ln_fwd(o, res, g, b, 1e-12, p, seed if p else None, site)
+    y1, mean1, rstd1 = ops.ln_fwd(s, None, g, b, 1e-12)
+    assert rel_err(y1.float(), y0.float()) < 8e-3
+    dy = rnd((M, N), 8, 0.1, dtype)
+    dg0, db0, dbi0 = [torch.zeros(N, device=DEV) for _ in range(3)]
+    dg1, db1, dbi1 = [torch.zeros(N, device=DEV) for _ in range(3)]
+    dx0, dr0 = ops.ln_bwd(dy, o, res, g, mean0, rstd0, dg0, db0, p, seed if p else None, site, dbias=dbi0)
+    dx1, dr1 = ops.ln_bwd(dy, s, None, g, mean1, rstd1, dg1, db1, p, seed if p else None, site, dbias=dbi1, drop_after=2)
+    ops.join_side_streams()
+    torch.cuda.synchronize()
+    assert torch.equal(dx1 == 0, dx0 == 0)                                  # same mask on the dense layer's gradient
+    if p:
+        assert torch.equal((dx1 == 0) | (dr1 == 0), ~keep | (dr1 == 0))
+    assert rel_err(dx1.float(), dx0.float()) < 1e-2 and rel_err(dr1.float(), dr0.float()) < 1e-2
+    for a_, b_ in ((dg1, dg0), (db1, db0), (dbi1, dbi0)):
+        assert rel_err(a_, b_) < 1e-2
+    # fp32 restatement of the backward through the sum
+    sf = s.float().requires_grad_(True)
+    refy = torch.nn.functional.layer_norm(sf, (N,), g, b, 1e-12)
+    refy.backward(dy.float())
+    assert rel_err(dr1.float(), sf.grad) < 6e-3
+    assert rel_err(dx1.float(), torch.where(keep, sf.grad / (1 - p), torch.zeros_like(sf.grad))) < 6e-3
+
+
+def test_gemm_drop_residual_refuses_shapes_off_the_pingpong_kernel():
+    x = rnd((200, 768), 1, 0.5, torch.bfloat16)
+    w = rnd((768, 768), 2, 0.03, torch.bfloat16)
+    res = rnd((200, 768), 4, 1.0, torch.bfloat16)
+    assert ops.linear_drop_residual(x, w, None, res, 0.1, torch.tensor([1], dtype=torch.int64, device=DEV), 3) is None
+    from uc2_amd import _lib
+    lib = _lib.load()
+    x = rnd((256, 768), 1, 0.5, torch.bfloat16)
+    res = rnd((256, 768), 4, 1.0, torch.bfloat16)
+    out = torch.empty_like(res)
+    # unaligned residual pointer: -2, nothing launched
+    r1 = torch.empty(256 * 768 + 8, dtype=torch.bfloat16, device=DEV)[1:1 + 256 * 768].view(256, 768)
+    rc = lib.uc2_gemm_drop_residual(256, 768, 768, x.data_ptr(), 768, w.data_ptr(), 768, out.data_ptr(), 768, None, r1.data_ptr(), 768,
+                                    0.1, None, 5, 0, None, None)
+    assert rc == -2
+    rc = lib.uc2_gemm_drop_residual(256, 768, 768, x.data_ptr(), 768, w.data_ptr(), 768, out.data_ptr(), 768, None, res.data_ptr(), 768,
+                                    1.0, None, 5, 0, None, None)
+    assert rc != 0 and rc != -2                                                  # p = 1 is an argument error
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -1304,4 +1394,36 @@ def test_layernorm_fused_e4m3_outputs(M, H):
     assert rel_err(d8.view(torch.float8_e4m3fn).float() / sc, dx0.float()) < 0.04
     assert abs(float(cells[C:2 * C].max().view(torch.float32)) - amax_d) <= 1e-2 * amax_d
     assert int(cells[2 * C:].abs().max()) == 0
+    del ops._FP8_HIST[key]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fp8_delayed_scaling_quantisation_one_pass(dtype):
+    """uc2_fp8_quant_delayed through ops.fp8_quantize_act: the first use of a tensor role takes the just-in-time route and starts the
+    role's history; the second quantises with HALF the scale of the first use's maximum while recording its own; a value above twice
+    the previous maximum saturates at the e4m3 maximum instead of overflowing; the third use sees the second's maximum."""
+    key = ("test-quant-delayed", str(dtype))
+    ops._FP8_HIST.pop(key, None)
+    x1 = rnd((300, 512), 1, 1.0, dtype=dtype)
+    a1 = float(x1.float().abs().max())
+    q1, s1 = ops.fp8_quantize_act(x1, key)
+    assert float(s1) == 2.0 ** math.floor(math.log2(448.0 / a1))                       # just in time
+    x2 = rnd((300, 512), 2, 1.5, dtype=dtype)
+    x2[7, 9] = 5.0 * a1                                                               # beyond twice the previous maximum
+    a2 = float(x2.float().abs().max())
+    q2, s2 = ops.fp8_quantize_act(x2, key)
+    torch.cuda.synchronize()
+    assert float(s2) == float(s1) * 0.5
+    deq = q2.view(torch.float8_e4m3fn).float() / s2
+    assert float(deq[7, 9]) == 448.0 / float(s2)                                      # saturated, finite
+    mask = torch.ones_like(deq, dtype=torch.bool)
+    mask[7, 9] = False
+    assert rel_err(deq[mask], x2.float()[mask]) < 0.04
+    x3 = rnd((300, 512), 3, 0.7, dtype=dtype)
+    q3, s3 = ops.fp8_quantize_act(x3, key)
+    torch.cuda.synchronize()
+    assert float(s3) == 2.0 ** math.floor(math.log2(448.0 / a2)) * 0.5
+    cells, i = ops._FP8_HIST[key]
+    C = ops.AMAX_CELLS
+    assert i == 2 and int(cells[((i + 1) % 3) * C:((i + 1) % 3 + 1) * C].abs().max()) == 0       # the group after next is clear
     del ops._FP8_HIST[key]

@@ -148,6 +148,51 @@ def test_bert_layer_backward_paths_at_bench_token_counts():
             assert rel_err(g[n], g_ref[n]) < 4e-3, n
 
 
+def test_bert_layer_fused_dropout_residual_tails_vs_unfused():
+    """ops.LN_FUSE (from ops.LN_FUSE_MIN_ROWS tokens): the Wo and FFN2 GEMMs write dropout(dense) + residual, the LayerNorm kernels
+    read that one tensor.  Same dropout masks as the unfused tails (same seed and sites); the sum is rounded to bf16 once where the
+    unfused form rounds the dense output: layer output, dx and every parameter gradient agree to bf16 rounding
+    (base geometry, 176 x 96 tokens, dropout on; forward-only route too)"""
+    cfg = make_cfg(O.BASE, drop=0.1)
+    layer = BertLayer(cfg)
+    synth.det_init_(layer)
+    layer.to(DEV).train()
+    set_compute_dtype(layer, torch.bfloat16)
+    B, L, H = 176, 96, 768
+    assert B * L >= ops.LN_FUSE_MIN_ROWS
+    x0 = (synth.det_normal((B, L, H), 3) * 0.5).to(DEV).to(torch.bfloat16)
+    ext = torch.zeros(B, 1, 1, L, device=DEV)
+    ext[::5, :, :, L - 11:] = -10000.0
+    dy = (synth.det_normal((B, L, H), 4) * 0.1).to(DEV).to(torch.bfloat16)
+
+    def run(on):
+        was, ops.LN_FUSE = ops.LN_FUSE, (3 if on else 0)
+        try:
+            layer.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            ops.rng.manual_seed(5)
+            y = layer(x, ext)
+            y.backward(dy)
+            ops.join_side_streams()
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                ops.rng.manual_seed(5)
+                yf = layer(x0, ext)
+            return y.detach().clone(), x.grad.clone(), OrderedDict((n, p.grad.detach().clone()) for n, p in layer.named_parameters()), yf
+        finally:
+            ops.LN_FUSE = was
+    y0, dx0, g0, yf0 = run(False)
+    y1, dx1, g1, yf1 = run(True)
+    assert not torch.equal(y1, y0)                                   # (the fused route really ran: another rounding point)
+    assert torch.equal(yf1, y1) and torch.equal(yf0, y0)             # forward-only route == training forward, in both forms
+    assert rel_err(y1.float(), y0.float()) < 6e-3
+    assert rel_err(dx1.float(), dx0.float()) < 1e-2
+    for n in g0:
+        if n.endswith("key.bias"):
+            continue
+        assert rel_err(g1[n], g0[n]) < 1e-2, n
+
+
 def test_bert_layer_interleaved_qkv_route_is_bit_identical():
     """ops.QKV_INTERLEAVED (from 16 384 tokens): the QKV GEMM on the row-permuted weight copy, attention on head-interleaved q|k|v,
     dWqkv un-permuted by its split-K reduction, dX through W'^T -- same dot products in the same order as the plain layout: the

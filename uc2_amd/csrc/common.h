@@ -189,6 +189,14 @@ __device__ __forceinline__ float fp8_scale_of(unsigned amax_bits) {
   if (a > 0.f && a < INFINITY) s = exp2f(floorf(log2f(448.0f / a)));
   return fminf(fmaxf(s, 1.0f / 16777216.0f), 16777216.0f);
 }
+// four floats -> four e4m3 bytes, clamped to +-448 first: v_cvt_pk_fp8_f32 turns a finite value beyond the e4m3 range into NaN (0x7f) under
+// the default mode, and with delayed scaling a tensor may outgrow twice its previous maximum between two uses
+__device__ __forceinline__ unsigned fp8_pack4_sat(float a, float b, float c, float d) {
+  unsigned r = 0;
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a, -448.f, 448.f), __builtin_amdgcn_fmed3f(b, -448.f, 448.f), r, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c, -448.f, 448.f), __builtin_amdgcn_fmed3f(d, -448.f, 448.f), r, true);
+  return r;
+}
 // delayed scaling: half the just-in-time scale of the previous use's maximum (twice that maximum stays representable)
 __device__ __forceinline__ float fp8_delayed_scale(const unsigned* __restrict__ prev_cells) { return fp8_scale_of(amax_cells_read(prev_cells)) * 0.5f; }
 
@@ -197,36 +205,25 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
-// One hash serves FOUR consecutive indices: two mix32 rounds of the group index (idx >> 2) give 64 bits, element
-// (idx & 3) takes 16 of them and is kept when they are >= thresh >> 16 (drop probability resolved to 2^-16).
-// (The 32-bit integer multiplies of mix32 are quarter-rate; one hash per element made the LayerNorm kernels
-// VALU-bound at twice their memory time.)  thresh = p * 2^32 (clamped), see drop_thresh.
-__device__ __forceinline__ void drop_hash4(uint64_t seed, uint64_t group, uint32_t& r0, uint32_t& r1) {
-  const uint32_t lo = (uint32_t)group, hi = (uint32_t)(group >> 32);
-  r0 = mix32(lo ^ (uint32_t)seed);
-  r1 = mix32(r0 + hi * 0x9E3779B9U + (uint32_t)(seed >> 32));
+// Hidden-state dropout (the dense -> dropout -> LayerNorm tails, the embedding tails): element (row, column) of a [rows, H] tensor is
+// kept when a 16-bit variate of (seed, row, column) is >= thresh >> 16 (drop probability resolved to 2^-16; thresh = p * 2^32,
+// see drop_thresh).  The variate is SEPARABLE: one fully mixed 32-bit hash per token row, one per group of four columns (a "piece":
+// the 8 bytes of bf16 a lane of every kernel here owns), and per element the top 16 bits of a full-rate 24-bit multiply of their
+// XOR with a per-position odd constant -- the scheme of the attention-probability mask below.  Rounds 1-4 hashed (seed, row * H +
+// column) per piece with four quarter-rate 32-bit multiplies; that was free in the HBM-bound LayerNorm kernels but cost ~4 us per
+// 256 x 256 tile in a GEMM epilogue (uc2_gemm_drop_residual), where a lane meets only 8 rows and 4 pieces per 128 elements.
+// Every kernel that applies or regenerates the mask (ln_fwd*, ln_bwd, the EPI_DROPADD epilogue) goes through these three functions.
+__device__ __forceinline__ uint32_t drop_row_hash(uint64_t seed, uint32_t row) {
+  return mix32((row ^ (uint32_t)seed) + (uint32_t)(seed >> 32) * 0x9E3779B9U);
 }
-// keep flags of indices idx4 .. idx4+3 (idx4 a multiple of 4)
-__device__ __forceinline__ void drop_keep4(uint64_t seed, uint64_t idx4, uint32_t thresh, bool (&keep)[4]) {
-  uint32_t r0, r1;
-  drop_hash4(seed, idx4 >> 2, r0, r1);
-  const uint32_t t16 = thresh >> 16;
-  keep[0] = (r0 & 0xffffu) >= t16; keep[1] = (r0 >> 16) >= t16;
-  keep[2] = (r1 & 0xffffu) >= t16; keep[3] = (r1 >> 16) >= t16;
+__device__ __forceinline__ uint32_t drop_col_hash(uint64_t seed, uint32_t piece) {
+  return mix32(piece * 0x9E3779B9U + (uint32_t)(seed >> 32) + __builtin_rotateleft32((uint32_t)seed, 16));
 }
-// four consecutive indices from any start: one hash when the start is group-aligned (`aligned` is wave-uniform)
-__device__ __forceinline__ void drop_keep4_any(uint64_t seed, uint64_t idx, uint32_t thresh, bool aligned, bool (&keep)[4]);
-// returns true with probability (1 - p) for one index (same function as drop_keep4, element idx & 3)
-__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
-  uint32_t r0, r1;
-  drop_hash4(seed, idx >> 2, r0, r1);
-  const uint32_t r = (idx & 2) ? r1 : r0;
-  return (((idx & 1) ? (r >> 16) : (r & 0xffffu))) >= (thresh >> 16);
-}
-__device__ __forceinline__ void drop_keep4_any(uint64_t seed, uint64_t idx, uint32_t thresh, bool aligned, bool (&keep)[4]) {
-  if (aligned) { drop_keep4(seed, idx, thresh, keep); return; }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) keep[e] = drop_keep(seed, idx + e, thresh);
+// keep flags of the four columns of a piece
+__device__ __forceinline__ void drop_keep4(uint32_t hrow, uint32_t hcol, uint32_t thresh, bool (&keep)[4]) {
+  const uint32_t w = hrow ^ hcol, t = thresh & 0xffff0000U;
+  keep[0] = __umul24(w, 0x9E3779U) >= t; keep[1] = __umul24(w, 0x85EBCBU) >= t;
+  keep[2] = __umul24(w, 0xC2B2AFU) >= t; keep[3] = __umul24(w, 0x27D4EBU) >= t;
 }
 // Attention-probability dropout: keep(q, k) = light(Hq[q] ^ Hk[k]) with one fully mixed 32-bit hash per query row
 // and per key column of a (batch, head) -- L + L full hashes per head instead of L*L; the per-element part is one

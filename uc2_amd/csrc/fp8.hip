@@ -29,10 +29,7 @@ __global__ __launch_bounds__(256) void fp8_amax_kernel(size_t n, const T* __rest
 }
 __global__ void fp8_scale_kernel(const unsigned* __restrict__ amax_bits, float* __restrict__ scale) { *scale = fp8_scale_of(*amax_bits); }
 __device__ __forceinline__ unsigned pack4_e4m3(const float (&v)[4]) {
-  unsigned r = 0;
-  r = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], r, false);      // saturating OCP e4m3 conversion, bytes 0-1
-  r = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], r, true);       // bytes 2-3
-  return r;
+  return fp8_pack4_sat(v[0], v[1], v[2], v[3]);
 }
 // rows x cols (cols % 4 == 0), out[r * ldo + c] = e4m3(x[r * ldx + c] * scale)
 template <typename T>

@@ -487,6 +487,51 @@ static int gemm_impl(int dtype, int trans_a, int trans_b, int M, int N, int K,
   return 0;
 }
 
+// C[M,N] (bf16) = dropout_p(A[M,K] W[N,K]^T + bias) + residual: the sum the LayerNorm of a BertSelfOutput / BertOutput normalises
+// (model/layer.py:78-81, :112-115 of the reference: dense -> dropout -> LayerNorm(hidden + input)), produced by the GEMM's epilogue so
+// that the LayerNorm kernels read one tensor instead of two and generate no mask.  The mask is the one uc2_ln_fwd / uc2_ln_bwd_partial
+// derive from (seed, row * N + column): a layer may mix the fused and the unfused form between forward and backward.
+// Runs on the ping-pong kernel only (variant 12); returns -2 with nothing launched when the shape does not qualify (M % 256, N % 256,
+// K % 128, 16-byte alignment, operands below 4 GiB) -- the caller then takes the unfused route.
+bool uc2_gemm_pp16_supported(const GemmArgs& p, int trans_a, int trans_b);                       // gemm_pp16.hip
+void uc2_gemm_pp16_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st);
+extern "C" int uc2_gemm_drop_residual(int M, int N, int K, const void* A, int lda, const void* W, int ldw, void* C, int ldc,
+                                      const float* bias, const void* residual, int ldres, float p_drop, const uint64_t* seed_ptr,
+                                      uint64_t seed_imm, int flags, void* queue, void* stream) {
+  UC2_CHECK_ARG(M >= 0 && N >= 0 && K >= 0);
+  UC2_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f);
+  if (M == 0 || N == 0) return 0;
+  UC2_CHECK_ARG(A && W && C && residual);
+  const int ktiles = K / 64;
+  const unsigned long long ea = 2ull * M * lda, eb = 2ull * N * ldw;
+  const bool ok = K >= 128 && (K % 64) == 0 && !(ktiles & 1) && (M % 256) == 0 && (N % 256) == 0 &&
+                  ((uintptr_t)A & 15) == 0 && (lda & 7) == 0 && ((uintptr_t)W & 15) == 0 && (ldw & 7) == 0 &&
+                  ((uintptr_t)C & 15) == 0 && (ldc & 7) == 0 && ((uintptr_t)residual & 15) == 0 && (ldres & 7) == 0 &&
+                  ((uintptr_t)bias & 15) == 0 && ea < (1ull << 32) && eb < (1ull << 32);
+  if (!ok) return -2;
+  GemmArgs p{};
+  p.A = A; p.B = W; p.C = C; p.bias = bias; p.aux_in = residual; p.aux_out = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldw; p.ldc = ldc; p.ldaux = ldres;
+  // (no dropout: the plain residual-add epilogue)
+  p.epi = p_drop > 0.f ? EPI_DROPADD : EPI_ADD; p.c_f32 = 0; p.accumulate = 0; p.split_k = 1; p.atomic = 0; p.alpha = 1.0f;
+  p.variant = 12; p.queue = reinterpret_cast<int*>(queue);
+  {
+    const int nbx = N / 256;
+    int cg = nbx;
+    if (nbx > 6) { cg = 1; for (int d = 6; d >= 2; --d) if (nbx % d == 0) { cg = d; break; } if (cg == 1) cg = 6; }
+    p.col_group = cg;
+  }
+  p.skew = (flags >> 4) & 15; p.diag = (flags >> 8) & 0xFFFF; p.spare_cus = 8 * ((flags >> 28) & 7);
+  if (p.diag) p.atomic |= (p.diag << 8);
+  p.a_vec = 1; p.b_vec = 1;
+  p.drop_thresh = drop_thresh(p_drop); p.drop_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  p.drop_seed_ptr = seed_ptr; p.drop_seed_imm = seed_imm;
+  if (!uc2_gemm_pp16_supported(p, 0, 0)) return -2;
+  uc2_gemm_pp16_launch(p, 0, 0, (hipStream_t)stream);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K,
                         const void* A, int lda, const void* B, int ldb, void* C, int ldc, int c_is_f32,
                         const float* bias, int epilogue, const void* aux_in, void* aux_out, int ldaux,

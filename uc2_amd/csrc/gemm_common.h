@@ -6,7 +6,8 @@ enum { EPI_NONE = 0, EPI_GELU = 1, EPI_DGELU = 2, EPI_ADD = 3, EPI_TANH = 4,
        EPI_GELU_D = 5, EPI_MUL = 6,       // internal to the ping-pong kernel: EPI_GELU / EPI_DGELU under GemmArgs::aux_deriv
        EPI_GELU_NOAUX = 7,                // ... and EPI_GELU without a second output stream (aux_out == NULL)
        EPI_ACC = 8,                       // ... fp32 C += tile through the line-wide partial-tile store (unsplit weight gradient)
-       EPI_GROUP = 9 };                   // ... one launch over the split-K items of up to four weight gradients (GemmArgs::grp)
+       EPI_GROUP = 9,                     // ... one launch over the split-K items of up to four weight gradients (GemmArgs::grp)
+       EPI_DROPADD = 10 };                // ... dropout(acc + bias) + aux_in: the pre-LayerNorm sum of the encoder's dense -> dropout -> add tails (uc2_gemm_drop_residual)
 
 // One problem of a grouped weight-gradient launch (uc2_gemm_wgrad_group): dW[M,N] += A^T B over `ktiles` 64-row k-tiles,
 // A = dY [rows][M] and B = X [rows][N] both k-strided; items item0 .. item0 + ntile * split - 1 of the launch, tile-major
@@ -43,6 +44,8 @@ struct GemmArgs {
   GemmProb grp[UC2_GEMM_MAX_GROUP];
   // fp8 ping-pong kernel (gemm_pp8.hip), optional: an e4m3 copy of the MAIN output for the next GEMM (delayed scaling: quantised with
   // half the scale of *q_amax_prev; max |output| accumulated into *q_amax_next; *q_amax_clear zeroed; the scale used -> *q_scale_out)
+  // EPI_DROPADD: the dropout of nn.Dropout behind the dense layer, same counter-based mask as the LayerNorm kernels (common.h drop_keep4)
+  unsigned drop_thresh; float drop_scale; const uint64_t* drop_seed_ptr; uint64_t drop_seed_imm;
   void* q_out; int ldq;
   const unsigned* q_amax_prev; unsigned* q_amax_next; unsigned* q_amax_clear; float* q_scale_out;
 };

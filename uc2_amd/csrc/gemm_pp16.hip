@@ -223,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
   // main-loop diagnostics (with 0x800): 0x100 = no LDS-DMA issue (stale LDS contents), 0x200 = no fragment reads after the first k-tile
   const bool dg_nodma = UC2_PP_DIAG && (p.atomic & 0x100) != 0, dg_nord = UC2_PP_DIAG && (p.atomic & 0x200) != 0;     // (make EXTRA=-DUC2_PP_DIAG=1)
   bool more = false;                                   // another item follows the current one
-  constexpr bool AUXK = TACC && (EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_DGELU);     // epilogues that read an aux_in tile
+  constexpr bool AUXK = TACC && (EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_DGELU || EPI == EPI_DROPADD);     // epilogues that read an aux_in tile
   unsigned aux_t0 = 0, aux_t1 = 0;                     // (PP16_AUX_TOUCH) destinations of the line-touching loads
   const bool aux_touch = AUXK && (size_t)p.M * (size_t)p.N <= ((size_t)32 << 20);
   auto body = [&](auto tail_c, auto swap_c, int kt) __attribute__((always_inline)) {
@@ -489,7 +489,7 @@ bool uc2_gemm_pp16_supported(const GemmArgs& p, int trans_a, int trans_b) {
     if (p.partial) return true;
     return p.accumulate && !(p.atomic & 1) && p.split_k == 1 && trans_a && trans_b;
   }
-  if (!trans_a && !trans_b) return p.epi == EPI_NONE || p.epi == EPI_GELU || p.epi == EPI_ADD || p.epi == EPI_TANH || p.epi == EPI_DGELU;
+  if (!trans_a && !trans_b) return p.epi == EPI_NONE || p.epi == EPI_GELU || p.epi == EPI_ADD || p.epi == EPI_TANH || p.epi == EPI_DGELU || p.epi == EPI_DROPADD;
   if (!trans_a && trans_b) return p.epi == EPI_NONE || p.epi == EPI_DGELU || p.epi == EPI_ADD;
   return p.epi == EPI_NONE;
 }
@@ -507,6 +507,7 @@ void uc2_gemm_pp16_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream
     else if (p.epi == EPI_GELU && p.aux_deriv) pp16_launch0<false, false, EPI_GELU_D>(p, st);
     else if (p.epi == EPI_GELU) pp16_launch0<false, false, EPI_GELU>(p, st);
     else if (p.epi == EPI_ADD) pp16_launch0<false, false, EPI_ADD>(p, st);
+    else if (p.epi == EPI_DROPADD) pp16_launch0<false, false, EPI_DROPADD>(p, st);
     else if (p.epi == EPI_TANH) pp16_launch0<false, false, EPI_TANH>(p, st);
     else if (p.epi == EPI_DGELU && p.aux_deriv) pp16_launch0<false, false, EPI_MUL>(p, st);     // dX = dY W with a k-contiguous W^T
     else if (p.epi == EPI_DGELU) pp16_launch0<false, false, EPI_DGELU>(p, st);

@@ -130,10 +130,7 @@ __device__ __forceinline__ void pp8_epi_compute_q(const GemmArgs& p, const f32x4
           else asm volatile("ds_write_b64 %0, %1 offset:2048" :: "v"(qa), "v"(o) : "memory");
           if (QOUT) {
             qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-            unsigned r = 0;
-            r = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * qs, v[1] * qs, r, false);
-            r = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * qs, v[3] * qs, r, true);
-            qv[k] = r;
+            qv[k] = fp8_pack4_sat(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs);
           }
         }
       tp_read_o<0>(out.o[hh][i][0], ta.line); tp_read_o<1024>(out.o[hh][i][1], ta.line);

@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int H, const T* __re
   if (row >= M) return;
   const int nch = H >> 2;
   const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
+  const uint32_t hrow = drop_row_hash(seed, (uint32_t)row);
   // every load of the row is issued before the first use (chunks past the row end are clamped, not branched around:
   // a branch per chunk makes hipcc wait for each load before issuing the next)
   typedef typename Raw4<T>::type raw_t;
@@ -37,11 +38,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int H, const T* __re
 #pragma unroll
   for (int i = 0; i < LN_MAXC; ++i) {
     const int c = lane + 64 * i;
-    const size_t off = (size_t)row * H + c * 4;
     Raw4<T>::to_f(rx[i], v[i]);
     if (thresh && !drop_after) {
       bool kp4[4];
-      drop_keep4(seed, off, thresh, kp4);
+      drop_keep4(hrow, drop_col_hash(seed, (uint32_t)c), thresh, kp4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[i][e] = kp4[e] ? v[i][e] * keep_scale : 0.f;
     }
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int M, int H, const T* __re
       for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
       if (thresh && drop_after) {          // y = dropout(LN(x + res)): the embedding tails, model/model.py:331-333,361-363
         bool kp4[4];
-        drop_keep4(seed, (size_t)row * H + c * 4, thresh, kp4);
+        drop_keep4(hrow, drop_col_hash(seed, (uint32_t)c), thresh, kp4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = kp4[e] ? o[e] * keep_scale : 0.f;
       }
@@ -121,10 +121,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
   // are clamped, not branched around: with a branch per chunk hipcc waits for each load before issuing the next,
   // nine dependent memory round trips per row)
   float gmr[NC][4];
+  uint32_t hcol[NC];                                   // the column part of the dropout variate: the same for every row of the lane
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     const int c = min(lane + 64 * i, nch - 1);
     Vec4<float>::load(gamma + c * 4, gmr[i]);
+    hcol[i] = drop_col_hash(seed, (uint32_t)(lane + 64 * i));
   }
   typedef typename Raw4<T>::type raw_t;
   for (int row = blockIdx.x * 4 + wv; row < M; row += gridDim.x * 4) {
@@ -140,6 +142,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
       for (int i = 0; i < NC; ++i) rr[i] = Raw4<T>::load_nt(res + (size_t)row * H + min(lane + 64 * i, nch - 1) * 4);
     }
     const float mean = mean_i[row], rstd = rstd_i[row];
+    const uint32_t hrow = drop_row_hash(seed, (uint32_t)row);
     // (fetching the next row into a second register set during the arithmetic changed nothing: 169 vs 172 us)
     float xh[NC][4], g[NC][4];
     bool kp[NC][4];
@@ -155,11 +158,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
 #pragma unroll
       for (int e = 0; e < 4; ++e) kp[i][e] = true;
       if (thresh) {
-        drop_keep4(seed, off, thresh, kp[i]);
-        if (drop_after) {                  // mask sits on the output: dy_eff = keep ? dy / (1-p) : 0, x is not masked
+        drop_keep4(hrow, hcol[i], thresh, kp[i]);
+        if (drop_after == 1) {             // mask sits on the output: dy_eff = keep ? dy / (1-p) : 0, x is not masked
 #pragma unroll
           for (int e = 0; e < 4; ++e) dyv[e] = kp[i][e] ? dyv[e] * keep_scale : 0.f;
-        } else {
+        } else if (drop_after == 0) {      // (2: x is already the normalised sum dropout(dense) + residual, written by
+                                           //  uc2_gemm_drop_residual -- only dx below gets the mask)
 #pragma unroll
           for (int e = 0; e < 4; ++e) xv[e] = kp[i][e] ? xv[e] * keep_scale : 0.f;
         }
@@ -192,15 +196,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           dz[e] = rstd * (g[i][e] - s1 - xh[i][e] * s2);
-          dxv[e] = (thresh && !drop_after) ? (kp[i][e] ? dz[e] * keep_scale : 0.f) : dz[e];
+          dxv[e] = (thresh && drop_after != 1) ? (kp[i][e] ? dz[e] * keep_scale : 0.f) : dz[e];
           dbx[i][e] += dxv[e];
         }
         if (dx) Vec4<T>::store(dx + off, dxv);
         if (Q) {
           qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(dxv[0]), fabsf(dxv[1])), fmaxf(fabsf(dxv[2]), fabsf(dxv[3]))));
-          unsigned r = 0;
-          r = __builtin_amdgcn_cvt_pk_fp8_f32(dxv[0] * qs, dxv[1] * qs, r, false);
-          r = __builtin_amdgcn_cvt_pk_fp8_f32(dxv[2] * qs, dxv[3] * qs, r, true);
+          const unsigned r = fp8_pack4_sat(dxv[0] * qs, dxv[1] * qs, dxv[2] * qs, dxv[3] * qs);
           *reinterpret_cast<unsigned*>(qo + off) = r;
         }
         if (dres) Vec4<T>::store_nt(dres + off, dz);           // the residual-path gradient is read several kernels later (EPI_ADD of a dgrad GEMM)
@@ -264,6 +266,7 @@ __global__ __launch_bounds__(256) void ln_fwd16_kernel(int M, int H, const bf16*
   const int row = row_ok ? row_raw : M - 1;            // (both halves of a wave stay in the shuffles; stores are masked)
   const int nch = H >> 3;
   const uint64_t seed = seed_imm + (seed_ptr ? *seed_ptr : 0ull);
+  const uint32_t hrow = drop_row_hash(seed, (uint32_t)row);
   bf16x8 rx[NC8], rr[NC8];
 #pragma unroll
   for (int i = 0; i < NC8; ++i) rx[i] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(x + (size_t)row * H + min(l32 + 32 * i, nch - 1) * 8));
@@ -276,12 +279,11 @@ __global__ __launch_bounds__(256) void ln_fwd16_kernel(int M, int H, const bf16*
 #pragma unroll
   for (int i = 0; i < NC8; ++i) {
     const int c = l32 + 32 * i;
-    const size_t off = (size_t)row * H + c * 8;
     bf8_to_f(rx[i], v[i]);
     if (thresh && !drop_after) {
       bool k0[4], k1[4];
-      drop_keep4(seed, off, thresh, k0);
-      drop_keep4(seed, off + 4, thresh, k1);
+      drop_keep4(hrow, drop_col_hash(seed, 2u * c), thresh, k0);
+      drop_keep4(hrow, drop_col_hash(seed, 2u * c + 1u), thresh, k1);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[i][e] = k0[e] ? v[i][e] * keep_scale : 0.f; v[i][4 + e] = k1[e] ? v[i][4 + e] * keep_scale : 0.f; }
     }
@@ -325,8 +327,8 @@ __global__ __launch_bounds__(256) void ln_fwd16_kernel(int M, int H, const bf16*
       for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
       if (thresh && drop_after) {          // y = dropout(LN(x + res)): the embedding tails, model/model.py:331-333,361-363
         bool k0[4], k1[4];
-        drop_keep4(seed, (size_t)row * H + c * 8, thresh, k0);
-        drop_keep4(seed, (size_t)row * H + c * 8 + 4, thresh, k1);
+        drop_keep4(hrow, drop_col_hash(seed, 2u * c), thresh, k0);
+        drop_keep4(hrow, drop_col_hash(seed, 2u * c + 1u), thresh, k1);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { o[e] = k0[e] ? o[e] * keep_scale : 0.f; o[4 + e] = k1[e] ? o[4 + e] * keep_scale : 0.f; }
       }
@@ -337,11 +339,7 @@ __global__ __launch_bounds__(256) void ln_fwd16_kernel(int M, int H, const bf16*
       if (Q) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) qmax = fmaxf(qmax, fabsf(o[e]));
-        unsigned r0 = 0, r1 = 0;
-        r0 = __builtin_amdgcn_cvt_pk_fp8_f32(o[0] * qs, o[1] * qs, r0, false);
-        r0 = __builtin_amdgcn_cvt_pk_fp8_f32(o[2] * qs, o[3] * qs, r0, true);
-        r1 = __builtin_amdgcn_cvt_pk_fp8_f32(o[4] * qs, o[5] * qs, r1, false);
-        r1 = __builtin_amdgcn_cvt_pk_fp8_f32(o[6] * qs, o[7] * qs, r1, true);
+        const unsigned r0 = fp8_pack4_sat(o[0] * qs, o[1] * qs, o[2] * qs, o[3] * qs), r1 = fp8_pack4_sat(o[4] * qs, o[5] * qs, o[6] * qs, o[7] * qs);
         *reinterpret_cast<uint2*>(lq.q + (size_t)row * H + c * 8) = make_uint2(r0, r1);
       }
     }
@@ -390,6 +388,7 @@ static int ln_fwd_impl(int dtype, int M, int H, const void* x, const void* resid
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
   UC2_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= LN_MAXC * 256);
   UC2_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
+  UC2_CHECK_ARG(drop_after == 0 || drop_after == 1);
   if (M <= 0) return 0;
   UC2_CHECK_ARG(x && gamma && beta && y);
   const uint32_t th = drop_thresh(drop_p);
@@ -471,6 +470,7 @@ static int ln_bwd_partial_impl(int dtype, int M, int H, const void* dy, const vo
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
   UC2_CHECK_ARG(H > 0 && (H % 4) == 0 && H <= LN_MAXC * 256);
   UC2_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f);
+  UC2_CHECK_ARG(drop_after >= 0 && drop_after <= 2 && !(drop_after == 2 && residual));
   if (M <= 0) return 0;
   UC2_CHECK_ARG(dy && x && gamma && mean && rstd && ws);
   const uint32_t th = drop_thresh(drop_p);

@@ -674,6 +674,40 @@ def linear_fwd(x2, w, bias, epi=EPI_NONE, aux_out=None, flags=0):
     return _gemm_planned(x2, w, M, N, K, False, False, bias=bias, epi=epi, aux_out=aux_out, flags=flags)
 
 
+EPI_DROPADD = 10                 # internal to the ping-pong kernel (uc2_gemm_drop_residual)
+# dropout + residual of the dense -> dropout -> LayerNorm tails in the GEMM epilogue: bit 0 = the attention-output tail, bit 1 = the FFN tail
+LN_FUSE = int(os.environ.get("UC2_LN_FUSE", "3"))
+LN_FUSE_MIN_ROWS = int(os.environ.get("UC2_LN_FUSE_MIN_ROWS", "16384"))
+
+
+def linear_drop_residual(x2, w, bias, res2, drop_p, seed, seed_imm):
+    """s = dropout(x2 w^T + bias) + res2 (model/layer.py:111-115, :152-156 up to the LayerNorm) from one GEMM launch, with the mask
+    ln_fwd / ln_bwd derive from (seed, seed_imm); None (nothing launched) when the ping-pong kernel does not take the shape"""
+    M, K = x2.shape
+    N = w.shape[0]
+    if x2.dtype != torch.bfloat16 or M % 256 or N % 256 or K % 128:
+        return None
+    out = torch.empty((M, N), dtype=x2.dtype, device=x2.device)
+    timer = GEMM_TIMER
+    e0 = None
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    flags = _EXTRA_FLAGS
+    if PP_SKEW:
+        flags |= (PP_SKEW.get(EPI_ADD, 0) & 15) << 4
+    rc = _lib.load().uc2_gemm_drop_residual(M, N, K, ptr(x2), x2.stride(0), ptr(w), w.stride(0), ptr(out), N, ptr(bias), ptr(res2),
+                                            res2.stride(0), float(drop_p), ptr(seed), seed_imm, flags,
+                                            ptr(_gemm_queue(x2.device)) if GEMM_QUEUE else None, stream())
+    if rc == -2:
+        return None
+    _lib.check(rc)
+    if e0 is not None:
+        e1.record()
+        timer.add((False, False, 12, False, EPI_DROPADD), 2.0 * M * N * K, e0, e1, 2.0 * (M * K + N * K + 2 * M * N))
+    return out
+
+
 DGRAD_TRANSPOSED_W = os.environ.get("UC2_DGRAD_WT", "1") != "0"     # bf16: dX = dY W reads a k-contiguous copy W^T (store.compute_t)
 DGRAD_WT_MIN_ROWS = 16384        # ... from this many tokens (its own knob, not the side stream's: at the reference's 104-pair
                                  # micro-batch the k-contiguous form is no faster on the ring kernels and 8 % slower for the
@@ -941,7 +975,7 @@ def ln_bwd(dy2, x2, res2, gamma, mean, rstd, dgamma, dbeta, drop_p=0.0, seed=Non
     lib = _lib.load()
     ws = torch.empty(lib.uc2_ln_bwd_workspace(M, H) // 4, dtype=torch.float32, device=x2.device)
     dx = torch.empty_like(x2)
-    dres = torch.empty_like(x2) if (drop_p > 0.0 and need_dres and not drop_after) else None
+    dres = torch.empty_like(x2) if (drop_p > 0.0 and need_dres and drop_after != 1) else None       # (drop_after: False / True / 2)
     streams = 3 + (1 if res2 is not None else 0) + (1 if dres is not None else 0)     # dy, x, (res) in; dx, (dres) out
     d = dt(x2.dtype)
     h = _fp8_hist_for(q_key, x2.device) if x2.dtype == torch.bfloat16 else None
@@ -1167,13 +1201,22 @@ class BertLayerFn(torch.autograd.Function):
             qkv = linear_fwd(x2, wqkv, bqkv)
             ctxv, _ = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn, want_lse=False, ilv=ilv is not None)
             del qkv
-            o1 = linear_fwd(ctxv, st.compute(P["ow"], dtype), P["ob"].data)
-            a, _, _ = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, s_ln1, want_stats=False)
+            fuse = int(LN_FUSE) if (dtype == torch.bfloat16 and M >= LN_FUSE_MIN_ROWS) else 0
+            o1 = linear_drop_residual(ctxv, st.compute(P["ow"], dtype), P["ob"].data, x2, p_h, seed, s_ln1) if fuse & 1 else None
+            if o1 is not None:
+                a, _, _ = ln_fwd(o1, None, P["g1"].data, P["b1"].data, 1e-12, want_stats=False)
+            else:
+                o1 = linear_fwd(ctxv, st.compute(P["ow"], dtype), P["ob"].data)
+                a, _, _ = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, s_ln1, want_stats=False)
             del o1, ctxv
             u = linear_fwd(a, st.compute(P["iw"], dtype), P["ib"].data, EPI_GELU, None)
-            o2 = linear_fwd(u, st.compute(P["fw"], dtype), P["fb"].data)
+            o2 = linear_drop_residual(u, st.compute(P["fw"], dtype), P["fb"].data, a, p_h, seed, s_ln2) if fuse & 2 else None
+            if o2 is not None:
+                y, _, _ = ln_fwd(o2, None, P["g2"].data, P["b2"].data, 1e-12, want_stats=False)
+            else:
+                o2 = linear_fwd(u, st.compute(P["fw"], dtype), P["fb"].data)
+                y, _, _ = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, s_ln2, want_stats=False)
             del u
-            y, _, _ = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, s_ln2, want_stats=False)
             return y.view(B, L, H)
         fp8 = bool(cfg.get("fp8")) and dtype == torch.bfloat16 and H % 128 == 0 and P["iw"].shape[0] % 128 == 0
         I_ = P["iw"].shape[0]
@@ -1201,19 +1244,35 @@ class BertLayerFn(torch.autograd.Function):
         else:
             qkv = linear_fwd(x2, wqkv, bqkv)
             ctxv, lse = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn, ilv=ilv is not None)
-            o1 = linear_fwd(ctxv, st.compute(P["ow"], dtype), P["ob"].data)
-            a, mean1, rstd1 = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, s_ln1)
+            # The dense -> dropout -> + residual tails: with LN_FUSE the Wo / FFN2 GEMM writes the pre-LayerNorm SUM (dropout mask and
+            # residual in its epilogue), the LayerNorm reads one tensor and hashes no mask; o1 / o2 then hold the sums and the
+            # backward runs the LayerNorm in its drop_after = 2 form (fused1 / fused2 say which form each tail took)
+            fuse = int(LN_FUSE) if M >= LN_FUSE_MIN_ROWS else 0
+            o1 = linear_drop_residual(ctxv, st.compute(P["ow"], dtype), P["ob"].data, x2, p_h, seed, s_ln1) if fuse & 1 else None
+            fused1 = o1 is not None
+            if fused1:
+                a, mean1, rstd1 = ln_fwd(o1, None, P["g1"].data, P["b1"].data, 1e-12)
+            else:
+                o1 = linear_fwd(ctxv, st.compute(P["ow"], dtype), P["ob"].data)
+                a, mean1, rstd1 = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, s_ln1)
             # `pre` holds gelu'(a W1^T + b1), not the pre-activation itself (UC2_GEMM_AUX_DERIV): one more exp2 beside
             # the forward's Phi(x) there, and the backward's dGELU epilogue becomes a plain multiply
             u = linear_fwd(a, st.compute(P["iw"], dtype), P["ib"].data, EPI_GELU, pre, flags=GEMM_AUX_DERIV)
-            o2 = linear_fwd(u, st.compute(P["fw"], dtype), P["fb"].data)
+            o2 = linear_drop_residual(u, st.compute(P["fw"], dtype), P["fb"].data, a, p_h, seed, s_ln2) if fuse & 2 else None
+            fused2 = o2 is not None
+            if not fused2:
+                o2 = linear_fwd(u, st.compute(P["fw"], dtype), P["fb"].data)
         if fp8:
+            fused1 = fused2 = False
             y, mean2, rstd2, yq = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, s_ln2, q_key=ky)
             _FP8_PREQ.clear()                          # (at most one hand-over alive: the last layer's copy has no fp8 consumer)
             if yq is not None:
                 _FP8_PREQ[y.data_ptr()] = yq
+        elif fused2:
+            y, mean2, rstd2 = ln_fwd(o2, None, P["g2"].data, P["b2"].data, 1e-12)
         else:
             y, mean2, rstd2 = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, s_ln2)
+        ctx.ln_fused = (fused1, fused2)
 
         ctx.save_for_backward(x2, mask2d, qkv, ctxv, lse, o1, mean1, rstd1, a, pre, u, o2, mean2, rstd2, seed)
         ctx.layer, ctx.cfg, ctx.shape, ctx.p = layer, cfg, (B, L, H, nh, D), (p_h, p_a, (s_attn, s_ln1, s_ln2))
@@ -1241,8 +1300,8 @@ class BertLayerFn(torch.autograd.Function):
             d_o2, dz2, dq2 = ln_bwd(dy2, o2, a, P["g2"].data, mean2, rstd2, G(P["g2"]), G(P["b2"]), p_h, seed, s_ln2, dbias=G(P["fb"]),
                                     q_key=(_st_uid(st), st.offsets[id(P["fw"])], "bwd", "d_o2", ctx.fp8_tag))
         else:
-            d_o2, dz2 = ln_bwd(dy2, o2, a, P["g2"].data, mean2, rstd2, G(P["g2"]), G(P["b2"]), p_h, seed, s_ln2,
-                               dbias=G(P["fb"]))
+            d_o2, dz2 = ln_bwd(dy2, o2, None if ctx.ln_fused[1] else a, P["g2"].data, mean2, rstd2, G(P["g2"]), G(P["b2"]), p_h, seed, s_ln2,
+                               dbias=G(P["fb"]), drop_after=2 if ctx.ln_fused[1] else False)
         I_ = P["iw"].shape[0]
         # k-contiguous copies W^T for the input-gradient GEMMs (bf16; refreshed once per optimizer step, one launch for all)
         # (from DGRAD_WT_MIN_ROWS tokens)
@@ -1268,8 +1327,8 @@ class BertLayerFn(torch.autograd.Function):
             d_o1, dz1, dq1 = ln_bwd(da, o1, x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, s_ln1, dbias=G(P["ob"]),
                                     q_key=(_st_uid(st), st.offsets[id(P["ow"])], "bwd", "d_o1", ctx.fp8_tag))
         else:
-            d_o1, dz1 = ln_bwd(da, o1, x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, s_ln1,
-                               dbias=G(P["ob"]))
+            d_o1, dz1 = ln_bwd(da, o1, None if ctx.ln_fused[0] else x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, s_ln1,
+                               dbias=G(P["ob"]), drop_after=2 if ctx.ln_fused[0] else False)
             dq1 = None
         wgrad(d_o1, ctxv, G(P["ow"]))
         dctx = linear_dgrad_fp8(d_o1, st, P["ow"], P["ow"], (H, H), role="d_o1", tag=ctx.fp8_tag, pre_q=dq1) if fp8 else linear_dgrad(d_o1, st.compute(P["ow"], dtype), wt=WT(P["ow"]))
