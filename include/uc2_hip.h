@@ -153,6 +153,45 @@ int uc2_gemm_fp8(int M, int N, int K, const void* A8, int lda, const void* B8, i
                  const float* scale_b, void* C, int ldc, const float* bias, int epilogue, const void* aux_in, void* aux_out,
                  int ldaux, int flags, void* stream);
 
+/* ---- One BertLayer per call (model/layer.py:159-170: BertAttention -> BertIntermediate -> BertOutput) ---------------------------
+ * The launch sequence of uc2_amd/ops.py BertLayerFn -- 7 launches forward, 8 backward -- enqueued by one C call per direction: the same
+ * kernels with the same arguments in the same order as the per-kernel entry points above, hence the same bits.  It exists for the host:
+ * at the reference's 104-pair micro-batches (config/uc2_pretrain.json:17-19) an optimizer step is ~700 launches of 10-170 us and the
+ * per-launch Python/ctypes path is within 15 % of the device time.  The caller keeps every decision: it allocates all activations and
+ * gradients (M = B L rows, row-major, leading dimension = width), chooses each GEMM's plan (variant / split_k / UC2_GEMM_* flags, as
+ * for uc2_gemm: the library holds no kernel-selection state), runs the four weight gradients itself (uc2_gemm_wgrad_group on
+ * (d_o2, u), (d_pre, a), (d_o1, ctx), (dqkv, x)) and the second stage of the two LayerNorm backwards (uc2_ln_bwd_reduce* on ws2 ->
+ * dg2 / db2 / d(bf), ws1 -> dg1 / db1 / d(bo)).  Weights in the compute dtype ([out, in], q|k|v stacked), biases / LayerNorm fp32.
+ * The plain route only: no fp8, no head-interleaved q|k|v, no fused dropout-residual tails (those stay in uc2_amd/ops.py). */
+typedef struct Uc2GemmPlan { int variant, split_k, flags; } Uc2GemmPlan;
+typedef struct Uc2BertLayer {
+  int dtype, B, L, H, nh, I, attn_impl;                 /* I: intermediate size; attn_impl as uc2_attn_fwd */
+  float eps, p_hidden, p_attn;                          /* LayerNorm epsilon, hidden / attention-probability dropout */
+  const uint64_t* seed;                                 /* device seed cell (NULL when both probabilities are 0) */
+  uint64_t site_attn, site_ln1, site_ln2;               /* seed offsets of the layer's three dropout sites */
+  const void *wqkv, *wo, *wi, *wf;                      /* [3H,H], [H,H], [I,H], [H,I] */
+  const float *bqkv, *bo, *g1, *b1, *bi, *bf, *g2, *b2;
+  const float* mask;                                    /* additive key mask [B, L] */
+  const void* x;                                        /* layer input [M, H] */
+  void *qkv, *ctx; float* lse;                          /* [M,3H], [M,H], [B,nh,L] */
+  void* o1; float *mean1, *rstd1; void* a;              /* dense output, LayerNorm statistics, attention block output */
+  void *pre, *u;                                        /* gelu'(pre-activation) and gelu(pre-activation), [M, I] */
+  void* o2; float *mean2, *rstd2; void* y;              /* y: the layer output (forward only) */
+  Uc2GemmPlan plan_qkv, plan_o, plan_i, plan_f;
+  void* queue;                                          /* item queue of uc2_gemm_queued, or NULL */
+} Uc2BertLayer;
+typedef struct Uc2BertLayerGrad {
+  const void* dy;                                       /* gradient of the layer output */
+  void *d_o2, *dz2, *d_pre, *da, *d_o1, *dz1, *dctx, *dqkv;   /* dz1 / dz2 (residual-branch gradients) only read with p_hidden > 0 */
+  void* dx;                                             /* gradient of the layer input, or NULL */
+  void *ws1, *ws2;                                      /* uc2_ln_bwd_workspace(M, H) bytes each: partial sums for the caller's reduction */
+  float *dbi, *dbqkv;                                   /* += gradients of the intermediate bias and of the fused q|k|v bias */
+  int* attn_queue;                                      /* queue of uc2_attn_bwd_queued, or NULL */
+  Uc2GemmPlan plan_df, plan_di, plan_do, plan_dqkv;     /* input-gradient GEMMs through W2, W1, Wo, Wqkv (weights read k-strided) */
+} Uc2BertLayerGrad;
+int uc2_bert_layer_fwd(const Uc2BertLayer* layer, void* stream);
+int uc2_bert_layer_bwd(const Uc2BertLayer* layer, const Uc2BertLayerGrad* grad, void* stream);
+
 /* ---- LayerNorm fused with dropout + residual (apex FusedLayerNorm, model/layer.py:25; the dense->dropout->
  *      LayerNorm(x + residual) tails at model/layer.py:111-115,152-156; embeddings model/model.py:331,358-362) -----
  *   drop_after == 0: y = LN(dropout(x) + residual) * gamma + beta     (encoder tails, model/layer.py:113-114,154-155)

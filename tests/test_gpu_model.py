@@ -6,6 +6,8 @@ checked against the same vectors at bf16 resolution (SURVEY.md §7 'Tolerance vs
 from collections import OrderedDict
 
 import numpy as np
+import ctypes
+
 import pytest
 import torch
 
@@ -191,6 +193,58 @@ def test_bert_layer_fused_dropout_residual_tails_vs_unfused():
         if n.endswith("key.bias"):
             continue
         assert rel_err(g1[n], g0[n]) < 1e-2, n
+
+
+@pytest.mark.parametrize("dtype,geom,B,L", [(torch.bfloat16, O.BASE, 104, 96), (torch.bfloat16, O.TINY, 5, 68), (torch.float32, O.TINY, 5, 68)])
+def test_bert_layer_native_entry_is_bit_identical(dtype, geom, B, L):
+    """uc2_bert_layer_fwd / uc2_bert_layer_bwd (ops.NATIVE_LAYER: one C call per layer and direction at the reference's micro-batch
+    sizes, config/uc2_pretrain.json:17-19) against the per-kernel calls of BertLayerFn: the same kernels with the same arguments in
+    the same order -- layer output, dx and every weight gradient bit-identical (dropout on, key mask, forward-only route unchanged)"""
+    cfg = make_cfg(geom, drop=0.1)
+    layer = BertLayer(cfg)
+    synth.det_init_(layer)
+    layer.to(DEV).train()
+    set_compute_dtype(layer, dtype)
+    H = cfg.hidden_size
+    x0 = (synth.det_normal((B, L, H), 3) * 0.5).to(DEV).to(dtype)
+    ext = torch.zeros(B, 1, 1, L, device=DEV)
+    ext[::3, :, :, L - 9:] = -10000.0
+    dy = (synth.det_normal((B, L, H), 4) * 0.1).to(DEV).to(dtype)
+    from uc2_amd import _lib
+    calls = []
+    lib = _lib.load()
+
+    def run(on):
+        was, ops.NATIVE_LAYER = ops.NATIVE_LAYER, on
+        try:
+            outs = []
+            for need_dx in (True, False):
+                layer.zero_grad()
+                x = x0.clone().requires_grad_(need_dx)
+                ops.rng.manual_seed(5)
+                y = layer(x, ext)
+                y.backward(dy)
+                ops.join_side_streams()
+                torch.cuda.synchronize()
+                outs.append((y.detach().clone(), x.grad.clone() if need_dx else None,
+                             OrderedDict((n, p.grad.detach().clone()) for n, p in layer.named_parameters())))
+            return outs
+        finally:
+            ops.NATIVE_LAYER = was
+    assert ops._native_layer_ok(dtype, B * L, False, None) == ops.NATIVE_LAYER
+    ref = run(False)
+    nat = run(True)
+    for (y0, dx0, g0), (y1, dx1, g1) in zip(ref, nat):
+        assert torch.equal(y1, y0)
+        assert (dx0 is None and dx1 is None) or torch.equal(dx1, dx0)
+        for n in g0:
+            if n.endswith("bias") or "LayerNorm" in n:
+                assert rel_err(g1[n], g0[n]) < 1e-5 or g0[n].norm() < 1e-6, n      # (column sums through fp32 atomics: order varies run to run)
+            else:
+                assert torch.equal(g1[n], g0[n]), n
+    # argument errors are reported, not executed
+    bad = ops._BertLayerC()
+    assert lib.uc2_bert_layer_fwd(ctypes.byref(bad), None) != 0 and b"layer.hip" in lib.uc2_last_error()
 
 
 def test_bert_layer_interleaved_qkv_route_is_bit_identical():

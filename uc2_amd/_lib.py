@@ -25,6 +25,8 @@ SIGNATURES = {
     "uc2_gemm": (I, [I, I, I, I, I, I, P, I, P, I, P, I, I, P, I, P, P, I, I, I, I, P, SZ, I, P]),
     "uc2_gemm_queued": (I, [I, I, I, I, I, I, P, I, P, I, P, I, I, P, I, P, P, I, I, I, I, P, SZ, I, P, P]),
     "uc2_gemm_splitk_reduce": (I, [I, I, P, I, I, I, P, SZ, P]),
+    "uc2_bert_layer_fwd": (I, [P, P]),
+    "uc2_bert_layer_bwd": (I, [P, P, P]),
     "uc2_gemm_drop_residual": (I, [I, I, I, P, I, P, I, P, I, P, P, I, F, P, U64, I, P, P]),
     "uc2_gemm_fallback_count": (ctypes.c_longlong, [I]),
     "uc2_gemm_wgrad_group_workspace": (SZ, [I, P]),

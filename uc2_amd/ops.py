@@ -999,16 +999,22 @@ def ln_bwd(dy2, x2, res2, gamma, mean, rstd, dgamma, dbeta, drop_p=0.0, seed=Non
             call("uc2_ln_bwd_partial", d, M, H, ptr(dy2), ptr(x2), ptr(res2), ptr(gamma), ptr(mean), ptr(rstd), drop_p,
                  int(drop_after), ptr(seed), seed_imm, ptr(dx), ptr(dres), int(dbias is not None), ptr(ws), stream())
 
+    _ln_bwd_second_stage(d, M, H, ws, dgamma, dbeta, dbias, x2.device)
+    if q_key is not None:
+        return dx, (dres if dres is not None else dx), q
+    return dx, (dres if dres is not None else dx)
+
+
+def _ln_bwd_second_stage(d, M, H, ws, dgamma, dbeta, dbias, device):
+    """the reduction of a LayerNorm backward's partial column sums (ws) into dgamma / dbeta / dbias: on the side stream, queued for
+    the end of the pass, or right away (see ln_bwd)"""
     def reduce():
         call("uc2_ln_bwd_reduce", d, M, H, ptr(ws), ptr(dgamma), ptr(dbeta), ptr(dbias), stream())
     if dgamma is not None or dbeta is not None or dbias is not None:
         if LN_REDUCE_SIDE and _side_route(M):      # (below WGRAD_SIDE_MIN_ROWS tokens it made the regime erratic: 27.0-30.8 ms against 27.0-27.1)
-            _on_side_stream(x2.device, reduce, (ws,))
+            _on_side_stream(device, reduce, (ws,))
         elif not (LN_REDUCE_BATCH and M < WGRAD_SIDE_MIN_ROWS and _defer_ln_reduction(d, M, H, ws, dgamma, dbeta, dbias)):
             reduce()
-    if q_key is not None:
-        return dx, (dres if dres is not None else dx), q
-    return dx, (dres if dres is not None else dx)
 
 
 # Small token counts (the reference's 104-pair micro-batches): the second stage of every LayerNorm backward of a pass goes out as ONE
@@ -1153,6 +1159,48 @@ def _ilv_wgrad_plan(n_out, n_in, rows, device):
     return 12, min(valid, key=lambda s_: (abs(tiles * s_ - cus), s_))
 
 
+# One C call per layer and direction (include/uc2_hip.h: uc2_bert_layer_fwd / _bwd) for the plain route -- no fp8, no head-interleaved
+# q|k|v, no fused dropout-residual tails, no k-contiguous W^T copies, i.e. the reference's micro-batch sizes: the same kernels with
+# the same arguments in the same order as the per-kernel calls of BertLayerFn below, so the same bits; what it saves is host time
+# (~20 ctypes calls, their argument marshalling and the timing hooks per layer).
+NATIVE_LAYER = os.environ.get("UC2_NATIVE_LAYER", "1") != "0"
+
+
+class _GemmPlanC(ctypes.Structure):
+    _fields_ = [("variant", ctypes.c_int), ("split_k", ctypes.c_int), ("flags", ctypes.c_int)]
+
+
+_VP, _CI, _CF, _U64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_uint64
+
+
+class _BertLayerC(ctypes.Structure):            # Uc2BertLayer
+    _fields_ = ([(n, _CI) for n in ("dtype", "B", "L", "H", "nh", "I", "attn_impl")] + [(n, _CF) for n in ("eps", "p_hidden", "p_attn")]
+                + [("seed", _VP)] + [(n, _U64) for n in ("site_attn", "site_ln1", "site_ln2")]
+                + [(n, _VP) for n in ("wqkv", "wo", "wi", "wf", "bqkv", "bo", "g1", "b1", "bi", "bf", "g2", "b2", "mask", "x", "qkv", "ctx",
+                                      "lse", "o1", "mean1", "rstd1", "a", "pre", "u", "o2", "mean2", "rstd2", "y")]
+                + [(n, _GemmPlanC) for n in ("plan_qkv", "plan_o", "plan_i", "plan_f")] + [("queue", _VP)])
+
+
+class _BertLayerGradC(ctypes.Structure):        # Uc2BertLayerGrad
+    _fields_ = ([(n, _VP) for n in ("dy", "d_o2", "dz2", "d_pre", "da", "d_o1", "dz1", "dctx", "dqkv", "dx", "ws1", "ws2", "dbi", "dbqkv",
+                                    "attn_queue")]
+                + [(n, _GemmPlanC) for n in ("plan_df", "plan_di", "plan_do", "plan_dqkv")])
+
+
+def _plan_c(dtype, tb, M, N, K, epi=EPI_NONE, flags=0):
+    """the (variant, split_k, flags) _gemm_planned + gemm would pass for this GEMM"""
+    v, sp = gemm_plan(dtype, False, tb, M, N, K, False)
+    if PP_SKEW and v in (8, 9, 12):
+        flags |= (PP_SKEW.get(epi, 0) & 15) << 4
+    return _GemmPlanC(v, sp, flags | _EXTRA_FLAGS)
+
+
+def _native_layer_ok(dtype, M, fp8, ilv):
+    return (NATIVE_LAYER and not fp8 and ilv is None and GEMM_TIMER is None and HBM_TIMER is None and _FORCED[0] is None
+            and not (LN_FUSE and dtype == torch.bfloat16 and M >= LN_FUSE_MIN_ROWS)
+            and not (DGRAD_TRANSPOSED_W and dtype == torch.bfloat16 and M >= DGRAD_WT_MIN_ROWS))
+
+
 class BertLayerFn(torch.autograd.Function):
     """x -> LN(x + Wo.Attn(x)) -> LN(a + W2.gelu(W1.a)).  10 kernel launches forward, 21 backward.
     Weight/bias/LN gradients are accumulated by the kernels directly into the fp32 gradient arena
@@ -1221,7 +1269,32 @@ class BertLayerFn(torch.autograd.Function):
         fp8 = bool(cfg.get("fp8")) and dtype == torch.bfloat16 and H % 128 == 0 and P["iw"].shape[0] % 128 == 0
         I_ = P["iw"].shape[0]
         pre = torch.empty((M, I_), dtype=dtype, device=x.device)
-        if fp8:
+        native = _native_layer_ok(dtype, M, fp8, ilv)
+        if native:
+            dev = x.device
+            e = lambda *shape, dt_=dtype: torch.empty(shape, dtype=dt_, device=dev)
+            f32 = torch.float32
+            qkv, ctxv, lse = e(M, 3 * H), e(M, H), e(B, nh, L, dt_=f32)
+            o1, mean1, rstd1, a = e(M, H), e(M, dt_=f32), e(M, dt_=f32), e(M, H)
+            u, o2, mean2, rstd2, y = e(M, I_), e(M, H), e(M, dt_=f32), e(M, dt_=f32), e(M, H)
+            c = _BertLayerC()
+            c.dtype, c.B, c.L, c.H, c.nh, c.I, c.attn_impl = dt(dtype), B, L, H, nh, I_, ATTN_IMPL
+            c.eps, c.p_hidden, c.p_attn = 1e-12, p_h, p_a
+            c.seed, c.site_attn, c.site_ln1, c.site_ln2 = ptr(seed), s_attn, s_ln1, s_ln2
+            c.wqkv, c.wo, c.wi, c.wf = wqkv.data_ptr(), st.compute(P["ow"], dtype).data_ptr(), st.compute(P["iw"], dtype).data_ptr(), st.compute(P["fw"], dtype).data_ptr()
+            c.bqkv, c.bo, c.g1, c.b1 = bqkv.data_ptr(), P["ob"].data.data_ptr(), P["g1"].data.data_ptr(), P["b1"].data.data_ptr()
+            c.bi, c.bf, c.g2, c.b2 = P["ib"].data.data_ptr(), P["fb"].data.data_ptr(), P["g2"].data.data_ptr(), P["b2"].data.data_ptr()
+            c.mask, c.x = mask2d.data_ptr(), x2.data_ptr()
+            c.qkv, c.ctx, c.lse, c.o1, c.mean1, c.rstd1, c.a = (qkv.data_ptr(), ctxv.data_ptr(), lse.data_ptr(), o1.data_ptr(), mean1.data_ptr(),
+                                                                 rstd1.data_ptr(), a.data_ptr())
+            c.pre, c.u, c.o2, c.mean2, c.rstd2, c.y = pre.data_ptr(), u.data_ptr(), o2.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), y.data_ptr()
+            c.plan_qkv, c.plan_o = _plan_c(dtype, False, M, 3 * H, H), _plan_c(dtype, False, M, H, H)
+            c.plan_i, c.plan_f = _plan_c(dtype, False, M, I_, H, EPI_GELU, GEMM_AUX_DERIV), _plan_c(dtype, False, M, H, I_)
+            c.queue = ptr(_gemm_queue(dev)) if (GEMM_QUEUE and dtype == torch.bfloat16) else None
+            _lib.check(_lib.load().uc2_bert_layer_fwd(ctypes.byref(c), stream()))
+            ctx.native_c = c
+            fused1 = fused2 = False
+        elif fp8:
             # e4m3 operands for the four forward GEMMs (per-tensor scales computed on the device), bf16 outputs
             # tensor roles (keys of the delayed-scaling histories): a role is named by its CONSUMER; the layer input's by the layer id,
             # so that the layer above can write the e4m3 copy from its last LayerNorm (handed over through _FP8_PREQ)
@@ -1262,7 +1335,9 @@ class BertLayerFn(torch.autograd.Function):
             fused2 = o2 is not None
             if not fused2:
                 o2 = linear_fwd(u, st.compute(P["fw"], dtype), P["fb"].data)
-        if fp8:
+        if native:
+            pass
+        elif fp8:
             fused1 = fused2 = False
             y, mean2, rstd2, yq = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, s_ln2, q_key=ky)
             _FP8_PREQ.clear()                          # (at most one hand-over alive: the last layer's copy has no fp8 consumer)
@@ -1277,6 +1352,7 @@ class BertLayerFn(torch.autograd.Function):
         ctx.save_for_backward(x2, mask2d, qkv, ctxv, lse, o1, mean1, rstd1, a, pre, u, o2, mean2, rstd2, seed)
         ctx.layer, ctx.cfg, ctx.shape, ctx.p = layer, cfg, (B, L, H, nh, D), (p_h, p_a, (s_attn, s_ln1, s_ln2))
         ctx.params, ctx.fp8, ctx.fp8_tag = params, fp8, FP8_TAG
+        ctx.native = native
         ctx.ilv_plan = ilv[1] if ilv is not None else None
         return y.view(B, L, H)
 
@@ -1296,7 +1372,35 @@ class BertLayerFn(torch.autograd.Function):
 
         # LN2 and FFN
         fp8 = ctx.fp8
-        if fp8:
+        I_ = P["iw"].shape[0]
+        nat = None
+        if ctx.native:
+            # everything of this layer's backward except the weight gradients and the LayerNorm reductions: one C call
+            dev = x2.device
+            e = lambda *shape: torch.empty(shape, dtype=dtype, device=dev)
+            lib = _lib.load()
+            nws = lib.uc2_ln_bwd_workspace(M, H) // 4
+            ws1, ws2 = torch.empty(nws, dtype=torch.float32, device=dev), torch.empty(nws, dtype=torch.float32, device=dev)
+            d_o2, d_pre, da, d_o1, dctx, dqkv = e(M, H), e(M, I_), e(M, H), e(M, H), e(M, H), e(M, 3 * H)
+            dz2, dz1 = (e(M, H), e(M, H)) if p_h > 0.0 else (None, None)
+            dxn = e(M, H) if ctx.needs_input_grad[0] else None
+            g = _BertLayerGradC()
+            g.dy, g.d_o2, g.dz2, g.d_pre, g.da = dy2.data_ptr(), d_o2.data_ptr(), ptr(dz2), d_pre.data_ptr(), da.data_ptr()
+            g.d_o1, g.dz1, g.dctx, g.dqkv, g.dx = d_o1.data_ptr(), ptr(dz1), dctx.data_ptr(), dqkv.data_ptr(), ptr(dxn)
+            g.ws1, g.ws2 = ws1.data_ptr(), ws2.data_ptr()
+            g.dbi = G(P["ib"]).data_ptr()
+            g.dbqkv = st.grad_span(P["qb"], P["vb"], (3 * H,)).data_ptr()
+            g.attn_queue = ptr(_gemm_queue(dev)[12:14]) if (GEMM_QUEUE and dtype == torch.bfloat16) else None
+            g.plan_df = _plan_c(dtype, True, M, I_, H, EPI_DGELU, GEMM_AUX_DERIV)
+            g.plan_di, g.plan_do, g.plan_dqkv = _plan_c(dtype, True, M, H, I_, EPI_ADD), _plan_c(dtype, True, M, H, H), _plan_c(dtype, True, M, H, 3 * H, EPI_ADD)
+            _lib.check(lib.uc2_bert_layer_bwd(ctypes.byref(ctx.native_c), ctypes.byref(g), stream()))
+            d_ = dt(dtype)
+            _ln_bwd_second_stage(d_, M, H, ws2, G(P["g2"]), G(P["b2"]), G(P["fb"]), dev)
+            _ln_bwd_second_stage(d_, M, H, ws1, G(P["g1"]), G(P["b1"]), G(P["ob"]), dev)
+            nat = (d_o2, d_pre, d_o1, dqkv, dxn)
+        if nat is not None:
+            pass
+        elif fp8:
             d_o2, dz2, dq2 = ln_bwd(dy2, o2, a, P["g2"].data, mean2, rstd2, G(P["g2"]), G(P["b2"]), p_h, seed, s_ln2, dbias=G(P["fb"]),
                                     q_key=(_st_uid(st), st.offsets[id(P["fw"])], "bwd", "d_o2", ctx.fp8_tag))
         else:
@@ -1311,19 +1415,25 @@ class BertLayerFn(torch.autograd.Function):
         grouped = [] if (WGRAD_GROUP and dtype == torch.bfloat16 and M < WGRAD_SIDE_MIN_ROWS and M % 128 == 0) else None
         wgrad = (lambda dyv, xv, dwv: grouped.append((dyv, xv, dwv))) if grouped is not None else (lambda dyv, xv, dwv: linear_wgrad(dyv, xv, dwv, None))
         wgrad(d_o2, u, G(P["fw"]))
-        if fp8:
+        if nat is not None:
+            pass
+        elif fp8:
             d_pre, dq = linear_dgrad_fp8(d_o2, st, P["fw"], P["fw"], (H, I_), EPI_DGELU, pre, colsum_out=G(P["ib"]), flags=GEMM_AUX_DERIV, role="d_o2",
                                          tag=ctx.fp8_tag, pre_q=dq2, q_key=(_st_uid(st), st.offsets[id(P["iw"])], "bwd", "d_pre", ctx.fp8_tag))
         else:
             d_pre = linear_dgrad(d_o2, st.compute(P["fw"], dtype), EPI_DGELU, pre, colsum_out=G(P["ib"]),
                                  flags=GEMM_AUX_DERIV, wt=WT(P["fw"]))                         # + d(intermediate bias)
         wgrad(d_pre, a, G(P["iw"]))
-        if fp8:
+        if nat is not None:
+            pass
+        elif fp8:
             da = linear_dgrad_fp8(d_pre, st, P["iw"], P["iw"], (I_, H), EPI_ADD, dz2, role="d_pre", tag=ctx.fp8_tag, pre_q=dq)
         else:
             da = linear_dgrad(d_pre, st.compute(P["iw"], dtype), EPI_ADD, dz2, wt=WT(P["iw"]))
         # LN1, output projection, attention, fused QKV
-        if fp8:
+        if nat is not None:
+            pass
+        elif fp8:
             d_o1, dz1, dq1 = ln_bwd(da, o1, x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, s_ln1, dbias=G(P["ob"]),
                                     q_key=(_st_uid(st), st.offsets[id(P["ow"])], "bwd", "d_o1", ctx.fp8_tag))
         else:
@@ -1331,6 +1441,10 @@ class BertLayerFn(torch.autograd.Function):
                                dbias=G(P["ob"]), drop_after=2 if ctx.ln_fused[0] else False)
             dq1 = None
         wgrad(d_o1, ctxv, G(P["ow"]))
+        dwqkv = st.grad_span(P["qw"], P["vw"], (3 * H, H))
+        if nat is not None:
+            wgrad(dqkv, x2, dwqkv)
+            return BertLayerFn._finish_backward(ctx, grouped, dy2, None if dxn is None else dxn.view(B, L, H))
         dctx = linear_dgrad_fp8(d_o1, st, P["ow"], P["ow"], (H, H), role="d_o1", tag=ctx.fp8_tag, pre_q=dq1) if fp8 else linear_dgrad(d_o1, st.compute(P["ow"], dtype), wt=WT(P["ow"]))
         dwqkv = st.grad_span(P["qw"], P["vw"], (3 * H, H))
         dbqkv = st.grad_span(P["qb"], P["vb"], (3 * H,))
@@ -1364,6 +1478,11 @@ class BertLayerFn(torch.autograd.Function):
                 else:
                     dx = linear_dgrad(dqkv, st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype), EPI_ADD, dz1,
                                       wt=WT(P["qw"], P["vw"], (3 * H, H))).view(B, L, H)
+        return BertLayerFn._finish_backward(ctx, grouped, dy2, dx)
+
+    @staticmethod
+    def _finish_backward(ctx, grouped, dy2, dx):
+        """the layer's grouped weight-gradient launch and the gradient-ready hook (both routes of backward end here)"""
         if grouped:
             if WGRAD_GROUP_SIDE and WGRAD_SIDE_STREAM and not torch.cuda.is_current_stream_capturing():
                 # the layer's grouped weight-gradient launch beside the next layer's backward (small token counts: the main chain's
