@@ -282,7 +282,13 @@ int uc2_embed_fwd(int dtype, int rows, int H, const int64_t* ids, const int64_t*
                   int type_const, const float* word, const float* pos, const float* type, void* out, void* stream);
 int uc2_embed_bwd(int dtype, int rows, int H, const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
                   const void* dpre, float* dword, float* dpos, float* dtype_tab, int64_t word_pad, int64_t pos_pad,
-                  void* stream);     /* word_pad / pos_pad: nn.Embedding padding_idx rows get no gradient (-1 = none) */
+                  void* stream);
+/* uc2_embed_bwd for ids laid out [B, T]: position / type gradient rows are summed in registers down the batch (their ids repeat from
+ * sequence to sequence) and flushed with one atomic per column per id change, instead of one atomic per token and column; the word
+ * rows are direct atomics as before.  Same sums up to fp32 order.  Returns -2 (nothing launched) unless H / 64 is one of 1, 2, 4, 8, 12, 16. */
+int uc2_embed_bwd_seq(int dtype, int B, int T, int H, const int64_t* ids, const int64_t* pos_ids, const int64_t* type_ids,
+                      const void* dpre, float* dword, float* dpos, float* dtype_tab, int64_t word_pad, int64_t pos_pad,
+                      void* stream);     /* word_pad / pos_pad: nn.Embedding padding_idx rows get no gradient (-1 = none) */
 int uc2_add_rowvec(int a_dtype, int dtype, int rows, int H, const void* a, const void* b, const float* vec,
                    const uint8_t* rowmask, void* out, void* stream);
 int uc2_gather_rows_fwd(int dtype, int B, int S, int L, int H, const void* src, const int64_t* index, void* out,

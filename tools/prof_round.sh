@@ -20,8 +20,9 @@ python3 tools/pmc_summarize.py $R $O/pmc_fetch $O/pmc_write $O/pmc_sq "gemm_bf16
 unset UC2_WGRAD_SIDE
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_1024 -- python3 bench.py --batch 1024 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/trace_1024.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_2048 -- python3 bench.py --batch 2048 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/trace_2048.log 2>&1
-python3 scratch/regime_step.py itm 8 > /dev/null 2>&1
+python3 scratch/regime_step.py itm 8 > $O/regime_plain.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_regime -- python3 scratch/regime_step.py itm 8 > $O/trace_regime.log 2>&1
+python3 tools/timeline.py $O/trace_regime adamw_kernel 4 > $O/regime_timeline.txt 2>&1
 find $O -name "*kernel_trace.csv" -delete
 find $O -name "*counter_collection.csv" -delete
 find $O -name "*.db" -delete

@@ -57,6 +57,7 @@ SIGNATURES = {
     "uc2_position_ids": (I, [I, I, P, I64, P, P]),
     "uc2_embed_fwd": (I, [I, I, I, P, P, P, I, P, P, P, P, P]),
     "uc2_embed_bwd": (I, [I, I, I, P, P, P, P, P, P, P, I64, I64, P]),
+    "uc2_embed_bwd_seq": (I, [I, I, I, I, P, P, P, P, P, P, P, I64, I64, P]),
     "uc2_gather_rows_fwd": (I, [I, I, I, I, I, P, P, P, P]),
     "uc2_gather_rows_bwd": (I, [I, I, I, I, I, P, P, P, P]),
     "uc2_transpose_batch": (I, [I, P, P, P, P]),

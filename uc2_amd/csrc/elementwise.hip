@@ -84,6 +84,54 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(int rows, int H, const i
     if (ty) atomicAdd(ty + c, g);
   }
 }
+// The same for ids laid out [B, T] (the embedding call of model/model.py:296-333): a wave walks ONE sequence position t down a chunk of
+// the batch.  Position ids (and type ids) then repeat from row to row -- arange + offset per sequence, one type per modality -- so
+// their gradient rows are accumulated in registers and flushed with one atomic per column when the id changes and at the end of
+// the chunk: 6144 pairs x 60 tokens piled 368 k atomic adds onto each element of ~60 position rows and ONE type row in
+// embed_bwd_kernel (1.88 ms per step).  Any id pattern is handled (a change of id is a flush), only the speed assumes repetition.
+// The word rows stay direct atomics (distinct ids, no pile-up).
+template <typename T, int NC>                         // NC = H / 64 columns per lane (column = lane + 64 k: one dword per lane and
+__global__ __launch_bounds__(256) void embed_bwd_seq_kernel(int B, int Tn, int H, int bchunk, const int64_t* __restrict__ ids,   // instruction, 256 contiguous bytes per atomic)
+                                                            const int64_t* __restrict__ pos_ids, const int64_t* __restrict__ type_ids,
+                                                            const T* __restrict__ dpre, float* __restrict__ dword,
+                                                            float* __restrict__ dpos, float* __restrict__ dtype, int64_t word_pad,
+                                                            int64_t pos_pad) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nchunk = (B + bchunk - 1) / bchunk;
+  if (w >= Tn * nchunk) return;
+  const int t = w % Tn, b0 = (w / Tn) * bchunk, b1 = min(B, b0 + bchunk);
+  float ap[NC], at[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) { ap[k] = 0.f; at[k] = 0.f; }
+  int64_t curp = -1, curt = -1;                        // ids whose sums are in ap / at (-1: none)
+  auto flush = [&](float (&a)[NC], float* tab, int64_t id) {
+    if (id < 0) return;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { atomicAdd(tab + (size_t)id * H + lane + 64 * k, a[k]); a[k] = 0.f; }
+  };
+  for (int b = b0; b < b1; ++b) {
+    const size_t r = (size_t)b * Tn + t;
+    const int64_t wid = ids[r];
+    const int64_t pid = (dpos && pos_ids[r] != pos_pad) ? pos_ids[r] : -1;
+    const int64_t tid = (dtype && type_ids) ? type_ids[r] : -1;
+    if (pid != curp) { flush(ap, dpos, curp); curp = pid; }
+    if (tid != curt) { flush(at, dtype, curt); curt = tid; }
+    float* wrow = (dword && wid != word_pad) ? dword + (size_t)wid * H : nullptr;
+    float g[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) g[k] = to_f<T>(dpre[r * H + lane + 64 * k]);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      if (wrow) atomicAdd(wrow + lane + 64 * k, g[k]);
+      if (pid >= 0) ap[k] += g[k];                     // (a padding position / no type table: nothing to sum)
+      if (tid >= 0) at[k] += g[k];
+    }
+  }
+  flush(ap, dpos, curp);
+  flush(at, dtype, curt);
+}
+
 extern "C" int uc2_embed_fwd(int dtype, int rows, int H, const int64_t* ids, const int64_t* pos_ids,
                              const int64_t* type_ids, int type_const, const float* word, const float* pos,
                              const float* type, void* out, void* stream) {
@@ -106,6 +154,30 @@ extern "C" int uc2_embed_bwd(int dtype, int rows, int H, const int64_t* ids, con
   dim3 grid((rows + 3) / 4);
   if (dtype == 0) hipLaunchKernelGGL(embed_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, rows, H, ids, pos_ids, type_ids, (const float*)dpre, dword, dpos, dtype_tab, word_pad, pos_pad);
   else hipLaunchKernelGGL(embed_bwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, rows, H, ids, pos_ids, type_ids, (const bf16*)dpre, dword, dpos, dtype_tab, word_pad, pos_pad);
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int uc2_embed_bwd_seq(int dtype, int B, int T, int H, const int64_t* ids, const int64_t* pos_ids,
+                                 const int64_t* type_ids, const void* dpre, float* dword, float* dpos, float* dtype_tab,
+                                 int64_t word_pad, int64_t pos_pad, void* stream) {
+  UC2_CHECK_ARG(dtype == 0 || dtype == 1);
+  if (B <= 0 || T <= 0) return 0;
+  UC2_CHECK_ARG(ids && pos_ids && dpre);
+  if (H <= 0 || (H % 64) != 0 || H > 1024) return -2;        // (the caller falls back to uc2_embed_bwd)
+  // batch chunk per wave: long enough to amortise the flush (H atomics per table), short enough for ~8 waves per SIMD over the chip
+  int bchunk = (int)(((long long)B * T + 8191) / 8192);
+  if (bchunk < 8) bchunk = 8;
+  if (bchunk > B) bchunk = B;
+  const int nchunk = (B + bchunk - 1) / bchunk;
+  const int waves = T * nchunk;
+  dim3 grid((waves + 3) / 4);
+#define EB_LAUNCH(TT, NCC) hipLaunchKernelGGL((embed_bwd_seq_kernel<TT, NCC>), grid, dim3(256), 0, (hipStream_t)stream, B, T, H, bchunk, ids, pos_ids, type_ids, (const TT*)dpre, dword, dpos, dtype_tab, word_pad, pos_pad)
+#define EB_NC(TT) do { switch (H / 64) { case 1: EB_LAUNCH(TT, 1); break; case 2: EB_LAUNCH(TT, 2); break; case 4: EB_LAUNCH(TT, 4); break; case 8: EB_LAUNCH(TT, 8); break; \
+                                         case 12: EB_LAUNCH(TT, 12); break; case 16: EB_LAUNCH(TT, 16); break; default: return -2; } } while (0)
+  if (dtype == 0) EB_NC(float); else EB_NC(bf16);
+#undef EB_NC
+#undef EB_LAUNCH
   UC2_LAUNCH_CHECK();
   return 0;
 }

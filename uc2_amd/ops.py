@@ -1766,11 +1766,22 @@ class EmbedTextFn(torch.autograd.Function):
             d2 = d2.contiguous()
         rows = d2.shape[0]
         dtyp = st.grad_buf(typ)
-        call("uc2_embed_bwd", dt(d2.dtype), rows, H, ptr(ids), ptr(pos_ids), ptr(type_ids), ptr(d2),
-             ptr(st.grad_buf(word)), ptr(st.grad_buf(pos)), ptr(dtyp), ctx.pads[0], ctx.pads[1], stream())
+        # ids are [B, T]: position / type rows repeat down the batch and are summed in registers (uc2_embed_bwd_seq); -2 = shape not
+        # taken, the row-per-wave kernel then adds every token's row with atomics
+        Bn, Tn = ids.shape
+        rc = _lib.load().uc2_embed_bwd_seq(dt(d2.dtype), Bn, Tn, H, ptr(ids), ptr(pos_ids), ptr(type_ids), ptr(d2), ptr(st.grad_buf(word)),
+                                           ptr(st.grad_buf(pos)), ptr(dtyp), ctx.pads[0], ctx.pads[1], stream()) if EMBED_BWD_SEQ else -2
+        if rc == -2:
+            call("uc2_embed_bwd", dt(d2.dtype), rows, H, ptr(ids), ptr(pos_ids), ptr(type_ids), ptr(d2),
+                 ptr(st.grad_buf(word)), ptr(st.grad_buf(pos)), ptr(dtyp), ctx.pads[0], ctx.pads[1], stream())
+        else:
+            _lib.check(rc)
         if type_ids is None:         # constant type 0: its row gets the column sum (no atomic pile-up on one row)
             colsum_accum(d2, dtyp[0])
         return (None,) * 10
+
+
+EMBED_BWD_SEQ = os.environ.get("UC2_EMBED_BWD_SEQ", "1") != "0"      # per-position embedding backward (uc2_embed_bwd_seq)
 
 
 class GatherRowsFn(torch.autograd.Function):
