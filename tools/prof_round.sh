@@ -16,7 +16,7 @@ B="python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B > $O/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq -- $B > $O/pmc_sq.log 2>&1
-python3 tools/pmc_summarize.py $R $O/pmc_fetch $O/pmc_write $O/pmc_sq "gemm_bf16_pp16_kernel<true, true, true, 0, 2>" "gemm_bf16_pp16_kernel<false, false, true, 5, 2>" "gemm_bf16_pp16_kernel<false, false, true, 6, 2>" "gemm_bf16_pp16_kernel<false, false, true, 3, 2>" "gemm_bf16_pp16_kernel<false, false, true, 0, 2>" attn_bwd_mfma attn_fwd_mfma ln_bwd_kernel ln_fwd16_kernel adamw_kernel > $O/pmc_summary.json
+python3 tools/pmc_summarize.py $R $O/pmc_fetch $O/pmc_write $O/pmc_sq "gemm_bf16_pp16_kernel<true, true, true, 0, 2>" "gemm_bf16_pp16_kernel<false, false, true, 5, 2>" "gemm_bf16_pp16_kernel<false, false, true, 6, 2>" "gemm_bf16_pp16_kernel<false, false, true, 3, 2>" "gemm_bf16_pp16_kernel<false, false, true, 0, 2>" "gemm_bf16_pp16_kernel<false, false, true, 10, 2>" attn_bwd_mfma attn_fwd_mfma ln_bwd_kernel ln_fwd16_kernel adamw_kernel > $O/pmc_summary.json
 unset UC2_WGRAD_SIDE
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_1024 -- python3 bench.py --batch 1024 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/trace_1024.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_2048 -- python3 bench.py --batch 2048 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/trace_2048.log 2>&1
