@@ -133,6 +133,12 @@ int uc2_fp8_quant(int dtype, int rows, int cols, const void* x, int ldx, const f
 /* the same with the scale derived from the amax cell inside the kernel and written to *scale_out (one launch less per tensor) */
 int uc2_fp8_quant_amax(int dtype, int rows, int cols, const void* x, int ldx, const void* amax_bits, float* scale_out,
                        void* out, int ldo, int transpose, void* stream);
+/* The e4m3 copies of up to any number of fp32 weight matrices in 3 launches per 32 of them: per item its maximum |w| (amax: one 4-byte
+ * cell, cleared here), scale = the just-in-time power of two of uc2_fp8_quant_amax, out = sat_e4m3(w * scale) [rows, cols] and
+ * out_t = its transpose [cols, rows] (either may be NULL).  Bit-identical to uc2_fp8_amax + uc2_fp8_quant_amax per weight.  rows and
+ * cols multiples of 64, w 16-byte aligned: -2 (nothing launched) otherwise.  `items` is host memory. */
+typedef struct Uc2Fp8WeightItem { const float* w; int rows, cols; void* out; void* out_t; void* amax; float* scale; } Uc2Fp8WeightItem;
+int uc2_fp8_quant_weights_batch(int n, const Uc2Fp8WeightItem* items, void* stream);
 /* delayed scaling, ONE pass over x: quantise with half the scale of the previous maximum (the maximum this tensor role had at its
  * previous use; twice that maximum stays representable, e4m3 saturates beyond) while accumulating max |x| for the next use, and clear
  * the cells of the use after that.  amax_prev / amax_next / amax_clear: three distinct groups of UC2_AMAX_CELLS (16) 4-byte cells the
@@ -255,6 +261,18 @@ int uc2_attn_bwd(int dtype, int impl, int B, int L, int nh, int D, const void* q
 int uc2_attn_bwd_queued(int dtype, int impl, int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
                         float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx, const void* dctx,
                         const float* lse, void* dqkv, float* dbias_qkv, int* queue, void* stream);
+/* fp8 mode (BASELINE.json configs[4]): the MFMA attention kernels (plain q|k|v layout) also write the e4m3 copy of their output for the
+ * GEMM that reads it -- uc2_attn_fwd_q: q_out = sat_e4m3(ctx * scale) [B L, nh D] (output projection); uc2_attn_bwd_q: q_out =
+ * sat_e4m3(dqkv * scale) [B L, 3 nh D] (input gradient of the q|k|v projection) -- from the bf16-rounded values, with delayed scaling
+ * and the cell groups of uc2_fp8_quant_delayed: no quantisation pass over ctx / dqkv.  bf16 only; -2 (nothing launched) when the MFMA
+ * kernels do not take (L, D).  `queue` as uc2_attn_bwd_queued (may be NULL). */
+int uc2_attn_fwd_q(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale, float drop_p,
+                   const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse, void* q_out, const void* amax_prev,
+                   void* amax_next, void* amax_clear, float* q_scale_out, void* stream);
+int uc2_attn_bwd_q(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale, float drop_p,
+                   const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx, const void* dctx, const float* lse, void* dqkv,
+                   float* dbias_qkv, int* queue, void* q_out, const void* amax_prev, void* amax_next, void* amax_clear,
+                   float* q_scale_out, void* stream);
 int uc2_attn_mfma_supported(int L, int D);
 /* head-averaged attention probabilities out[B, L, L] (MultiheadAttention need_weights, model/attention.py:255-260) */
 int uc2_attn_probs_mean(int dtype, int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,

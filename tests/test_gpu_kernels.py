@@ -1443,6 +1443,80 @@ def test_layernorm_fused_e4m3_outputs(M, H):
     del ops._FP8_HIST[key]
 
 
+@pytest.mark.parametrize("B,L,nh,D,p", [(6, 96, 12, 64, 0.1), (3, 130, 16, 64, 0.1), (4, 40, 4, 32, 0.0)])
+def test_attention_fused_e4m3_outputs(B, L, nh, D, p, request):
+    """uc2_attn_fwd_q / uc2_attn_bwd_q (fp8 mode): ctx / dqkv bit-identical to the plain kernels, their e4m3 copies equal to
+    quantising the bf16 result with the same (delayed) scale, the role's next maximum recorded, the third cell group cleared"""
+    import math
+    H = nh * D
+    qkv = rnd((B * L, 3 * H), 1, 0.5, torch.bfloat16)
+    mask = torch.zeros(B, L, device=DEV)
+    mask[0, L - 5:] = -10000.0
+    seed = torch.tensor([77], dtype=torch.int64, device=DEV)
+    dctx = rnd((B * L, H), 2, 0.1, torch.bfloat16)
+    ctx0, lse0 = ops.attn_fwd(qkv, mask, B, L, nh, D, p, seed if p else None, 3)
+    dq0 = ops.attn_bwd(qkv, mask, ctx0, dctx, lse0, B, L, nh, D, p, seed if p else None, 3)
+    C = ops.AMAX_CELLS
+    was, ops.FP8_ATTN_FUSED = ops.FP8_ATTN_FUSED, True                   # (off by default: measured break-even on uc2-large)
+    request.addfinalizer(lambda: setattr(ops, "FP8_ATTN_FUSED", was))
+    for which in ("fwd", "bwd"):
+        key = ("test-attn-q", which, B, L)
+        ref = ctx0 if which == "fwd" else dq0
+        amax_prev = float(ref.float().abs().max()) * 1.3
+        cells = torch.zeros(3 * C, dtype=torch.int32, device=DEV)
+        cells[0] = torch.tensor(amax_prev, device=DEV).view(torch.int32)
+        cells[2 * C:] = 777
+        ops._FP8_HIST[key] = [cells, 0]
+        if which == "fwd":
+            out, lse1, q = ops.attn_fwd(qkv, mask, B, L, nh, D, p, seed if p else None, 3, q_key=key)
+            assert torch.equal(lse1, lse0)
+        else:
+            out, q = ops.attn_bwd(qkv, mask, ctx0, dctx, lse0, B, L, nh, D, p, seed if p else None, 3, q_key=key)
+        assert q is not None
+        q8, sc = q
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+        assert float(sc) == 2.0 ** math.floor(math.log2(448.0 / amax_prev)) * 0.5
+        want = (ref.float() * sc).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+        assert torch.equal(q8, want)
+        assert float(cells[C:2 * C].max().view(torch.float32)) == float(ref.float().abs().max())
+        assert int(cells[2 * C:].abs().max()) == 0
+        del ops._FP8_HIST[key]
+    # no history for the role yet: the plain kernels run, no e4m3 copy
+    out, lse1, q = ops.attn_fwd(qkv, mask, B, L, nh, D, p, seed if p else None, 3, q_key=("test-attn-q", "none"))
+    assert q is None and torch.equal(out.view(torch.int16), ctx0.view(torch.int16))
+
+
+def test_fp8_weight_copies_in_one_batch():
+    """uc2_fp8_quant_weights_batch: maxima, scales and both e4m3 orientations of 35 weight matrices (two batches of the kernel's 32)
+    bit-identical to uc2_fp8_amax + uc2_fp8_quant_amax per weight; shapes off the 64 x 64 tiling are refused"""
+    import ctypes
+    from uc2_amd import _lib
+    lib = _lib.load()
+    shapes = [(128, 64), (64, 256), (768, 768), (3072, 768), (768, 3072), (192, 320)] * 6
+    shapes = shapes[:35]
+    ws = [rnd(shp, 10 + i, 0.02 * (1 + i % 5)) for i, shp in enumerate(shapes)]
+    outs = [(torch.zeros(shp, dtype=torch.uint8, device=DEV), torch.zeros(shp[::-1], dtype=torch.uint8, device=DEV),
+             torch.full((1,), 12345, dtype=torch.int32, device=DEV), torch.zeros(1, device=DEV)) for shp in shapes]
+    arr = (ops._Fp8WeightItem * len(ws))()
+    for i, (w, (o, ot, am, sc)) in enumerate(zip(ws, outs)):
+        arr[i] = ops._Fp8WeightItem(w.data_ptr(), w.shape[0], w.shape[1], o.data_ptr(), ot.data_ptr() if i % 7 != 3 else None, am.data_ptr(), sc.data_ptr())
+    assert lib.uc2_fp8_quant_weights_batch(len(ws), arr, None) == 0
+    torch.cuda.synchronize()
+    for i, (w, (o, ot, am, sc)) in enumerate(zip(ws, outs)):
+        r8, rs = ops.fp8_quantize(w)
+        rt8, rts = ops.fp8_quantize(w, transpose=True)
+        assert float(sc) == float(rs) == float(rts)
+        assert float(am.view(torch.float32)) == float(w.abs().max())
+        assert torch.equal(o, r8)
+        if i % 7 != 3:
+            assert torch.equal(ot, rt8)
+        else:
+            assert int(ot.max()) == 0                                   # no transposed copy asked for: untouched
+    bad = (ops._Fp8WeightItem * 1)(ops._Fp8WeightItem(ws[0].data_ptr(), 100, 64, outs[0][0].data_ptr(), None, outs[0][2].data_ptr(), outs[0][3].data_ptr()))
+    assert lib.uc2_fp8_quant_weights_batch(1, bad, None) == -2
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_fp8_delayed_scaling_quantisation_one_pass(dtype):
     """uc2_fp8_quant_delayed through ops.fp8_quantize_act: the first use of a tensor role takes the just-in-time route and starts the

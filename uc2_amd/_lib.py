@@ -31,6 +31,9 @@ SIGNATURES = {
     "uc2_gemm_fallback_count": (ctypes.c_longlong, [I]),
     "uc2_gemm_wgrad_group_workspace": (SZ, [I, P]),
     "uc2_gemm_wgrad_group": (I, [I, I, P, I, P, SZ, P]),
+    "uc2_fp8_quant_weights_batch": (I, [I, P, P]),
+    "uc2_attn_fwd_q": (I, [I, I, I, I, P, P, F, F, P, U64, P, P, P, P, P, P, P, P]),
+    "uc2_attn_bwd_q": (I, [I, I, I, I, P, P, F, F, P, U64, P, P, P, P, P, P, P, P, P, P, P, P]),
     "uc2_fp8_amax": (I, [I, SZ, P, P, P]),
     "uc2_fp8_scale": (I, [P, P, P]),
     "uc2_fp8_quant": (I, [I, I, I, P, I, P, P, I, I, P]),

@@ -93,7 +93,46 @@ __device__ __forceinline__ void acc_colsum_atomic(const f32x16 (&a)[DB], bool ro
 // Store one transposed 32x32 accumulator block (lane = output row, register 4g+e = column 8g + 4h + e) as bf16: the two
 // lane halves exchange 4-column groups (v_permlane32_swap) so every lane owns 8 consecutive columns -- two 16-byte stores
 // (columns 8h.. and 16+8h..) instead of four 8-byte ones.  Must be called by the whole wave; `ok` masks the store.
-__device__ __forceinline__ void store_acc_block(bf16* __restrict__ row_ptr, const f32x16& a, float scale, int h, bool ok) {
+// fp8 mode (uc2_attn_fwd_q / uc2_attn_bwd_q): the kernel also writes the e4m3 copy of its output that the next GEMM reads (ctx -> the
+// output projection, dqkv -> the q|k|v input gradient), with delayed scaling and the three cell groups of uc2_fp8_quant_delayed.
+// q == NULL: off.  The copy is taken from the bf16-ROUNDED values, like the stand-alone quantisation pass it replaces.
+struct AttnQ { uint8_t* q; const unsigned* prev; unsigned* next; unsigned* clear; float* scale_out; };
+// e4m3 bytes of the lane's eight values (+ their maximum)
+__device__ __forceinline__ uint2 attn_q8(const bf16x8& o, float qs, float& qmax, bool ok) {
+  float f[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = (float)o[e];
+  if (ok) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qmax = fmaxf(qmax, fabsf(f[e]));
+  }
+  return make_uint2(fp8_pack4_sat(f[0] * qs, f[1] * qs, f[2] * qs, f[3] * qs), fp8_pack4_sat(f[4] * qs, f[5] * qs, f[6] * qs, f[7] * qs));
+}
+// A lane owns columns 8h .. 8h+7 (piece 0) and 16+8h .. 16+8h+7 (piece 1) of a 32-column block of its row; the two lanes of a row
+// (h = 0 / 1) trade one piece each (v_permlane32_swap: piece 0 of the upper half <-> piece 1 of the lower half), so that each stores
+// ONE 16-byte run -- columns 0..15 (h = 0) or 16..31 (h = 1) -- instead of two 8-byte ones: half the partial-line write requests.
+__device__ __forceinline__ void attn_q8_store(uint2 k0, uint2 k1, uint8_t* __restrict__ row32, int h, bool ok) {
+  const auto sx = __builtin_amdgcn_permlane32_swap(k0.x, k1.x, false, false);
+  const auto sy = __builtin_amdgcn_permlane32_swap(k0.y, k1.y, false, false);
+  if (ok) *reinterpret_cast<uint4*>(row32 + 16 * h) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+}
+// the workgroup's max |value| -> one atomic into the role's next cell group (wm: NW floats of LDS nobody else uses any more)
+template <int NW>
+__device__ __forceinline__ void attn_q_amax(const AttnQ& aq, float qmax, float* wm, int tid) {
+  qmax = wave_max(qmax);
+  __syncthreads();
+  if ((tid & 63) == 0) wm[tid >> 6] = qmax;
+  __syncthreads();
+  if (tid == 0) {
+    float m = wm[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) m = fmaxf(m, wm[i]);
+    atomicMax(aq.next + (blockIdx.x & (UC2_AMAX_CELLS - 1)), __float_as_uint(m));
+  }
+}
+__device__ __forceinline__ void store_acc_block(bf16* __restrict__ row_ptr, const f32x16& a, float scale, int h, bool ok,
+                                                uint8_t* __restrict__ q_ptr = nullptr, float qs = 0.f, float* qmax = nullptr) {
+  uint2 qk[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     bf16x8 o;
@@ -105,10 +144,14 @@ __device__ __forceinline__ void store_acc_block(bf16* __restrict__ row_ptr, cons
       o[4 + e] = (bf16)__uint_as_float(sw[1]);
     }
     if (ok) *reinterpret_cast<bf16x8*>(row_ptr + 16 * k + 8 * h) = o;
+    if (q_ptr) qk[k] = attn_q8(o, qs, *qmax, ok);                       // (uniform branch)
   }
+  if (q_ptr) attn_q8_store(qk[0], qk[1], q_ptr, h, ok);
 }
 // store_acc_block for a workgroup-uniform base + one per-lane byte offset (row and lane half; L == Lp: no mask)
-__device__ __forceinline__ void store_acc_block_s(char* __restrict__ sbase, uint32_t voff, const f32x16& a) {
+__device__ __forceinline__ void store_acc_block_s(char* __restrict__ sbase, uint32_t voff, const f32x16& a,
+                                                  uint8_t* __restrict__ qbase = nullptr, float qs = 0.f, float* qmax = nullptr) {
+  uint2 qk[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     bf16x8 o;
@@ -119,6 +162,14 @@ __device__ __forceinline__ void store_acc_block_s(char* __restrict__ sbase, uint
       o[4 + e] = (bf16)__uint_as_float(sw[1]);
     }
     *reinterpret_cast<bf16x8*>(sbase + voff + 32 * k) = o;
+    if (qbase) qk[k] = attn_q8(o, qs, *qmax, true);
+  }
+  // (voff = row offset + 16 h bytes of bf16 = element offset 8 h: the e4m3 row starts at (voff >> 1) - 8 h, the lane's run at + 16 h)
+  if (qbase) {
+    const auto sx = __builtin_amdgcn_permlane32_swap(qk[0].x, qk[1].x, false, false);
+    const auto sy = __builtin_amdgcn_permlane32_swap(qk[0].y, qk[1].y, false, false);
+    const uint32_t hb = (voff & 16u) >> 1;                              // 8 h
+    *reinterpret_cast<uint4*>(qbase + (voff >> 1) - hb + 2 * hb) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
   }
 }
 // The same block set stored as WHOLE 128-byte lines (round 4): store_acc_block writes 16-byte pieces of 32 different rows per
@@ -223,15 +274,18 @@ __device__ __forceinline__ void store_tile_lean(char* dst, const bf16x8 (&r)[NCH
 //  prefetched into registers under the current head's compute -- at the bench size: 139.0-139.5 us against 138.2 for this one
 //  (scratch/ab_attn_libs.py, same box).  The forward is not bound by the latency of its per-workgroup chain; what moved it in
 //  round 3 was the access pattern (head-major buffers: 147 -> 121 us).  Not kept.)
-template <int D, int NW, bool FULL, bool DROP>
+template <int D, int NW, bool FULL, bool DROP, bool Q = false>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, const bf16* __restrict__ qkv,
                                                                 const float* __restrict__ mask, float scale,
                                                                 uint32_t thresh, float keep_scale,
                                                                 const uint64_t* __restrict__ seed_ptr,
                                                                 uint64_t seed_imm, bf16* __restrict__ ctx,
-                                                                float* __restrict__ lse, int ilv) {
+                                                                float* __restrict__ lse, int ilv, AttnQ aq) {
   constexpr int KS = D / 16, DB = D / 32, RS = D * 2 + 16, Lp = NW * 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const float qs = Q ? fp8_delayed_scale(aq.prev) : 0.f;
+  float qmax = 0.f;
+  if (Q && blockIdx.x == 0 && threadIdx.x < UC2_AMAX_CELLS) { aq.clear[threadIdx.x] = 0u; if (threadIdx.x == 0) *aq.scale_out = qs; }
   char* Ks = smem;
   char* Vs = smem + Lp * RS;
   float* Ms = reinterpret_cast<float*>(smem + 2 * Lp * RS);
@@ -332,6 +386,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
   const float inv = 1.0f / sum;
 
   bf16* out = ctx + ((size_t)b * L + q) * H + head * D;
+  uint8_t* out8 = Q ? aq.q + ((size_t)b * L + q) * H + head * D : nullptr;
 #pragma unroll
   for (int db = 0; db < DB; ++db) {
     f32x16 o;
@@ -343,9 +398,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
       for (int s = 0; s < 2; ++s)
         o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr(Vs, RS, 32 * kb + 16 * s, 32 * db, lane), pack8(sc[kb], s), o,
                                                     0, 0, 0);
-    store_acc_block(out + 32 * db, o, DROP ? inv * keep_scale : inv, h, FULL || q < L);
+    store_acc_block(out + 32 * db, o, DROP ? inv * keep_scale : inv, h, FULL || q < L, Q ? out8 + 32 * db : nullptr, qs, &qmax);
   }
   if (lse && (FULL || q < L) && h == 0) lse[(size_t)bh * L + q] = (mx + __builtin_amdgcn_logf(sum)) * 0.69314718056f;     // natural-log lse
+  if (Q) attn_q_amax<NW>(aq, qmax, Ms, tid);           // (Ms: the mask row, dead after the scores)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -360,7 +416,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_mfma_kernel(int L, int nh, c
 // wave and head, and no V tile in LDS.
 // (launch bound: 2 waves per SIMD = 256 registers per lane.  Unbounded, hipcc took 254 VGPRs + 96 AGPRs, which admits ONE
 // wave per SIMD: one 3-wave workgroup per CU with a SIMD idle -- rocprofv3 showed wave lifetimes of half the kernel.)
-template <int D, int NW, bool FULL, bool DROP>
+template <int D, int NW, bool FULL, bool DROP, bool Q = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh, const bf16* __restrict__ qkv,
                                                                 const float* __restrict__ mask, float scale,
                                                                 uint32_t thresh, float keep_scale,
@@ -369,8 +425,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
                                                                 const bf16* __restrict__ dctx,
                                                                 const float* __restrict__ lse,
                                                                 bf16* __restrict__ dqkv, float* __restrict__ dbias, int nbh, int hpw,
-                                                                int* __restrict__ queue, int ilv) {
+                                                                int* __restrict__ queue, int ilv, AttnQ aq) {
   constexpr int KS = D / 16, DB = D / 32, RS = D * 2 + 16, Lp = NW * 32;
+  const float qs = Q ? fp8_delayed_scale(aq.prev) : 0.f;
+  float qmax = 0.f;
+  if (Q && blockIdx.x == 0 && threadIdx.x < UC2_AMAX_CELLS) { aq.clear[threadIdx.x] = 0u; if (threadIdx.x == 0) *aq.scale_out = qs; }
   constexpr int RSD = Lp * 2 + 16;                     // dS^T image: [key][query] bf16
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qs = smem;
@@ -456,6 +515,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
   for (; bh < bh_end; ++bh) {
   const int b = bh / nh, head = bh - b * nh;
   bf16* dbase = dqkv + (size_t)b * L * ld + head * AM_HS(D, H);
+  uint8_t* qbase = Q ? aq.q + (size_t)b * L * ld + head * AM_HS(D, H) : nullptr;        // (the e4m3 copy of dqkv, same element offsets)
   if (!AM_BWD_PREFETCH) fetch(bh);                     // no register prefetch: the CU's other workgroup covers the latency
   if (AM_BWD_PREFETCH == 2) { fetch_tiles(bh, AM_BWD_EARLY, 4); fetch_rest(bh); }     // what the dQ phase of the previous head did not fetch
   // ---- registers -> LDS (the previous head's readers are past the barrier at the end of the loop body)
@@ -558,11 +618,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
         if (FULL) {
-          store_acc_block_s(reinterpret_cast<char*>(dbase + AM_WS(D, H) + 32 * db), roff_qkv, dk[db]);
-          store_acc_block_s(reinterpret_cast<char*>(dbase + 2 * AM_WS(D, H) + 32 * db), roff_qkv, dv[db]);
+          store_acc_block_s(reinterpret_cast<char*>(dbase + AM_WS(D, H) + 32 * db), roff_qkv, dk[db], Q ? qbase + AM_WS(D, H) + 32 * db : nullptr, qs, &qmax);
+          store_acc_block_s(reinterpret_cast<char*>(dbase + 2 * AM_WS(D, H) + 32 * db), roff_qkv, dv[db], Q ? qbase + 2 * AM_WS(D, H) + 32 * db : nullptr, qs, &qmax);
         } else {
-          store_acc_block(dbase + (size_t)r0 * ld + AM_WS(D, H) + 32 * db, dk[db], 1.0f, h, r0 < L);
-          store_acc_block(dbase + (size_t)r0 * ld + 2 * AM_WS(D, H) + 32 * db, dv[db], 1.0f, h, r0 < L);
+          store_acc_block(dbase + (size_t)r0 * ld + AM_WS(D, H) + 32 * db, dk[db], 1.0f, h, r0 < L,
+                          Q ? qbase + (size_t)r0 * ld + AM_WS(D, H) + 32 * db : nullptr, qs, &qmax);
+          store_acc_block(dbase + (size_t)r0 * ld + 2 * AM_WS(D, H) + 32 * db, dv[db], 1.0f, h, r0 < L,
+                          Q ? qbase + (size_t)r0 * ld + 2 * AM_WS(D, H) + 32 * db : nullptr, qs, &qmax);
         }
       }
     }
@@ -595,8 +657,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
     } else {
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
-        if (FULL) store_acc_block_s(reinterpret_cast<char*>(dbase + 32 * db), roff_qkv, dq[db]);
-        else store_acc_block(dbase + (size_t)r0 * ld + 32 * db, dq[db], 1.0f, h, r0 < L);
+        if (FULL) store_acc_block_s(reinterpret_cast<char*>(dbase + 32 * db), roff_qkv, dq[db], Q ? qbase + 32 * db : nullptr, qs, &qmax);
+        else store_acc_block(dbase + (size_t)r0 * ld + 32 * db, dq[db], 1.0f, h, r0 < L, Q ? qbase + (size_t)r0 * ld + 32 * db : nullptr, qs, &qmax);
       }
     }
   }
@@ -616,6 +678,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
   if (dbias) {
     for (int i = tid; i < 3 * H; i += NTHR) atomicAdd(dbias + i, Cs[i]);
   }
+  if (Q) attn_q_amax<NW>(aq, qmax, Ms, tid);           // (Ms: no head is in flight any more)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -625,28 +688,32 @@ extern "C" int uc2_attn_mfma_supported(int L, int D) { return (D == 32 || D == 6
 
 template <int D, int NW>
 static int launch_fwd(int B, int L, int nh, const void* qkv, const float* mask, float scale, float drop_p,
-                      const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse, int ilv, hipStream_t st) {
+                      const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse, int ilv, AttnQ aq, hipStream_t st) {
   constexpr int RS = D * 2 + 16, Lp = NW * 32;
   const size_t smem = 2 * Lp * RS + 2 * Lp * sizeof(float);
   const uint32_t th = drop_thresh(drop_p);
   const bool full = L == Lp && AM_LEAN;
-  auto kern = full ? (th ? attn_fwd_mfma_kernel<D, NW, true, true> : attn_fwd_mfma_kernel<D, NW, true, false>)
-                   : (th ? attn_fwd_mfma_kernel<D, NW, false, true> : attn_fwd_mfma_kernel<D, NW, false, false>);
+  auto kern = aq.q ? (full ? (th ? attn_fwd_mfma_kernel<D, NW, true, true, true> : attn_fwd_mfma_kernel<D, NW, true, false, true>)
+                           : (th ? attn_fwd_mfma_kernel<D, NW, false, true, true> : attn_fwd_mfma_kernel<D, NW, false, false, true>))
+                   : (full ? (th ? attn_fwd_mfma_kernel<D, NW, true, true> : attn_fwd_mfma_kernel<D, NW, true, false>)
+                           : (th ? attn_fwd_mfma_kernel<D, NW, false, true> : attn_fwd_mfma_kernel<D, NW, false, false>));
   hipLaunchKernelGGL(kern, dim3(B * nh), dim3(NW * 64), smem, st, L, nh, (const bf16*)qkv, mask, scale, th, 1.0f / (1.0f - drop_p),
-                     seed_ptr, seed_imm, (bf16*)ctx, lse, ilv);
+                     seed_ptr, seed_imm, (bf16*)ctx, lse, ilv, aq);
   UC2_LAUNCH_CHECK();
   return 0;
 }
 template <int D, int NW>
 static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, float scale, float drop_p,
                       const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx, const void* dctx,
-                      const float* lse, void* dqkv, float* dbias, int* queue, int ilv, hipStream_t st) {
+                      const float* lse, void* dqkv, float* dbias, int* queue, int ilv, AttnQ aq, hipStream_t st) {
   constexpr int RS = D * 2 + 16, Lp = NW * 32, RSD = Lp * 2 + 16;
   const size_t smem = 3 * Lp * RS + Lp * RSD + 5 * Lp * sizeof(float) + 16 + (dbias ? 3 * (size_t)nh * D * sizeof(float) : 0);
   const uint32_t th = drop_thresh(drop_p);
   const bool full = L == Lp && AM_LEAN;
-  auto kern = full ? (th ? attn_bwd_mfma_kernel<D, NW, true, true> : attn_bwd_mfma_kernel<D, NW, true, false>)
-                   : (th ? attn_bwd_mfma_kernel<D, NW, false, true> : attn_bwd_mfma_kernel<D, NW, false, false>);
+  auto kern = aq.q ? (full ? (th ? attn_bwd_mfma_kernel<D, NW, true, true, true> : attn_bwd_mfma_kernel<D, NW, true, false, true>)
+                           : (th ? attn_bwd_mfma_kernel<D, NW, false, true, true> : attn_bwd_mfma_kernel<D, NW, false, false, true>))
+                   : (full ? (th ? attn_bwd_mfma_kernel<D, NW, true, true> : attn_bwd_mfma_kernel<D, NW, true, false>)
+                           : (th ? attn_bwd_mfma_kernel<D, NW, false, true> : attn_bwd_mfma_kernel<D, NW, false, false>));
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { uc2_set_error(__FILE__, __LINE__, hipGetErrorString(e)); return (int)e; }
@@ -674,7 +741,7 @@ static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, 
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, L, nh, (const bf16*)qkv, mask, scale,
                      th, 1.0f / (1.0f - drop_p), seed_ptr, seed_imm, (const bf16*)ctx,
-                     (const bf16*)dctx, lse, (bf16*)dqkv, dbias, nbh, hpw, queue, ilv);
+                     (const bf16*)dctx, lse, (bf16*)dqkv, dbias, nbh, hpw, queue, ilv, aq);
   UC2_LAUNCH_CHECK();
   return 0;
 }
@@ -701,26 +768,60 @@ static int launch_bwd(int B, int L, int nh, const void* qkv, const float* mask, 
     }                                                                          \
   } while (0)
 
-extern "C" int uc2_attn_fwd_mfma(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
-                                 float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse,
-                                 int ilv, void* stream) {
+static int attn_fwd_mfma_impl(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
+                              float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse,
+                              int ilv, AttnQ aq, void* stream) {
   UC2_CHECK_ARG(uc2_attn_mfma_supported(L, D));
   UC2_CHECK_ARG(B >= 0 && nh >= 1 && drop_p >= 0.f && drop_p < 1.f);
   UC2_CHECK_ARG(((nh * D) % 8) == 0);
   if (B == 0) return 0;
   UC2_CHECK_ARG(qkv && ctx);
   hipStream_t st = (hipStream_t)stream;
-  AM_DISPATCH(launch_fwd, B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, lse, ilv, st);
+  AM_DISPATCH(launch_fwd, B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, lse, ilv, aq, st);
+}
+extern "C" int uc2_attn_fwd_mfma(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
+                                 float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse,
+                                 int ilv, void* stream) {
+  return attn_fwd_mfma_impl(B, L, nh, D, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, lse, ilv, AttnQ{}, stream);
+}
+// fp8 mode: uc2_attn_fwd (MFMA kernels, plain q|k|v layout) that also writes q_out = sat_e4m3(ctx * scale) [B L, nh D] for the output
+// projection's GEMM -- delayed scaling, cell groups as uc2_fp8_quant_delayed.  -2 (nothing launched) when the MFMA kernels do not
+// take (L, D).
+extern "C" int uc2_attn_fwd_q(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale, float drop_p,
+                              const uint64_t* seed_ptr, uint64_t seed_imm, void* ctx, float* lse, void* q_out,
+                              const void* amax_prev, void* amax_next, void* amax_clear, float* q_scale_out, void* stream) {
+  UC2_CHECK_ARG(q_out && amax_prev && amax_next && amax_clear && q_scale_out);
+  UC2_CHECK_ARG(amax_prev != amax_next && amax_next != amax_clear && amax_prev != amax_clear);
+  if (!uc2_attn_mfma_supported(L, D) || ((uintptr_t)q_out & 7)) return -2;
+  return attn_fwd_mfma_impl(B, L, nh, D, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, lse, 0,
+                            AttnQ{(uint8_t*)q_out, (const unsigned*)amax_prev, (unsigned*)amax_next, (unsigned*)amax_clear, q_scale_out}, stream);
 }
 
-extern "C" int uc2_attn_bwd_mfma(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
-                                 float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx,
-                                 const void* dctx, const float* lse, void* dqkv, float* dbias, int* queue, int ilv, void* stream) {
+static int attn_bwd_mfma_impl(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
+                              float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx,
+                              const void* dctx, const float* lse, void* dqkv, float* dbias, int* queue, int ilv, AttnQ aq, void* stream) {
   UC2_CHECK_ARG(uc2_attn_mfma_supported(L, D));
   UC2_CHECK_ARG(B >= 0 && nh >= 1 && drop_p >= 0.f && drop_p < 1.f);
   UC2_CHECK_ARG(((nh * D) % 8) == 0);
   if (B == 0) return 0;
   UC2_CHECK_ARG(qkv && ctx && dctx && lse && dqkv);
   hipStream_t st = (hipStream_t)stream;
-  AM_DISPATCH(launch_bwd, B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv, dbias, queue, ilv, st);
+  AM_DISPATCH(launch_bwd, B, L, nh, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv, dbias, queue, ilv, aq, st);
+}
+extern "C" int uc2_attn_bwd_mfma(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale,
+                                 float drop_p, const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx,
+                                 const void* dctx, const float* lse, void* dqkv, float* dbias, int* queue, int ilv, void* stream) {
+  return attn_bwd_mfma_impl(B, L, nh, D, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv, dbias, queue, ilv, AttnQ{}, stream);
+}
+// fp8 mode: uc2_attn_bwd (MFMA kernels, plain q|k|v layout) that also writes q_out = sat_e4m3(dqkv * scale) [B L, 3 nh D] for the
+// q|k|v projection's input-gradient GEMM.  -2 (nothing launched) when the MFMA kernels do not take (L, D).
+extern "C" int uc2_attn_bwd_q(int B, int L, int nh, int D, const void* qkv, const float* mask, float scale, float drop_p,
+                              const uint64_t* seed_ptr, uint64_t seed_imm, const void* ctx, const void* dctx, const float* lse,
+                              void* dqkv, float* dbias_qkv, int* queue, void* q_out, const void* amax_prev, void* amax_next,
+                              void* amax_clear, float* q_scale_out, void* stream) {
+  UC2_CHECK_ARG(q_out && amax_prev && amax_next && amax_clear && q_scale_out);
+  UC2_CHECK_ARG(amax_prev != amax_next && amax_next != amax_clear && amax_prev != amax_clear);
+  if (!uc2_attn_mfma_supported(L, D) || ((uintptr_t)q_out & 7) || AM_LINE_STORES) return -2;
+  return attn_bwd_mfma_impl(B, L, nh, D, qkv, mask, scale, drop_p, seed_ptr, seed_imm, ctx, dctx, lse, dqkv, dbias_qkv, queue, 0,
+                            AttnQ{(uint8_t*)q_out, (const unsigned*)amax_prev, (unsigned*)amax_next, (unsigned*)amax_clear, q_scale_out}, stream);
 }

@@ -119,6 +119,96 @@ extern "C" int uc2_fp8_quant_delayed(int dtype, int rows, int cols, const void* 
   return 0;
 }
 
+// ---- all e4m3 weight copies of a model in a few launches --------------------------------------------------------------------------
+// After every optimizer step each layer weight W [rows, cols] (fp32 master copy) is quantised again, in both orientations (W for
+// the forward GEMM, W^T k-contiguous for the input-gradient GEMM), with its own just-in-time power-of-two scale: per weight one
+// maximum pass and two quantisation passes = 288 launches of ~15 us per uc2-large step when issued one by one.  Here: per batch of up
+// to 32 weights one launch that clears the maxima, one that accumulates them (a workgroup per 64 x 64 tile of any of the weights)
+// and one that reads each tile once and writes it twice (row-major and, through LDS, transposed).
+#define UC2_FP8_WB_MAX 32
+struct Fp8WBatch {
+  int n; int tile0[UC2_FP8_WB_MAX + 1]; int rows[UC2_FP8_WB_MAX], cols[UC2_FP8_WB_MAX];
+  const float* src[UC2_FP8_WB_MAX]; uint8_t* out[UC2_FP8_WB_MAX]; uint8_t* out_t[UC2_FP8_WB_MAX]; unsigned* amax[UC2_FP8_WB_MAX];
+  float* scale[UC2_FP8_WB_MAX];
+};
+__device__ __forceinline__ int fp8_wb_item(const Fp8WBatch& b, int blk) {
+  int i = 0;
+  for (int k = 1; k < UC2_FP8_WB_MAX; ++k) if (k < b.n && blk >= b.tile0[k]) i = k;     // (uniform)
+  return i;
+}
+__global__ void fp8_wb_clear_kernel(Fp8WBatch b) { if ((int)threadIdx.x < b.n) *b.amax[threadIdx.x] = 0u; }
+__global__ __launch_bounds__(256) void fp8_wb_amax_kernel(Fp8WBatch b) {
+  __shared__ float wm[4];
+  const int i = fp8_wb_item(b, blockIdx.x), t = blockIdx.x - b.tile0[i];
+  const int tc = b.cols[i] / 64, tr_ = t / tc, tcx = t - tr_ * tc;
+  const float* s = b.src[i] + (size_t)(tr_ * 64) * b.cols[i] + tcx * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  float m = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float4 v = *reinterpret_cast<const float4*>(s + (size_t)(ty + 16 * r) * b.cols[i] + tx * 4);
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(b.amax[i], __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+}
+__global__ __launch_bounds__(256) void fp8_wb_quant_kernel(Fp8WBatch b) {
+  __shared__ float tile[64][65];
+  const int i = fp8_wb_item(b, blockIdx.x), t = blockIdx.x - b.tile0[i];
+  const int rows = b.rows[i], cols = b.cols[i];
+  const int tc = cols / 64, tr_ = t / tc, tcx = t - tr_ * tc;
+  const float sc = fp8_scale_of(*b.amax[i]);
+  if (t == 0 && threadIdx.x == 0) *b.scale[i] = sc;
+  const float* s = b.src[i] + (size_t)(tr_ * 64) * cols + tcx * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = ty + 16 * r;
+    const float4 v4 = *reinterpret_cast<const float4*>(s + (size_t)row * cols + tx * 4);
+    const float v[4] = {v4.x * sc, v4.y * sc, v4.z * sc, v4.w * sc};
+    if (b.out[i]) *reinterpret_cast<unsigned*>(b.out[i] + (size_t)(tr_ * 64 + row) * cols + tcx * 64 + tx * 4) = pack4_e4m3(v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[row][tx * 4 + e] = v[e];
+  }
+  if (!b.out_t[i]) return;                             // (uniform)
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int col = ty + 16 * r;                       // source column = row of W^T
+    const float v[4] = {tile[tx * 4][col], tile[tx * 4 + 1][col], tile[tx * 4 + 2][col], tile[tx * 4 + 3][col]};
+    *reinterpret_cast<unsigned*>(b.out_t[i] + (size_t)(tcx * 64 + col) * rows + tr_ * 64 + tx * 4) = pack4_e4m3(v);
+  }
+}
+struct Uc2Fp8WeightItem { const float* w; int rows, cols; void* out; void* out_t; void* amax; float* scale; };   // mirrors include/uc2_hip.h
+extern "C" int uc2_fp8_quant_weights_batch(int n, const Uc2Fp8WeightItem* items, void* stream) {
+  UC2_CHECK_ARG(n >= 0 && (n == 0 || items));
+  for (int k = 0; k < n; ++k) {
+    const Uc2Fp8WeightItem& it = items[k];
+    UC2_CHECK_ARG(it.w && it.amax && it.scale && (it.out || it.out_t) && it.rows > 0 && it.cols > 0);
+    if ((it.rows % 64) || (it.cols % 64) || ((uintptr_t)it.w & 15) || ((uintptr_t)it.out & 3) || ((uintptr_t)it.out_t & 3)) return -2;   // nothing launched
+  }
+  hipStream_t st = (hipStream_t)stream;
+  for (int i0 = 0; i0 < n; i0 += UC2_FP8_WB_MAX) {
+    Fp8WBatch b{};
+    b.n = n - i0 < UC2_FP8_WB_MAX ? n - i0 : UC2_FP8_WB_MAX;
+    int tiles = 0;
+    for (int k = 0; k < b.n; ++k) {
+      const Uc2Fp8WeightItem& it = items[i0 + k];
+      b.tile0[k] = tiles; b.rows[k] = it.rows; b.cols[k] = it.cols; b.src[k] = it.w; b.out[k] = (uint8_t*)it.out; b.out_t[k] = (uint8_t*)it.out_t;
+      b.amax[k] = (unsigned*)it.amax; b.scale[k] = it.scale;
+      tiles += (it.rows / 64) * (it.cols / 64);
+    }
+    b.tile0[b.n] = tiles;
+    hipLaunchKernelGGL(fp8_wb_clear_kernel, dim3(1), dim3(64), 0, st, b);
+    hipLaunchKernelGGL(fp8_wb_amax_kernel, dim3(tiles), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(fp8_wb_quant_kernel, dim3(tiles), dim3(256), 0, st, b);
+  }
+  UC2_LAUNCH_CHECK();
+  return 0;
+}
+
 // amax_bits must be zeroed by the caller (uc2_fp8_amax accumulates a maximum, so several tensors can share one scale)
 extern "C" int uc2_fp8_amax(int dtype, size_t n, const void* x, void* amax_bits, void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);

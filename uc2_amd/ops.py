@@ -629,14 +629,56 @@ def gemm_fp8_q(a8, sa, b8, sb, q_key, bias=None, epi=EPI_NONE, aux_in=None, aux_
     return out, (q8, scale)
 
 
+class _Fp8WeightItem(ctypes.Structure):          # Uc2Fp8WeightItem
+    _fields_ = [("w", ctypes.c_void_p), ("rows", ctypes.c_int), ("cols", ctypes.c_int), ("out", ctypes.c_void_p), ("out_t", ctypes.c_void_p),
+                ("amax", ctypes.c_void_p), ("scale", ctypes.c_void_p)]
+
+
+FP8_WEIGHT_BATCH = os.environ.get("UC2_FP8_WEIGHT_BATCH", "1") != "0"      # all e4m3 weight copies of a store in one call per optimizer step
+# attention kernels write the e4m3 copies of ctx / dqkv themselves (uc2_attn_fwd_q / uc2_attn_bwd_q): OFF -- measured break-even on
+# uc2-large (63.5-63.8 ms per step without, 63.9-64.4 with: the copies leave as 16-byte pieces of 32 different rows per wave
+# instruction, +59 us forward / +31 us backward per launch against a 53 us stand-alone pass; profiles/r05_experiments.md section 2)
+FP8_ATTN_FUSED = os.environ.get("UC2_FP8_ATTN_Q", "0") != "0"
+
+
 def _fp8_weight(st, p_first, p_last, shape, transpose):
-    """e4m3 copy (+ scale) of a weight span, re-quantised when the parameters change (AdamW step, load_state_dict)"""
+    """e4m3 copy (+ scale) of a weight span, re-quantised when the parameters change (AdamW step, load_state_dict).
+    Every span a forward / backward has asked for is remembered; when the store's version moves, ALL of them are quantised again,
+    both orientations, by one call (uc2_fp8_quant_weights_batch: 3 launches per 32 weights instead of 3 launches per weight)."""
     cache = st.__dict__.setdefault("_fp8_cache", {})
     key = (st.offsets[id(p_first)], st.offsets[id(p_last)], bool(transpose))
     hit = cache.get(key)
     if hit is not None and hit[2] == st.version:
         return hit[0], hit[1]
     w = st.span(st.data, p_first, p_last, shape)
+    rows, cols = w.shape
+    if FP8_WEIGHT_BATCH and rows % 64 == 0 and cols % 64 == 0 and w.is_contiguous() and not torch.cuda.is_current_stream_capturing():
+        spans = st.__dict__.setdefault("_fp8_spans", {})
+        skey = key[:2]
+        if skey not in spans:
+            dev = w.device
+            spans[skey] = (p_first, p_last, shape, torch.empty((rows, cols), dtype=torch.uint8, device=dev),
+                           torch.empty((cols, rows), dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int32, device=dev),
+                           torch.empty(1, dtype=torch.float32, device=dev))
+            todo = [skey]                                 # a span seen for the first time: quantise it alone, now
+        else:
+            todo = list(spans)                            # the parameters changed: every known span in one batch
+        arr = (_Fp8WeightItem * len(todo))()
+        for n_, k_ in enumerate(todo):
+            pf, pl, shp, w8_, wt8_, am_, sc_ = spans[k_]
+            wk = st.span(st.data, pf, pl, shp)
+            arr[n_] = _Fp8WeightItem(wk.data_ptr(), wk.shape[0], wk.shape[1], w8_.data_ptr(), wt8_.data_ptr(), am_.data_ptr(), sc_.data_ptr())
+        rc = _lib.load().uc2_fp8_quant_weights_batch(len(todo), arr, stream())
+        if rc == 0:
+            for k_ in todo:
+                _, _, _, w8_, wt8_, _, sc_ = spans[k_]
+                cache[(k_[0], k_[1], False)] = (w8_, sc_, st.version)
+                cache[(k_[0], k_[1], True)] = (wt8_, sc_, st.version)
+            hit = cache[key]
+            return hit[0], hit[1]
+        if rc != -2:
+            _lib.check(rc)
+        del spans[skey]
     akey = (key[0], key[1], "amax")
     ahit = cache.get(akey)
     if ahit is None or ahit[1] != st.version:                # one amax pass serves both orientations
@@ -1073,21 +1115,60 @@ def flush_ln_reductions(end_of_pass=True):
 ATTN_QKV_INTERLEAVED = 16          # include/uc2_hip.h UC2_ATTN_QKV_INTERLEAVED, OR-ed into `impl`
 
 
-def attn_fwd(qkv, mask2d, B, L, nh, D, drop_p=0.0, seed=None, seed_imm=0, impl=None, want_lse=True, ilv=False):
-    """ilv: qkv is [B L, nh, 3, D] (q|k|v of a head adjacent per token) instead of [B L, 3, nh, D]"""
+def _attn_q(q_key, qkv, impl, ilv):
+    """the delayed-scaling history of the tensor role `q_key` if the attention kernel may write the e4m3 copy itself"""
+    if q_key is None or not FP8_ATTN_FUSED or qkv.dtype != torch.bfloat16 or ilv or (ATTN_IMPL if impl is None else impl) == 1:
+        return None
+    return _fp8_hist_for(q_key, qkv.device)
+
+
+def attn_fwd(qkv, mask2d, B, L, nh, D, drop_p=0.0, seed=None, seed_imm=0, impl=None, want_lse=True, ilv=False, q_key=None):
+    """ilv: qkv is [B L, nh, 3, D] (q|k|v of a head adjacent per token) instead of [B L, 3, nh, D].
+    q_key (fp8 mode): the tensor role of ctx at the GEMM that reads it -- returns a third value, (ctx8, scale) written by the same
+    kernel (uc2_attn_fwd_q, delayed scaling) or None when that role has no history yet / the MFMA kernels do not take the shape"""
     H = nh * D
     ctx = torch.empty((B * L, H), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, nh, L), dtype=torch.float32, device=qkv.device) if want_lse else None
+    h = _attn_q(q_key, qkv, impl, ilv)
+    if h is not None:
+        c8 = torch.empty((B * L, H), dtype=torch.uint8, device=qkv.device)
+        scale = _fp8_cell(qkv.device)[1]
+        i_was = h[1]
+        prev, nxt, clr = _fp8_rotate(h)
+        with _Timed("attn_fwd", B * L * H * qkv.element_size() * 4 + B * nh * L * 4 + B * L * H):
+            rc = _lib.load().uc2_attn_fwd_q(B, L, nh, D, ptr(qkv), ptr(mask2d), 1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(lse),
+                                            ptr(c8), prev, nxt, clr, ptr(scale), stream())
+        if rc == 0:
+            return ctx, lse, (c8, scale)
+        h[1] = i_was
+        if rc != -2:
+            _lib.check(rc)
     with _Timed("attn_fwd", B * L * H * qkv.element_size() * 4 + B * nh * L * 4):       # q,k,v in; ctx, lse out
         call("uc2_attn_fwd", dt(qkv.dtype), (ATTN_IMPL if impl is None else impl) | (ATTN_QKV_INTERLEAVED if ilv else 0), B, L, nh, D, ptr(qkv), ptr(mask2d),
              1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(lse), stream())
-    return ctx, lse
+    return (ctx, lse, None) if q_key is not None else (ctx, lse)
 
 
-def attn_bwd(qkv, mask2d, ctx, dctx, lse, B, L, nh, D, drop_p=0.0, seed=None, seed_imm=0, impl=None, dbias=None, ilv=False):
+def attn_bwd(qkv, mask2d, ctx, dctx, lse, B, L, nh, D, drop_p=0.0, seed=None, seed_imm=0, impl=None, dbias=None, ilv=False, q_key=None):
     """dqkv; with dbias (fp32 [3H]) also dbias += column sums of dqkv = the gradient of the fused q|k|v bias (always in the
-    reference order q | k | v).  ilv: qkv and dqkv are in the head-interleaved layout (see attn_fwd)"""
+    reference order q | k | v).  ilv: qkv and dqkv are in the head-interleaved layout (see attn_fwd).
+    q_key (fp8 mode): returns (dqkv, (dqkv8, scale) or None), the e4m3 copy written by the same kernel (uc2_attn_bwd_q)"""
     dqkv = torch.empty_like(qkv)
+    h = _attn_q(q_key, qkv, impl, ilv)
+    if h is not None:
+        d8 = torch.empty(qkv.shape, dtype=torch.uint8, device=qkv.device)
+        scale = _fp8_cell(qkv.device)[1]
+        i_was = h[1]
+        prev, nxt, clr = _fp8_rotate(h)
+        with _Timed("attn_bwd", B * L * nh * D * qkv.element_size() * 8 + B * nh * L * 4 + B * L * nh * D * 3):
+            rc = _lib.load().uc2_attn_bwd_q(B, L, nh, D, ptr(qkv), ptr(mask2d), 1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(dctx),
+                                            ptr(lse), ptr(dqkv), ptr(dbias), ptr(_gemm_queue(qkv.device)[12:14]) if GEMM_QUEUE else None,
+                                            ptr(d8), prev, nxt, clr, ptr(scale), stream())
+        if rc == 0:
+            return dqkv, (d8, scale)
+        h[1] = i_was
+        if rc != -2:
+            _lib.check(rc)
     impl = (ATTN_IMPL if impl is None else impl) | (ATTN_QKV_INTERLEAVED if ilv else 0)
     with _Timed("attn_bwd", B * L * nh * D * qkv.element_size() * 8 + B * nh * L * 4):   # qkv, ctx, dctx, lse in; dqkv out
         if GEMM_QUEUE and qkv.dtype == torch.bfloat16:       # N > 1: the persistent kernels share the chip with the all-reduce kernels
@@ -1097,7 +1178,7 @@ def attn_bwd(qkv, mask2d, ctx, dctx, lse, B, L, nh, D, drop_p=0.0, seed=None, se
         else:
             call("uc2_attn_bwd", dt(qkv.dtype), impl, B, L, nh, D, ptr(qkv), ptr(mask2d),
                  1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(dbias), stream())
-    return dqkv
+    return (dqkv, None) if q_key is not None else dqkv
 
 
 def cast(x, dtype):
@@ -1307,8 +1388,9 @@ class BertLayerFn(torch.autograd.Function):
             w8_, sw_ = _fp8_weight(st, P["qw"], P["vw"], (3 * H, H), False)
             x8_, sx_ = xq if xq is not None else fp8_quantize_act(x2, kx)
             qkv = gemm_fp8(x8_, sx_, w8_, sw_, bias=bqkv)
-            ctxv, lse = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn)
-            o1 = linear_fwd_fp8(ctxv, st, P["ow"], P["ow"], (H, H), P["ob"].data, role="ctx", tag=FP8_TAG)
+            # (the attention kernel writes the e4m3 copy of ctx the output projection reads; same role key as the stand-alone pass)
+            ctxv, lse, cq = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn, q_key=(_st_uid(st), st.offsets[id(P["ow"])], "fwd", "ctx", FP8_TAG))
+            o1 = linear_fwd_fp8(ctxv, st, P["ow"], P["ow"], (H, H), P["ob"].data, role="ctx", tag=FP8_TAG, pre_q=cq)
             a, mean1, rstd1, aq = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, s_ln1, q_key=ka)
             # (the FFN1 GEMM's epilogue writes the e4m3 copy of u that FFN2 reads: no quantisation pass over [tokens, 4H])
             u, uq = linear_fwd_fp8(a, st, P["iw"], P["iw"], (I_, H), P["ib"].data, EPI_GELU, pre, flags=GEMM_AUX_DERIV, role="a", tag=FP8_TAG,
@@ -1452,7 +1534,12 @@ class BertLayerFn(torch.autograd.Function):
         # flushed with one global atomic per column and workgroup (the separate column-sum pass re-read dqkv: 97 us)
         # (the fp32-math kernels run the column-sum pass inside uc2_attn_bwd)
         ilv_plan = ctx.ilv_plan
-        dqkv = attn_bwd(qkv, mask2d, ctxv, dctx, lse, B, L, nh, D, p_a, seed, s_attn, dbias=dbqkv, ilv=ilv_plan is not None)
+        dqq = None
+        if fp8:
+            dqkv, dqq = attn_bwd(qkv, mask2d, ctxv, dctx, lse, B, L, nh, D, p_a, seed, s_attn, dbias=dbqkv,
+                                 q_key=(_st_uid(st), st.offsets[id(P["qw"])], "bwd", "dqkv", ctx.fp8_tag))
+        else:
+            dqkv = attn_bwd(qkv, mask2d, ctxv, dctx, lse, B, L, nh, D, p_a, seed, s_attn, dbias=dbqkv, ilv=ilv_plan is not None)
         if ilv_plan is not None:
             # dqkv is head-interleaved: dWqkv comes out with its rows in that order, the split-K reduction puts them back
             # (dqkv^T x on the two-stage ping-pong kernel: _ilv_wgrad_plan); the input gradient contracts over the interleaved
@@ -1474,7 +1561,7 @@ class BertLayerFn(torch.autograd.Function):
             dx = None
             if ctx.needs_input_grad[0]:
                 if fp8:
-                    dx = linear_dgrad_fp8(dqkv, st, P["qw"], P["vw"], (3 * H, H), EPI_ADD, dz1, role="dqkv", tag=ctx.fp8_tag).view(B, L, H)
+                    dx = linear_dgrad_fp8(dqkv, st, P["qw"], P["vw"], (3 * H, H), EPI_ADD, dz1, role="dqkv", tag=ctx.fp8_tag, pre_q=dqq).view(B, L, H)
                 else:
                     dx = linear_dgrad(dqkv, st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype), EPI_ADD, dz1,
                                       wt=WT(P["qw"], P["vw"], (3 * H, H))).view(B, L, H)
