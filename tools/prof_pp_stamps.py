@@ -18,7 +18,7 @@ def main():
     fl = kw.pop("flags", 0)
     # (the GELU kinds write their second stream to aux_out, which the stamps use: not available here)
     for _ in range(3):
-        ops.gemm(a, b, m, n, k, ta=ta, tb=tb, out=out, aux_out=dbg, variant=8, flags=fl | (256 << 8), **kw)      # UC2_GEMM_DIAG(256): stamps
+        ops.gemm(a, b, m, n, k, ta=ta, tb=tb, out=out, aux_out=dbg, variant=int(os.environ.get("VARIANT", "12")), flags=fl | (256 << 8), **kw)      # UC2_GEMM_DIAG(256): stamps
     torch.cuda.synchronize()
     t = dbg.cpu().numpy().astype("int64") & 0xffffffff
     for w in range(8):
