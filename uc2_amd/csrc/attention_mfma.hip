@@ -29,6 +29,9 @@
 // heads).  AM_HS = offset of head h inside a row / h, AM_WS = offset of k (and half that of v) from q.
 #define AM_HS(D, H) (ilv ? 3 * (D) : (D))
 #define AM_WS(D, H) (ilv ? (D) : (H))
+#ifndef AM_BWD_STRIDED
+#define AM_BWD_STRIDED 0     // backward, static partition: 1 = a workgroup walks heads chunk + j * (number of workgroups) instead of a contiguous range (measured: 18.55-18.65 ms per step against 18.22-18.60, same box -- no gain)
+#endif
 #ifndef AM_LINE_STORES
 #define AM_LINE_STORES 0     // backward: 1 = dQ / dK / dV leave as whole 128-byte lines through LDS (0: 16-byte pieces of 32 rows per
                              // instruction).  Measured (round 4, same box, bit-identical): 295.9 / 577.8 us with, 299.5 / 579.3 without at
@@ -466,8 +469,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
   for (;;) {
   if (chunk >= nchunk) break;
   if (queue && tid == 0) ticket = __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int bh_end = min(nbh, (chunk + 1) * hpw);
-  int bh = chunk * hpw;
+  // (AM_BWD_STRIDED, static partition only: the workgroup's heads are chunk, chunk + nchunk, chunk + 2 nchunk, ... instead of hpw
+  //  consecutive ones -- at any moment the resident workgroups then work on CONSECUTIVE (batch, head) pairs, i.e. all heads of a
+  //  token row are read at about the same time by neighbouring workgroups)
+  const bool strided = AM_BWD_STRIDED && !queue;
+  const int hstep = strided ? nchunk : 1;
+  const int bh_end = strided ? nbh : min(nbh, (chunk + 1) * hpw);
+  int bh = strided ? chunk : chunk * hpw;
   // ---- fetch of one head into registers: Q, K, dO, O tiles (NCH chunks each), this lane's V fragments, mask / lse of row tid
   bf16x8 rq[NCH], rk[NCH], rg[NCH], ro[NCH], rvf[KS];
   float rmask = 0.f, rlse = 0.f;
@@ -512,7 +520,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
   auto fetch = [&](int hd) __attribute__((always_inline)) { fetch_tiles(hd, 0, 4); fetch_rest(hd); };
   if (AM_BWD_PREFETCH == 1 && bh < bh_end) fetch(bh);
   if (AM_BWD_PREFETCH == 2 && bh < bh_end) fetch_tiles(bh, 0, AM_BWD_EARLY);      // (only the early tiles are carried around the loop)
-  for (; bh < bh_end; ++bh) {
+  for (; bh < bh_end; bh += hstep) {
   const int b = bh / nh, head = bh - b * nh;
   bf16* dbase = dqkv + (size_t)b * L * ld + head * AM_HS(D, H);
   uint8_t* qbase = Q ? aq.q + (size_t)b * L * ld + head * AM_HS(D, H) : nullptr;        // (the e4m3 copy of dqkv, same element offsets)
@@ -548,7 +556,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
 #pragma unroll
   for (int s = 0; s < KS; ++s) vf[s] = rvf[s];
   __syncthreads();
-  if (AM_BWD_PREFETCH == 1 && bh + 1 < bh_end) fetch(bh + 1);        // in flight during the compute below
+  if (AM_BWD_PREFETCH == 1 && bh + hstep < bh_end) fetch(bh + hstep);        // in flight during the compute below
 
   // ---------------- rows = query, cols = key (this wave's 32 keys) -> dK, dV, and dS^T into LDS ----------------
   f32x16 dk[DB], dv[DB];
@@ -636,7 +644,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_mfma_kernel(int L, int nh
   }
   // the next head's tiles: issued here, where dk / dv / the score tiles are dead (the prefetch then costs no register at the
   // kernel's peak); they are in flight during the dQ phase, its stores and the barrier, and the CU's other workgroup
-  if (AM_BWD_PREFETCH == 2 && bh + 1 < bh_end) fetch_tiles(bh + 1, 0, AM_BWD_EARLY);
+  if (AM_BWD_PREFETCH == 2 && bh + hstep < bh_end) fetch_tiles(bh + hstep, 0, AM_BWD_EARLY);
   // ---------------- dQ^T = K^T dS^T for this wave's 32 queries, contracted over all keys ----------------
   {
     f32x16 dq[DB];

@@ -1475,7 +1475,13 @@ class BertLayerFn(torch.autograd.Function):
             g.attn_queue = ptr(_gemm_queue(dev)[12:14]) if (GEMM_QUEUE and dtype == torch.bfloat16) else None
             g.plan_df = _plan_c(dtype, True, M, I_, H, EPI_DGELU, GEMM_AUX_DERIV)
             g.plan_di, g.plan_do, g.plan_dqkv = _plan_c(dtype, True, M, H, I_, EPI_ADD), _plan_c(dtype, True, M, H, H), _plan_c(dtype, True, M, H, 3 * H, EPI_ADD)
-            _lib.check(lib.uc2_bert_layer_bwd(ctypes.byref(ctx.native_c), ctypes.byref(g), stream()))
+            c = ctx.native_c
+            # (the parameter pointers are taken again here, like the per-kernel route does: a store re-created between forward and
+            #  backward -- set_compute_dtype, load_state_dict into a new arena -- must not leave this call with stale addresses)
+            c.wqkv = st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype).data_ptr()
+            c.wo, c.wi, c.wf = st.compute(P["ow"], dtype).data_ptr(), st.compute(P["iw"], dtype).data_ptr(), st.compute(P["fw"], dtype).data_ptr()
+            c.g1, c.g2 = P["g1"].data.data_ptr(), P["g2"].data.data_ptr()
+            _lib.check(lib.uc2_bert_layer_bwd(ctypes.byref(c), ctypes.byref(g), stream()))
             d_ = dt(dtype)
             _ln_bwd_second_stage(d_, M, H, ws2, G(P["g2"]), G(P["b2"]), G(P["fb"]), dev)
             _ln_bwd_second_stage(d_, M, H, ws1, G(P["g1"]), G(P["b1"]), G(P["ob"]), dev)
