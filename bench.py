@@ -457,6 +457,27 @@ def main():
         beat()
         return loss
 
+    def opt_step_pipelined(micro_batches, task):
+        """opt_step with the micro-batches software-pipelined over two streams (uc2_amd/utils/pipeline.py): forward i+1 beside
+        backward i; same micro-batches and sums, another enqueue order -- an opt-in the reference's loop does not use"""
+        from uc2_amd.utils.pipeline import accumulate
+
+        def one(b):
+            def f():
+                l = model(b, task, compute_loss=True)
+                l = l[0] if isinstance(l, tuple) else l
+                return l.mean()
+            return f
+        n = len(micro_batches)
+        losses = accumulate([one(b) for b in micro_batches], dev,
+                            before_backward=(lambda i: sync.arm() if i == n - 1 else None) if sync is not None else None)
+        grads = [p.grad.data for p in model.parameters() if p.requires_grad and p.grad is not None]
+        all_reduce_and_rescale_tensors(grads, float(1))
+        _, coef = clip_grad_norm_([p for p in model.parameters() if p.grad is not None], 5.0, fused=True)
+        opt.step(grad_scale=coef, zero_grad=True)
+        beat()
+        return losses[-1]
+
     def fence():
         torch.cuda.synchronize()
         if world > 1:
@@ -589,6 +610,15 @@ def main():
                                            / (world * PEAK_BF16_TFLOPS * 1e12), 4),
                 "note": "the reference's own regime: %d-pair micro-batches x %d accumulation micro-steps per optimizer step "
                         "(config/uc2_pretrain.json:17-19), all-reduce + clip + AdamW once per window" % (REF_MICRO, REF_ACCUM)}
+        for t in ("itm", "mlm"):
+            d3, _ = timed(lambda i: opt_step_pipelined(rb[t], t), max(w2, 2), k3)
+            workloads["reference_regime_%s_pipelined" % t] = {
+                "pairs_per_s": round(REF_MICRO * REF_ACCUM * world * k3 / d3, 1), "ms_per_optimizer_step": round(d3 / k3 * 1e3, 2),
+                "mfma_frac_encoder": round(REF_MICRO * REF_ACCUM * world * k3 / d3 * ENC_GFLOP_PER_PAIR * 1e9
+                                           / (world * PEAK_BF16_TFLOPS * 1e12), 4),
+                "note": "the same window with the micro-batches software-pipelined over two HIP streams (forward of micro-batch i+1 "
+                        "beside the backward of micro-batch i; uc2_amd/utils/pipeline.py) -- an opt-in: the reference's loop, as "
+                        "written, runs the sequential form above"}
         del rb
         # ---- BASELINE.json configs[2] as SURVEY.md 8(d) specifies it, on this GPU: the pretrain task mix itm : mlm : vmlm : tlm =
         # 9 : 12 : 9 : 3 (config/uc2_pretrain.json:72-76,100-102), one task per accumulation window like MetaLoader

@@ -1054,6 +1054,54 @@ def test_bf16_bench_path_trains_like_the_fp32_parity_mode():
         assert abs(a - c) <= 0.01 * abs(a) + 0.005, (s_, a, c)          # (measured: at most 0.3 % apart, step 3)
 
 
+@pytest.mark.parametrize("task", ["itm", "mlm"])
+def test_pipelined_accumulation_equals_the_sequential_loop(task):
+    """utils.pipeline.accumulate: three micro-batches with forward i+1 enqueued beside backward i on a second stream against the
+    plain loop -- the same gradients (dropout off: up to the fp32 order of the weight-gradient reductions; dropout on: it runs,
+    draws distinct masks per micro-batch, and leaves the current stream ordered behind both side streams)"""
+    from uc2_amd.utils.pipeline import accumulate
+    geom = dict(O.BASE, num_hidden_layers=2, vocab_size=2000)
+    batches = [to_dev(synth.make_batch(2000, 24, 40, 20, task=task, seed=90 + i, variable_len=(i == 1))) for i in range(3)]
+
+    def fns(model):
+        def one(b):
+            def f():
+                l = model(b, task, compute_loss=True)
+                l = l[0] if isinstance(l, tuple) else l
+                return l.mean()
+            return f
+        return [one(b) for b in batches]
+    for dtype in (torch.float32, torch.bfloat16):
+        model = build_pretrain(geom, dtype)
+        model.zero_grad()
+        ref_losses = []
+        for f in fns(model):
+            l = f()
+            l.backward()
+            ref_losses.append(float(l.detach()))
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        ref = OrderedDict((n, p.grad.detach().clone()) for n, p in model.named_parameters() if p.grad is not None)
+        model.zero_grad()
+        order = []
+        losses = accumulate(fns(model), before_backward=order.append)
+        got = OrderedDict((n, p.grad.detach().clone()) for n, p in model.named_parameters() if p.grad is not None)   # (current stream: ordered)
+        torch.cuda.synchronize()
+        assert order == [0, 1, 2] and [float(l) for l in losses] == ref_losses
+        assert set(got) == set(ref)
+        for n in ref:
+            assert rel_err(got[n], ref[n]) < (1e-6 if dtype == torch.float32 else 2e-5) or ref[n].norm() < 1e-7, n
+    # dropout on: runs, finite, and the three forwards did not share a mask
+    model = VLXLMRForPretraining(make_cfg(geom, drop=0.1), img_dim=2048, img_label_dim=1601)
+    synth.det_init_(model)
+    model.to(DEV).train()
+    set_compute_dtype(model, torch.bfloat16)
+    same = [to_dev(synth.make_batch(2000, 24, 40, 20, task=task, seed=90)) for _ in range(3)]
+    outs = accumulate([(lambda b=b: (lambda l: (l[0] if isinstance(l, tuple) else l).mean())(model(b, task, compute_loss=True))) for b in same])
+    vals = [float(v) for v in outs]
+    assert all(v == v for v in vals) and len(set(vals)) == 3, vals
+
+
 def test_adamw_bf16_shadow_and_fused_clip():
     model = build_pretrain(O.TINY, torch.bfloat16)
     opt = AdamW(param_groups(model, 0.01), lr=1e-3, betas=(0.9, 0.98))

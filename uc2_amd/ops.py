@@ -146,6 +146,7 @@ class _Rng:
     def __init__(self):
         self.state = {}
         self._scope = None
+        self._preset = None
 
     def buf(self, device):
         device = torch.device(device)
@@ -169,9 +170,20 @@ class _Rng:
         return self._fresh(device)
 
     def _fresh(self, device):
+        fifo = self._preset
+        if fifo:                                   # seeds drawn ahead on one stream (utils/pipeline.py: forwards on two streams)
+            return fifo.pop(0)
         b = self.buf(device)
         b.add_(0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFF)
         return b.clone()
+
+    def draw(self, device, n):
+        """n seed copies in the order n consecutive forwards would draw them (all on the current stream)"""
+        was, self._preset = self._preset, None
+        try:
+            return [self._fresh(device) for _ in range(n)]
+        finally:
+            self._preset = was
 
     def site(self, imm):
         """seed offset of one dropout site.  Outside a scope: `imm` itself (every caller has its own seed copy).  Inside: the
