@@ -82,7 +82,22 @@ def step_fwd_first():
     opt.step(grad_scale=coef, zero_grad=True)
 
 
-for name, step in (("sequential", step_seq), ("pipelined", step_pipe), ("fwd-first", step_fwd_first), ("sequential", step_seq), ("pipelined", step_pipe), ("fwd-first", step_fwd_first)):
+def step_unordered():
+    """TIMING ONLY (the gradient sums race): the three micro-batches on three streams with no order between their backward passes --
+    what a second gradient arena would make legal"""
+    n = len(rb)
+    for s in S3:
+        s.wait_stream(main)
+    for i in range(n):
+        with torch.cuda.stream(S3[i]):
+            fwd(rb[i]).backward()
+    for s in S3:
+        main.wait_stream(s)
+    _, coef = clip_grad_norm_([p for p in model.parameters() if p.grad is not None], 5.0, fused=True)
+    opt.step(grad_scale=coef, zero_grad=True)
+
+
+for name, step in (("sequential", step_seq), ("pipelined", step_pipe), ("unordered(timing only)", step_unordered), ("sequential", step_seq), ("pipelined", step_pipe), ("unordered(timing only)", step_unordered)):
     for _ in range(3): step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
