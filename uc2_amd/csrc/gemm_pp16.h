@@ -111,7 +111,7 @@ __device__ __forceinline__ float colsum_butterfly16(float (&v)[16], int lane) {
 #endif
 template <int EPI>
 __device__ __forceinline__ void pp16_epi_compute_q(const GemmArgs& p, const f32x4 (&acc)[2][4][4], PpOut& out, int mb0, int nb0,
-                                                   int lane, const TpAddr& ta) {
+                                                   int lane, const TpAddr& ta, bool aux0_in_lds = false) {
   const int g = lane >> 4, r15 = lane & 15, lr = lane >> 3, lc = lane & 7;
   constexpr bool has_aux = (EPI == EPI_DGELU || EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_DROPADD);
   constexpr bool two = (EPI == EPI_GELU || EPI == EPI_GELU_D);
@@ -138,6 +138,8 @@ __device__ __forceinline__ void pp16_epi_compute_q(const GemmArgs& p, const f32x
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
+          // (aux0_in_lds, wave-uniform: block (0, 0) is already on its way into the transposition buffer by LDS-DMA, gemm_pp16.hip)
+          if (hh == 0 && i == 0 && aux0_in_lds) continue;
           const int m = mb0 + hh * 64 + i * 32 + 8 * it + lr;
           ax[hh][i][it] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.aux_in) + (size_t)m * p.ldaux + nb0 + 8 * lc));
         }
@@ -148,8 +150,13 @@ __device__ __forceinline__ void pp16_epi_compute_q(const GemmArgs& p, const f32x
     for (int i = 0; i < 2; ++i) {
       bf16x4 axq[8];                                   // aux tile of this block, piece k
       if (has_aux) {
-        tp_write_o<0>(ta.line, ax[hh][i][0]); tp_write_o<1024>(ta.line, ax[hh][i][1]);
-        tp_write_o<2048>(ta.line, ax[hh][i][2]); tp_write_o<3072>(ta.line, ax[hh][i][3]);
+        if (hh == 0 && i == 0 && aux0_in_lds) {
+          // the 12 register loads above are the only VMEM operations younger than the four LDS-DMA writes (in-order return)
+          asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        } else {
+          tp_write_o<0>(ta.line, ax[hh][i][0]); tp_write_o<1024>(ta.line, ax[hh][i][1]);
+          tp_write_o<2048>(ta.line, ax[hh][i][2]); tp_write_o<3072>(ta.line, ax[hh][i][3]);
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const unsigned qa = q0 ^ (unsigned)((k & 3) << 5);
