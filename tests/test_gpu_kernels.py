@@ -271,43 +271,6 @@ def test_gemm_drop_residual_epilogue_and_layernorm_of_the_sum(M, N, K, p):
     assert rel_err(dx1.float(), torch.where(keep, sf.grad / (1 - p), torch.zeros_like(sf.grad))) < 6e-3
 
 
-@pytest.mark.parametrize("tb", [False, True])
-def test_gemm_aux_tile_first_block_by_lds_dma_is_bit_identical(tb):
-    """Large aux tensors (more than 32 M elements): the ping-pong kernel fetches the first 32-row block of every wave's residual /
-    gelu' tile by LDS-DMA during the two tail k-tiles (gemm_pp16.hip, PP16_AUX_DMA).  Same bits as the route with all sixteen
-    register loads (diagnostic flag 0x2000 switches the DMA off), for the residual-add, gelu'-multiply (+ column sums) and
-    dropout-residual epilogues, k-contiguous and k-strided weights, K = 128 (both k-tiles are tail k-tiles) and K = 768"""
-    M, N = 45056, 768
-    assert M * N > (32 << 20)
-    OFF = 0x20 << 8                                                     # UC2_GEMM_DIAG(0x20) -> p.atomic & 0x2000
-    for K in (128, 768):
-        a = rnd((M, K), 1, 0.5, torch.bfloat16)
-        w = rnd((K, N) if tb else (N, K), 2, 0.05, torch.bfloat16)
-        aux = rnd((M, N), 3, 1.0, torch.bfloat16)
-        ref = a.float() @ (w.float() if tb else w.float().t())
-        for epi, fl in ((ops.EPI_ADD, 0), (ops.EPI_DGELU, ops.GEMM_AUX_DERIV)):
-            outs = []
-            for extra in (0, OFF):
-                cs = torch.zeros(N, device=DEV) if epi == ops.EPI_DGELU else None
-                o = ops.gemm(a, w, M, N, K, tb=tb, epi=epi, aux_in=aux, aux_out=cs, variant=12, flags=fl | extra)
-                outs.append((o, cs))
-            assert torch.equal(outs[0][0], outs[1][0])
-            want = ref + aux.float() if epi == ops.EPI_ADD else ref * aux.float()
-            assert rel_err(outs[0][0].float(), want) < 6e-3
-            if epi == ops.EPI_DGELU:
-                assert rel_err(outs[0][1], outs[1][1]) < 1e-5 and rel_err(outs[0][1], want.sum(0)) < 5e-3
-        if not tb:
-            seed = torch.tensor([99], dtype=torch.int64, device=DEV)
-            was = ops._EXTRA_FLAGS
-            try:
-                s0 = ops.linear_drop_residual(a, w, None, aux, 0.1, seed, 5)
-                ops._EXTRA_FLAGS = OFF
-                s1 = ops.linear_drop_residual(a, w, None, aux, 0.1, seed, 5)
-            finally:
-                ops._EXTRA_FLAGS = was
-            assert torch.equal(s0, s1)
-
-
 def test_gemm_drop_residual_refuses_shapes_off_the_pingpong_kernel():
     x = rnd((200, 768), 1, 0.5, torch.bfloat16)
     w = rnd((768, 768), 2, 0.03, torch.bfloat16)

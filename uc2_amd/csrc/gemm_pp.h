@@ -406,10 +406,9 @@ template <> __device__ __forceinline__ void wait_vmcnt<5>() { asm volatile("s_wa
 template <> __device__ __forceinline__ void wait_vmcnt<7>() { asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vmcnt<19>() { asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vmcnt<31>() { asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); }
-// n in 0..12 (wave-uniform; a compile-time constant in the steady-state loop)
+// n in 0..8 (wave-uniform; a compile-time constant in the steady-state loop)
 __device__ __forceinline__ void pp_wait_small(int n) {
-  if (n >= 12) wait_vmcnt<12>(); else if (n == 11) wait_vmcnt<11>(); else if (n == 10) wait_vmcnt<10>(); else if (n == 9) wait_vmcnt<9>();
-  else if (n == 8) wait_vmcnt<8>(); else if (n == 7) wait_vmcnt<7>(); else if (n == 6) wait_vmcnt<6>(); else if (n == 5) wait_vmcnt<5>();
+  if (n >= 8) wait_vmcnt<8>(); else if (n == 7) wait_vmcnt<7>(); else if (n == 6) wait_vmcnt<6>(); else if (n == 5) wait_vmcnt<5>();
   else if (n == 4) wait_vmcnt<4>(); else if (n == 3) wait_vmcnt<3>(); else if (n == 2) wait_vmcnt<2>(); else if (n == 1) wait_vmcnt<1>();
   else wait_vmcnt<0>();
 }

@@ -110,8 +110,8 @@ __device__ __forceinline__ float colsum_butterfly16(float (&v)[16], int lane) {
 #define UC2_GELU_PACKED 1
 #endif
 template <int EPI>
-__device__ __forceinline__ void pp16_epi_compute_q(const GemmArgs& p, f32x4 (&acc)[2][4][4], PpOut& out, int mb0, int nb0,
-                                                   int lane, const TpAddr& ta, bool aux0_in_lds = false) {
+__device__ __forceinline__ void pp16_epi_compute_q(const GemmArgs& p, const f32x4 (&acc)[2][4][4], PpOut& out, int mb0, int nb0,
+                                                   int lane, const TpAddr& ta) {
   const int g = lane >> 4, r15 = lane & 15, lr = lane >> 3, lc = lane & 7;
   constexpr bool has_aux = (EPI == EPI_DGELU || EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_DROPADD);
   constexpr bool two = (EPI == EPI_GELU || EPI == EPI_GELU_D);
@@ -138,34 +138,9 @@ __device__ __forceinline__ void pp16_epi_compute_q(const GemmArgs& p, f32x4 (&ac
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-          // (aux0_in_lds, wave-uniform: block (0, 0) is already on its way into the transposition buffer by LDS-DMA, gemm_pp16.hip)
-          if (hh == 0 && i == 0 && aux0_in_lds) continue;
           const int m = mb0 + hh * 64 + i * 32 + 8 * it + lr;
           ax[hh][i][it] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.aux_in) + (size_t)m * p.ldaux + nb0 + 8 * lc));
         }
-  }
-  if (EPI == EPI_DROPADD && aux0_in_lds) {
-    // The dropout of the three blocks whose residual is still in flight, in place in their accumulators (dead after this epilogue):
-    // hashes, compares and selects that do not need the loads, done while the loads are on their way (block (0, 0), whose residual
-    // is already in LDS, keeps its dropout beside its add below).
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (hh == 0 && i == 0) continue;
-        const uint32_t hrow0 = drop_row_hash(dseed, (uint32_t)(mb0 + hh * 64 + i * 32 + r15));
-        const uint32_t hrow1 = drop_row_hash(dseed, (uint32_t)(mb0 + hh * 64 + i * 32 + 16 + r15));
-#pragma unroll
-        for (int mbl = 0; mbl < 2; ++mbl)
-#pragma unroll
-          for (int nb = 0; nb < 4; ++nb) {
-            bool kp[4];
-            drop_keep4(mbl ? hrow1 : hrow0, hcol[nb], p.drop_thresh, kp);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[hh][2 * i + mbl][nb][e] = kp[e] ? acc[hh][2 * i + mbl][nb][e] * p.drop_scale : 0.f;
-          }
-      }
-    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh)
@@ -173,13 +148,8 @@ __device__ __forceinline__ void pp16_epi_compute_q(const GemmArgs& p, f32x4 (&ac
     for (int i = 0; i < 2; ++i) {
       bf16x4 axq[8];                                   // aux tile of this block, piece k
       if (has_aux) {
-        if (hh == 0 && i == 0 && aux0_in_lds) {
-          // the 12 register loads above are the only VMEM operations younger than the four LDS-DMA writes (in-order return)
-          asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        } else {
-          tp_write_o<0>(ta.line, ax[hh][i][0]); tp_write_o<1024>(ta.line, ax[hh][i][1]);
-          tp_write_o<2048>(ta.line, ax[hh][i][2]); tp_write_o<3072>(ta.line, ax[hh][i][3]);
-        }
+        tp_write_o<0>(ta.line, ax[hh][i][0]); tp_write_o<1024>(ta.line, ax[hh][i][1]);
+        tp_write_o<2048>(ta.line, ax[hh][i][2]); tp_write_o<3072>(ta.line, ax[hh][i][3]);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const unsigned qa = q0 ^ (unsigned)((k & 3) << 5);
@@ -191,9 +161,7 @@ __device__ __forceinline__ void pp16_epi_compute_q(const GemmArgs& p, f32x4 (&ac
       }
       bf16x4 pre[8];
       uint32_t hrow[2];
-      // (aux0_in_lds: blocks other than (0, 0) had their dropout applied in place while their residual loads were in flight, below)
-      const bool dropped = EPI == EPI_DROPADD && aux0_in_lds && !(hh == 0 && i == 0);
-      if (EPI == EPI_DROPADD && !dropped) {
+      if (EPI == EPI_DROPADD) {
         hrow[0] = drop_row_hash(dseed, (uint32_t)(mb0 + hh * 64 + i * 32 + r15));
         hrow[1] = drop_row_hash(dseed, (uint32_t)(mb0 + hh * 64 + i * 32 + 16 + r15));
       }
@@ -250,14 +218,10 @@ __device__ __forceinline__ void pp16_epi_compute_q(const GemmArgs& p, f32x4 (&ac
             for (int e = 0; e < 4; ++e) v[e] += (float)axq[k][e];
           } else if (EPI == EPI_DROPADD) {
             // dropout(dense output) + residual, the mask of element (row, column) exactly as ln_fwd / ln_bwd derive it
-            if (!dropped) {
-              bool kp[4];
-              drop_keep4(hrow[mbl], hcol[nb], p.drop_thresh, kp);
+            bool kp[4];
+            drop_keep4(hrow[mbl], hcol[nb], p.drop_thresh, kp);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = kp[e] ? v[e] * p.drop_scale : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)axq[k][e];
+            for (int e = 0; e < 4; ++e) v[e] = (kp[e] ? v[e] * p.drop_scale : 0.f) + (float)axq[k][e];
           } else if (EPI == EPI_TANH) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = tanh_bf(v[e]);

@@ -15,9 +15,6 @@
 #define UC2_PP_DIAG 0            /* 1: build the main-loop diagnostics 0x100 / 0x200 (tools/bench_pp.py) */
 #endif
 
-#ifndef PP16_AUX_DMA
-#define PP16_AUX_DMA 1       // large aux tensors: the first 32-row block of the wave's aux_in tile arrives by LDS-DMA during the two tail k-tiles
-#endif
 #ifndef PP16_AUX_TOUCH
 #define PP16_AUX_TOUCH 1     // touch the lines of the epilogue's aux_in tile two k-tiles ahead (residual-add / gelu'-multiply / dGELU kinds)
 #endif
@@ -208,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
 #define PP_SYNC_L(ALLOW, P)                                                                                    \
   do {                                                                                                         \
     const int al_ = (ALLOW) > 4 ? 4 : ((ALLOW) < 0 ? 0 : (ALLOW));                                             \
-    pp_wait_small(2 * al_ - ((GA1 == 1 && al_ > ((4 - (P)) & 3)) ? 1 : 0) + ((TAIL && (!SW || (P) == 0)) ? aux_fly : 0)); \
+    pp_wait_small(2 * al_ - ((GA1 == 1 && al_ > ((4 - (P)) & 3)) ? 1 : 0));                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     __builtin_amdgcn_s_barrier();                                                                              \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
@@ -229,16 +226,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
   constexpr bool AUXK = TACC && (EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_DGELU || EPI == EPI_DROPADD);     // epilogues that read an aux_in tile
   unsigned aux_t0 = 0, aux_t1 = 0;                     // (PP16_AUX_TOUCH) destinations of the line-touching loads
   const bool aux_touch = AUXK && (size_t)p.M * (size_t)p.N <= ((size_t)32 << 20);
-  // Large aux tensors (the touch above would flood L2): the 4 KiB of aux_in that the epilogue consumes FIRST (32 rows x 128 bytes of
-  // this wave) are fetched by four LDS-DMA instructions straight into the wave's transposition buffer -- idle during the main loop --
-  // in the line layout the epilogue's own register loads + ds_writes would have produced.  The epilogue then starts on that block
-  // while the register loads of the other three are in flight (in-kernel stamps: ~4 000 cycles of exposed load latency per tile).
-  // They are issued right after unit f_a + 6 in phase f_a (phase 0 of the first tail k-tile).  The counted wait of phase f retires
-  // unit f + 2 and may leave the four younger units in flight: while that unit is OLDER than the four aux operations (f <= f_a + 4:
-  // the four phases of this k-tile and phase 0 of the last one) they are four more operations behind it (aux_fly); from phase
-  // f_a + 5 on the plain count already forces them complete, ~3 000 cycles after their issue.
-  const bool aux_dma = PP16_AUX_DMA && AUXK && !aux_touch && !(p.atomic & 0x2000);     // (diag 0x2000: off, for A/B runs)
-  int aux_fly = 0;
   auto body = [&](auto tail_c, auto swap_c, int kt) __attribute__((always_inline)) {
     constexpr bool TAIL = decltype(tail_c)::value;
     constexpr bool SW = decltype(swap_c)::value;       // k-tile parity: B0 lives in by, B1 in bx
@@ -268,15 +255,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
       asm volatile("global_load_dword %0, %1, off" : "=v"(aux_t1) : "v"(ap2) : "memory");
     }
     if ((!TAIL || f0 + 6 < nunits || more) && !dg_nodma) PP_ISSUE(2, nb);
-    if (PP16_AUX_DMA && AUXK && TAIL && !SW && aux_dma) {
-      // slot (row r = lane >> 3 of the 8-row group `it`, position s = lane & 7) of the line layout holds chunk s ^ r of the row
-      const int r8 = lane >> 3, ch = (lane & 7) ^ r8;
-      const char* ap = reinterpret_cast<const char*>(p.aux_in) + ((size_t)(m0 + wr * RW + r8) * p.ldaux + n0 + wc * 64 + 8 * ch) * 2;
-#pragma unroll
-      for (int it = 0; it < 4; ++it)
-        __builtin_amdgcn_global_load_lds((glb_void_p)(ap + (size_t)(8 * it) * p.ldaux * 2), (lds_void_p)(smem + 131072 + w * 4096 + it * 1024), 16, 0, 0);
-      aux_fly = 4;
-    }
     PP_SYNC_L((TAIL && !more) ? nunits - 3 - f0 : 4, 0);
     PP_MFMA(0, 0, b0);
     PP_SYNC_C();
@@ -436,8 +414,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
       asm volatile("" : "+v"(ln));
       {
         const TpAddr tpa = tp_addr(lds0 + 131072u + (unsigned)w * 4096u, ln);
-        pp16_epi_compute_q<EPI>(p, acc, out, em0, en0, ln, tpa, aux_fly != 0);
-        aux_fly = 0;
+        pp16_epi_compute_q<EPI>(p, acc, out, em0, en0, ln, tpa);
       }
       if (PP16_AUX_TOUCH && AUXK) asm volatile("" :: "v"(aux_t0), "v"(aux_t1));      // (the touch loads are older than the aux loads just consumed)
       // pin the finished outputs here: hipcc must not sink the aux-dependent arithmetic into the store sequence below
