@@ -212,6 +212,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     __builtin_amdgcn_s_setprio(1);                                                                             \
   } while (0)
+// the same with the tail's compile-time allowance: a next item keeps the window full (4 units), without one TAILC units may stay
+#define PP_SYNC_LT(TAILC, P)                                                                                   \
+  do {                                                                                                         \
+    if (!TAIL || more) pp_wait_small(8 - ((GA1 == 1 && 4 > ((4 - (P)) & 3)) ? 1 : 0));                         \
+    else pp_wait_small(2 * (TAILC) - ((GA1 == 1 && (TAILC) > ((4 - (P)) & 3)) ? 1 : 0));                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                                             \
+  } while (0)
 #define PP_SYNC_C()                                                                                            \
   do {                                                                                                         \
     __builtin_amdgcn_s_setprio(0);                                                                             \
@@ -232,9 +243,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
     bf16x8 (&b0)[4] = SW ? by : bx;
     bf16x8 (&b1)[4] = SW ? bx : by;
     const int nunits = 4 * nt;
+    // TAIL bodies are always the last two k-tiles of the item, in this order (nt is even): kt == nt - 2 (!SW) and kt == nt - 1 (SW).
+    // Everything the tail decides from kt / nt is therefore a compile-time constant of (TAIL, SW, phase) -- spelled out here because
+    // hipcc cannot know it: the run-time forms cost every tail phase ~30 scalar instructions and 7 branches in front of its barrier
+    // (16-21 instructions and no branch in a steady-state phase), two k-tiles of twelve in the K = 768 GEMMs.
+    //   issue of unit f + 6 + P:  exists in this item for the first two phases of the first tail k-tile only, else it is the next item's
+    //   units allowed in flight without a next item (nunits - 3 - P - f0, clamped to 0..4): 4 4 3 2 | 1 0 0 0
+    constexpr int TP = !TAIL ? 0 : (SW ? 2 : 1);
+    (void)nunits;
     constexpr int CB = SW ? 1 : 0;                     // this k-tile's buffer (the k-tile parity is the template argument)
     const int nb = (kt & 1) ^ 1;                       // buffer of k-tile kt+1 (kt+2 shares this tile's)
-    const int f0 = 4 * kt;                             // first phase; phase f issues unit f+6, may leave min(4, nunits-3-f) units in flight
+    // (first phase of this k-tile: f0 = 4 kt; phase f issues unit f + 6 and may leave min(4, nunits - 3 - f) units in flight)
     // Fragment reads are spread 8 / 4 / 8 / 4 over the phases: B0 of k-tile kt+1 is read in phase 3 of k-tile kt, into
     // the registers of B1 (dead after phase 2; the current B0 is still needed by this phase's MFMAs) -- the two B
     // register sets swap roles every k-tile.  The unit order of the stream is therefore B0, A0, B1, A1: every phase
@@ -254,14 +273,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
       asm volatile("global_load_dword %0, %1, off" : "=v"(aux_t0) : "v"(ap) : "memory");
       asm volatile("global_load_dword %0, %1, off" : "=v"(aux_t1) : "v"(ap2) : "memory");
     }
-    if ((!TAIL || f0 + 6 < nunits || more) && !dg_nodma) PP_ISSUE(2, nb);
-    PP_SYNC_L((TAIL && !more) ? nunits - 3 - f0 : 4, 0);
+    if ((TP != 2 || more) && !dg_nodma) PP_ISSUE(2, nb);
+    PP_SYNC_LT(TP == 2 ? 1 : 4, 0);
     PP_MFMA(0, 0, b0);
     PP_SYNC_C();
     // ---- phase 1
     if (!dg_nord || kt == 0) PP_READ_B(b1, CB, 2);
-    if ((!TAIL || f0 + 7 < nunits || more) && !dg_nodma) PP_ISSUE(3, nb);
-    PP_SYNC_L((TAIL && !more) ? nunits - 4 - f0 : 4, 1);
+    if ((TP != 2 || more) && !dg_nodma) PP_ISSUE(3, nb);
+    PP_SYNC_LT(TP == 2 ? 0 : 4, 1);
     PP_MFMA(0, 1, b1);
     PP_SYNC_C();
     // ---- phase 2
@@ -271,16 +290,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
     // instead of issuing 96 KiB of LDS-DMA and waiting for it with the matrix pipe idle.
     if (TAIL && !SW && more) setup(nxt);
     if (!dg_nord || kt == 0) PP_READ_A(CB, 3);
-    if ((!TAIL || f0 + 8 < nunits || more) && !dg_nodma) PP_ISSUE(1, nb ^ 1);
-    PP_SYNC_L((TAIL && !more) ? nunits - 5 - f0 : 4, 2);
+    if ((!TAIL || 4 * kt + 8 < nunits || more) && !dg_nodma) PP_ISSUE(1, nb ^ 1);
+    PP_SYNC_LT(TP == 2 ? 0 : 3, 2);
     PP_MFMA(1, 1, b1);
     PP_SYNC_C();
     // ---- phase 3
-    if ((!TAIL || kt + 1 < nt) && (!dg_nord || kt == 0)) PP_READ_B(b1, CB ^ 1, 1);
-    if ((!TAIL || f0 + 9 < nunits || more) && !dg_nodma) PP_ISSUE(0, nb ^ 1);
-    PP_SYNC_L((TAIL && !more) ? nunits - 6 - f0 : 4, 3);
+    if (TP != 2 && (!dg_nord || kt == 0)) PP_READ_B(b1, CB ^ 1, 1);
+    if ((!TAIL || 4 * kt + 9 < nunits || more) && !dg_nodma) PP_ISSUE(0, nb ^ 1);
+    PP_SYNC_LT(TP == 2 ? 0 : 2, 3);
     PP_MFMA(1, 0, b0);
-    if (TAIL && kt == nt - 1) {                        // wave row 1 has no partner barrier left after its last C section
+    if (TP == 2) {                                     // wave row 1 has no partner barrier left after its last C section
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       if (wr == 0) __builtin_amdgcn_s_barrier();
