@@ -1,4 +1,6 @@
-"""print the ping-pong GEMM kernel's in-kernel time stamps (not a test): workgroup 0, around its third item"""
+"""print the ping-pong GEMM kernel's in-kernel time stamps (not a test): workgroup 0, around its third item.
+Needs a diagnostic build of the library (cd uc2_amd/csrc && make EXTRA=-DUC2_PP_DIAG=1 after touching gemm_pp16.hip): the default
+build compiles the stamps out -- their six branches per item cost the K = 768 GEMMs ~1 % (profiles/r05_experiments.md)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -12,7 +12,9 @@
 #include "gemm_pp16.h"
 
 #ifndef UC2_PP_DIAG
-#define UC2_PP_DIAG 0            /* 1: build the main-loop diagnostics 0x100 / 0x200 (tools/bench_pp.py) */
+#define UC2_PP_DIAG 0            /* 1: build the main-loop diagnostics 0x100 / 0x200 (tools/bench_pp.py) and the time stamps 0x10000
+                                    (tools/prof_pp_stamps.py): make EXTRA=-DUC2_PP_DIAG=1.  Compiled out by default: every run-time
+                                    flag test is a scalar compare-and-branch per phase or per item */
 #endif
 
 #ifndef PP16_AUX_TOUCH
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
   };
 
   // diagnostic time stamps (p.atomic & 0x10000, p.aux_out = uint32 [8 waves][16]): workgroup 0, around its third item
-  const bool dbg = (p.atomic & 0x10000) && blockIdx.x == 0;
+  const bool dbg = UC2_PP_DIAG && (p.atomic & 0x10000) && blockIdx.x == 0;      // (diagnostic build only: six branches per item otherwise)
   unsigned ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int nitem_done = 0;
 #define PP_STAMP(I) do { if (dbg && nitem_done == 2) { unsigned long long t64_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t64_) :: "memory"); ts[I] = (unsigned)t64_; } } while (0)
@@ -381,7 +383,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
       nxt = item + item_step;
     }
     more = nxt < item_end;
-    if (!(p.atomic & 0x4000)) {                        // (diagnostic 0x4000: epilogue only)
+    if (!(p.atomic & 0x4000)) {                        // (diagnostic 0x4000: epilogue only; kept as a run-time test in every build:
+                                                       //  compiled out, hipcc moves code across the item loop and 15 of the 16
+                                                       //  instantiations spill 1-13 VGPRs)
       using F = std::false_type; using T = std::true_type;
       PP_READ_B(bx, 0, 1);                             // B0 of k-tile 0 (later k-tiles get theirs one phase ahead)
       int kt = 0;
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp16_kernel(GemmArgs p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
     };
-    const bool store = !(p.atomic & 0x800);            // (diagnostic 0x800: main loop only)
+    const bool store = !(p.atomic & 0x800);            // (diagnostic 0x800: main loop only; run-time in every build, see 0x4000)
     if (!store) {
       ticket_ready(); ticket_publish();
       younger = GKT;
