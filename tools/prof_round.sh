@@ -23,6 +23,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_2048 -- python3
 python3 scratch/regime_step.py itm 8 > $O/regime_plain.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_regime -- python3 scratch/regime_step.py itm 8 > $O/trace_regime.log 2>&1
 python3 tools/timeline.py $O/trace_regime adamw_kernel 4 > $O/regime_timeline.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_large_bf16 -- python3 scratch/large_step.py bf16 > $O/trace_large_bf16.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_large_fp8 -- python3 scratch/large_step.py fp8 > $O/trace_large_fp8.log 2>&1
 find $O -name "*kernel_trace.csv" -delete
 find $O -name "*counter_collection.csv" -delete
 find $O -name "*.db" -delete
