@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates uc2_amd/csrc/gemm_p2_body.inc: the fully unrolled work-item body of the one-wave-per-SIMD GEMM whose epilogue runs in
+"""Generates experiments/csrc/gemm_p2_body{1,2}.inc: the fully unrolled work-item body of the one-wave-per-SIMD GEMM whose epilogue runs in
 the MFMA gaps of the NEXT item (gemm_p2.hip, variant 14).  The schedule -- which fragment read, LDS-DMA piece, epilogue step, store
 and accumulator copy follows which MFMA -- and every counted s_waitcnt vmcnt(N) are decided HERE, in one place, and the counts are
 derived from the generated instruction order itself (simulate()), not by hand.
@@ -177,10 +177,10 @@ def emit(two_streams, path_tag):
 
 
 if __name__ == "__main__":
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     for two, name in ((False, "gemm_p2_body1.inc"), (True, "gemm_p2_body2.inc")):
         text, waits = emit(two, "one output stream" if not two else "two output streams")
-        with open(os.path.join(root, "uc2_amd", "csrc", name), "w") as f:
+        with open(os.path.join(root, "experiments", "csrc", name), "w") as f:
             f.write(text)
         print(name, len(text.splitlines()), "lines; waits (with stores, without):",
               " ".join("%s%d=%d/%d" % (w, kt, a, b) for (kt, w), (a, b) in sorted(waits.items())))

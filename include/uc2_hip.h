@@ -54,9 +54,9 @@ int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, const voi
  *              kernel (any shape/alignment); 0..12 = one specific kernel (0-2 LDS-DMA rings, 6/7 wave-specialised
  *              rings, 8 = persistent ping-pong 256x256 on v_mfma_f32_32x32x16_bf16, 9 = the same with 192-row tiles, 12 = the same
  *              schedule on v_mfma_f32_16x16x32_bf16 (less energy per flop: +4..8 % on X W^T and dY W; calls 12 does not cover run as 8);
- *              13 = the same tile on one wave per SIMD, 128 x 128 per wave (gemm_p1.hip; k-contiguous operands, calls it does not cover run as 12);
- *              10 and 11 were round-3 experiment kernels -- rolling epilogue, two phases per k-tile: scratch/kernels/ -- and are
- *              argument errors now, like every other number not listed).  A variant that does not
+ *              10, 11, 13 and 14 were experiment kernels -- rolling epilogue, two phases per k-tile, one wave per SIMD with and without
+ *              the epilogue in the next item's MFMA gaps: experiments/csrc/, built only by `make EXPERIMENTS=1` -- and are
+ *              argument errors in the shipped library, like every other number not listed).  A variant that does not
  *              support the shape falls back to the generic kernel.  uc2_amd/ops.py::gemm_plan picks it per shape.
  *   workspace  optional caller-owned device memory (>= split_k*M*N*4 bytes, 16-byte aligned) for split-K weight
  *              gradients: partial tiles are stored plainly and reduced in a second pass instead of fp32 atomics
@@ -98,7 +98,7 @@ int uc2_gemm_drop_residual(int M, int N, int K, const void* A, int lda, const vo
                            const void* residual, int ldres, float p_drop, const uint64_t* seed_ptr, uint64_t seed_imm, int flags,
                            void* queue, void* stream);
 /* Diagnostics: number of uc2_gemm / uc2_gemm_queued calls since load (or since the last reset != 0) that named a ping-pong kernel
- * (variant 8 / 9 / 12 / 13) and were run by another kernel because the shape, an alignment or the 32-bit staging-offset limit
+ * (variant 8 / 9 / 12) and were run by another kernel because the shape, an alignment or the 32-bit staging-offset limit
  * (an operand of 4 GiB or more) did not qualify.  bench.py prints it as config.gemm_fallbacks; nothing selects a kernel from it. */
 long long uc2_gemm_fallback_count(int reset);
 /* Grouped weight gradients: dW_i[n_out_i, n_in_i] (fp32) += dY_i[rows, n_out_i]^T X_i[rows, n_in_i] for up to four linear

@@ -361,10 +361,17 @@ bool uc2_gemm_pp_supported(int trans_a, int trans_b, int c_f32, int epi, int til
 void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st, int tile_rows);
 bool uc2_gemm_pp16_supported(const GemmArgs& p, int trans_a, int trans_b);                       // gemm_pp16.hip
 void uc2_gemm_pp16_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st);
-bool uc2_gemm_p1_supported(const GemmArgs& p, int trans_a, int trans_b);                         // gemm_p1.hip
+#if UC2_EXPERIMENTS        // `make EXPERIMENTS=1` only: variants 13 / 14 (experiments/csrc/gemm_p1.hip, gemm_p2.hip), measured slower than 12
+bool uc2_gemm_p1_supported(const GemmArgs& p, int trans_a, int trans_b);
 void uc2_gemm_p1_launch(const GemmArgs& p, hipStream_t st);
-bool uc2_gemm_p2_supported(const GemmArgs& p, int trans_a, int trans_b);                         // gemm_p2.hip
+bool uc2_gemm_p2_supported(const GemmArgs& p, int trans_a, int trans_b);
 void uc2_gemm_p2_launch(const GemmArgs& p, hipStream_t st);
+#else
+static inline bool uc2_gemm_p1_supported(const GemmArgs&, int, int) { return false; }
+static inline void uc2_gemm_p1_launch(const GemmArgs&, hipStream_t) {}
+static inline bool uc2_gemm_p2_supported(const GemmArgs&, int, int) { return false; }
+static inline void uc2_gemm_p2_launch(const GemmArgs&, hipStream_t) {}
+#endif
 void uc2_splitk_reduce(const GemmArgs& p, hipStream_t st);                                        // gemm.hip
 
 // ------------------------------------------------------------------------------------------------------
@@ -443,10 +450,10 @@ static int fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st)
   int variant = p.variant;                           // per call (uc2_gemm's `variant` argument), never process state
   if (variant == 99) return 0;                       // caller asked for the generic kernel
   // (variants 10 = rolling epilogue and 11 = two phases per k-tile were measured in round 3, never selected by a plan, and
-  //  live under scratch/kernels/ with their result table in DESIGN.md; uc2_gemm rejects the numbers)
+  //  live under experiments/csrc/ with their result table in profiles/HISTORY.md; uc2_gemm rejects the numbers)
   const bool want_pp16 = variant == 12;              // ping-pong kernel on the 16x16x32 MFMA (gemm_pp16.hip)
-  const bool want_p1 = variant == 13;                // one wave per SIMD, 128 x 128 per wave (gemm_p1.hip): falls back to variant 12
-  const bool want_p2 = variant == 14;                // ... with the epilogue in the next item's MFMA gaps (gemm_p2.hip): falls back to 12
+  const bool want_p1 = variant == 13;                // experiments build only (uc2_gemm rejects 13 / 14 otherwise): one wave per SIMD, falls back to 12
+  const bool want_p2 = variant == 14;                // ... with the epilogue in the next item's MFMA gaps: falls back to 12
   if (want_pp16 || want_p1 || want_p2) variant = 8;
   if (variant == 8 || variant == 9) {
     // ping-pong kernel: whole 256x256 (variant 9: 192x256) tiles, >= 2 k-tiles per split, and (bf16 output) an epilogue

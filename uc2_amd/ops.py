@@ -47,8 +47,6 @@ class GemmTimer:
         tacc = b(not atomic)
         if variant == 12:
             return "gemm_bf16_pp16_kernel<%s, %s, true, %d, 2>" % (b(ta), b(tb), epi)
-        if variant == 13:
-            return "gemm_bf16_p1_kernel<%d>" % epi
         if variant in (8, 9):
             return "gemm_bf16_pp_kernel<%s, %s, %s, %d, %d>" % (b(ta), b(tb), b(not atomic), epi, 2 if variant == 8 else 1)
         if variant == 99:
@@ -293,7 +291,7 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
         else:
             call("uc2_gemm_splitk_reduce", M, N, ptr(out), ldc, split_k, int(accumulate), ptr(ws), ws.numel(), stream())
     if e0 is not None:
-        if variant in (8, 9, 12, 13):  # ping-pong kernels: transposed accumulators unless fp32 atomics; the epilogue kind is a template argument
+        if variant in (8, 9, 12):  # ping-pong kernels: transposed accumulators unless fp32 atomics; the epilogue kind is a template argument
             epi_t = int(epi) + 4 if (flags & GEMM_AUX_DERIV and epi in (EPI_GELU, EPI_DGELU)) else int(epi)   # EPI_GELU_D = 5, EPI_MUL = 6
             key = (bool(ta), bool(tb), variant, bool(c_f32 and not two_stage), epi_t)
         else:
