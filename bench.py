@@ -192,6 +192,43 @@ def synth_batch(B, task, seed, device, T_TXT=T_TXT, N_REG=N_REG):
     return batch
 
 
+def synth_batch_varlen(B, task, seed, device, txt_range=(10, 60), reg_range=(10, 36), sample_size=None):
+    """variable-length synthetic batch laid out as the reference's collates build it (data/itm.py:205-232, :615-643;
+    data/data.py:360-384): per pair txt_len ~ U[txt_range], num_bb ~ U[reg_range]; input_ids padded with 1
+    (<pad>) to the batch's longest text, region features zero-padded to the batch's largest box count, attn_masks = 1 on the
+    first txt_len + num_bb positions, gather_index = arange(max(txt_len + num_bb)) with the regions of pair i read from offset
+    max_txt_len (get_gather_index), so every sequence is [real text | real regions | junk, masked as keys only].  Returns
+    (batch, valid_tokens, padded_tokens).  itm (targets) / itm-rank (sample_size) only."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    tl = torch.randint(txt_range[0], txt_range[1] + 1, (B,), generator=g, device=device)
+    nbb = torch.randint(reg_range[0], reg_range[1] + 1, (B,), generator=g, device=device)
+    T, R = int(tl.max().item()), int(nbb.max().item())
+    L = int((tl + nbb).max().item())
+    t_idx = torch.arange(T, device=device).unsqueeze(0)
+    ids = torch.randint(5, BASE["vocab_size"], (B, T), generator=g, device=device)
+    ids[:, 0] = 0
+    ids = torch.where(t_idx == (tl - 1).unsqueeze(1), torch.full_like(ids, 2), ids)
+    ids = torch.where(t_idx < tl.unsqueeze(1), ids, torch.ones_like(ids))
+    r_ok = (torch.arange(R, device=device).unsqueeze(0) < nbb.unsqueeze(1)).unsqueeze(-1)
+    feat = torch.randn(B, R, IMG_DIM, generator=g, device=device) * r_ok
+    pos = torch.rand(B, R, 7, generator=g, device=device)
+    pos[..., 6] = pos[..., 4] * pos[..., 5]
+    pos = pos * r_ok
+    l_idx = torch.arange(L, device=device).unsqueeze(0)
+    attn = (l_idx < (tl + nbb).unsqueeze(1)).long()
+    in_reg = (l_idx >= tl.unsqueeze(1)) & (l_idx < (tl + nbb).unsqueeze(1))
+    gather = torch.where(in_reg, T + l_idx - tl.unsqueeze(1), l_idx.expand(B, L)).contiguous()
+    batch = dict(input_ids=ids, position_ids=torch.arange(T, device=device).unsqueeze(0), img_feat=feat, img_pos_feat=pos,
+                 attn_masks=attn, gather_index=gather)
+    if sample_size is not None:
+        batch["sample_size"] = sample_size
+    else:
+        batch["targets"] = (torch.rand(B, generator=g, device=device) < 0.5).long()
+    return batch, int((tl + nbb).sum().item()), B * L
+
+
 def cpu_baseline(B, layers):
     """the CPU oracle on all host cores, B pairs, fwd+bwd of the same synthetic workload, one
     warm-up + median of 3 timed iterations, ITM-only and MLM-only steps; bounded (an iteration slower than 25 s is
@@ -321,14 +358,52 @@ def other_configs(dev, timed, steps):
         "note": "BASELINE.json configs[3] on one GPU: score 1 positive + %d candidates without autograd state (eval mode), keep "
                 "the %d hardest on the device, forward + backward + clip + AdamW on those %d pairs (triplet loss)"
                 % (npool - 1, hard, hard + 1)}
-    del model, opt, hb
+    del opt, hb
+    # ---- BASELINE.json configs[3] as SURVEY.md 8(d) writes it: the itm.py finetune step.  40 triplets (1 positive + 2 negatives:
+    # negative_size 1, data/itm.py:525-541) -> 120 sequences per micro-batch through VLXLMRForImageTextRetrieval.forward
+    # (model/itm.py:28-55: encoder -> pooler -> rank_output -> sigmoid -> triplet margin 0.2), 8 accumulation micro-steps per optimizer
+    # step, MSCOCO-like box counts num_bb in [10, 100], text <= 60 tokens, clip 2.0, weight decay 0, lr 5e-5
+    # (config/uc2_mscoco_itm.json:10-31); the reference's loop as written (itm.py:253-358).
+    from uc2_amd import ops as _ops
+    from uc2_amd.model.itm import VLXLMRForImageTextRetrieval
+    rank_forward = VLXLMRForImageTextRetrieval.forward     # the same parameters, the plain retrieval forward (no in-model mining)
+    opt = AdamW(param_groups(model, 0.0), lr=5e-5, betas=(0.9, 0.98))
+    n_trip, n_acc = 40, 8
+    rk, rstat = [], []
+    for j in range(2 * n_acc):
+        b_, valid_, padded_ = synth_batch_varlen(3 * n_trip, "itm", 500 + j, dev, reg_range=(10, 100), sample_size=3)
+        rk.append(b_)
+        rstat.append((valid_, padded_))
+
+    def rank_step(i):
+        loss = None
+        for j in range(n_acc):
+            loss = rank_forward(model, rk[(i % 2) * n_acc + j], compute_loss=True)
+            loss.mean().backward()
+        _, coef = clip_grad_norm_([p for p in model.parameters() if p.grad is not None], 2.0, fused=True)
+        opt.step(grad_scale=coef, zero_grad=True)
+        return loss
+    _ops.gemm_fallbacks(reset=True)
+    ksteps = max(steps, 6)
+    d, _ = timed(rank_step, 2, ksteps)
+    out["itm_rank_finetune"] = {
+        "triplets_per_s": round(n_trip * n_acc * ksteps / d, 1), "sequences_per_s": round(3 * n_trip * n_acc * ksteps / d, 1),
+        "ms_per_optimizer_step": round(d / ksteps * 1e3, 2), "triplets_per_micro_batch": n_trip, "sequences_per_micro_batch": 3 * n_trip,
+        "accumulation_steps": n_acc, "num_bb_range": [10, 100], "txt_len_range": [10, 60],
+        "padded_tokens_per_micro_batch": [p_ for _, p_ in rstat[:n_acc]],
+        "padding_fraction": round(1.0 - sum(v for v, _ in rstat) / float(sum(p_ for _, p_ in rstat)), 4),
+        "gemm_fallbacks": _ops.gemm_fallbacks(), "accumulation_overlap_passes": sum(s_.passes for s_ in _ops._accum.values()),
+        "note": "BASELINE.json configs[3] as config/uc2_mscoco_itm.json:10-31 runs it: 40 triplets -> 120 sequences per micro-batch "
+                "x 8 accumulation steps through VLXLMRForImageTextRetrieval.forward (triplet margin 0.2), num_bb in [10,100], clip 2.0, "
+                "weight decay 0, AdamW once per window; ragged token counts (120 x max(len) per micro-batch, a new shape every time)"}
+    del model, opt, rk
     torch.cuda.empty_cache()
 
     # ---- uc2-large (configs[4]): 24L / 1024H / 16 heads / 4096, 80 tokens + 50 regions (L = 130), MLM-type step, bf16 and fp8
     large = dict(BASE, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
                  hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, max_position_embeddings=514,
                  type_vocab_size=2, initializer_range=0.02, layer_norm_eps=1e-5, pad_token_id=1)
-    TL, RL, BL = 80, 50, 256
+    TL, RL, BL = 80, 50, 1024          # 133 120 tokens per step (round 5 benched 256 pairs = 33 280 tokens, 4 steps: VERDICT r5 weak #7)
     LL = TL + RL
     gflop = (24 * 1024 * 1024 + 4 * LL * 1024) * LL * 24 * 3 / 1e9
     torch.manual_seed(2)
@@ -348,16 +423,19 @@ def other_configs(dev, timed, steps):
         return loss
     for tag in ("bf16", "fp8"):
         uc2_amd.set_fp8(model, tag == "fp8")
-        d, loss = timed(lg_step, 2, steps)
+        lsteps = max(steps, 10)
+        d, loss = timed(lg_step, 3, lsteps)
         lv = float(loss.mean().item())
         assert lv == lv, "uc2-large %s: loss is NaN" % tag
         out["uc2_large_" + tag] = {
-            "pairs_per_s": round(BL * steps / d, 1), "ms_per_step": round(d / steps * 1e3, 2), "pairs_per_step": BL, "seq_len": LL,
-            "mfma_frac_encoder_vs_bf16_peak": round(BL * steps / d * gflop * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "pairs_per_s": round(BL * lsteps / d, 1), "ms_per_step": round(d / lsteps * 1e3, 2), "pairs_per_step": BL, "seq_len": LL,
+            "steps": lsteps,
+            "mfma_frac_encoder_vs_bf16_peak": round(BL * lsteps / d * gflop * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
             "note": "BASELINE.json configs[4] geometry on one GPU (24L/1024H/16 heads/4096, 80 tokens + 50 regions), ITM training "
                     "step incl. clip + AdamW; %s" % ("bf16 GEMMs" if tag == "bf16" else
                     "e4m3 forward and input-gradient GEMMs on the ping-pong kernel (gemm_pp8.hip; per-tensor power-of-two scales, delayed per task: one-pass "
                     "quantisation, fused into the LayerNorm kernels and the FFN GEMM epilogues), bf16 weight gradients")}
+    out["uc2_large_fp8_over_bf16"] = round(out["uc2_large_fp8"]["pairs_per_s"] / out["uc2_large_bf16"]["pairs_per_s"], 4)
     del model, opt, lb
     torch.cuda.empty_cache()
     return out
@@ -457,27 +535,6 @@ def main():
         beat()
         return loss
 
-    def opt_step_pipelined(micro_batches, task):
-        """opt_step with the micro-batches software-pipelined over two streams (uc2_amd/utils/pipeline.py): forward i+1 beside
-        backward i; same micro-batches and sums, another enqueue order -- an opt-in the reference's loop does not use"""
-        from uc2_amd.utils.pipeline import accumulate
-
-        def one(b):
-            def f():
-                l = model(b, task, compute_loss=True)
-                l = l[0] if isinstance(l, tuple) else l
-                return l.mean()
-            return f
-        n = len(micro_batches)
-        losses = accumulate([one(b) for b in micro_batches], dev,
-                            before_backward=(lambda i: sync.arm() if i == n - 1 else None) if sync is not None else None)
-        grads = [p.grad.data for p in model.parameters() if p.requires_grad and p.grad is not None]
-        all_reduce_and_rescale_tensors(grads, float(1))
-        _, coef = clip_grad_norm_([p for p in model.parameters() if p.grad is not None], 5.0, fused=True)
-        opt.step(grad_scale=coef, zero_grad=True)
-        beat()
-        return losses[-1]
-
     def fence():
         torch.cuda.synchronize()
         if world > 1:
@@ -509,6 +566,10 @@ def main():
     free_b, _tot_b = torch.cuda.mem_get_info(dev)
     need_b = (31.5 * a.batch / 1024.0 * (a.layers / 12.0) + 12.0) * 2 ** 30     # saved activations (30.7 GB per 1024 pairs at 12 layers) + model, optimizer, workspaces
     if free_b < need_b:
+        if world > 1:
+            # SystemExit bypasses sys.excepthook: without this the exit handler would ncclCommDestroy while the peers (whose own
+            # check passed) sit in the warm-up collective -- abort the communicator instead (NativeComm.mark_failed)
+            NativeComm.mark_failed()
         raise SystemExit("bench.py: --batch %d needs about %.0f GB of free HBM on %s, %.0f GB are free (another process on the device?); "
                          "use a smaller --batch" % (a.batch, need_b / 2 ** 30, dev, free_b / 2 ** 30))
     batches = [synth_batch(a.batch, a.task, 1000 * (rank + 1) + i, dev) for i in range(2)]
@@ -540,7 +601,20 @@ def main():
     dev_allocs = int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0))
     dev_alloc_mb = (ms1.get("reserved_bytes.all.peak", 0) - ms0.get("reserved_bytes.all.current", 0)) / 2 ** 20
     ops.GEMM_TIMER, ops.HBM_TIMER = None, None
+    # per-rank record of the timed region (the first SCALE run must be diagnosable from the one line rank 0 prints): each rank's own
+    # wall time per step, the exposed part of its all-reduce, and what the exposed tail carried
+    tail_elems = 0
+    bucket_bytes = (4 * sum(p.numel() for p in sync.layers[0].parameters())) if sync is not None else 0
+    if st.grad is not None and sync is not None:
+        lay = sum(sum(p.numel() for p in l.parameters()) for l in sync.layers)
+        tail_elems = sum(p.numel() for p in model.parameters() if p.grad is not None) - lay
+    per_rank = [{"rank": rank, "ms_per_step": round(dt / a.steps * 1e3, 3), "comm_exposed_ms_per_step": round(comm_exposed_ms, 3),
+                 "device": torch.cuda.get_device_name(dev), "gemm_fallbacks": gemm_fallbacks,
+                 "device_allocations_in_timed_region": dev_allocs}]
     if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -599,6 +673,29 @@ def main():
                 "mfma_frac_encoder": round(v6 * ENC_GFLOP_PER_PAIR * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
                 "note": hb_note}
             del hb
+        # ---- the headline step on VARIABLE-LENGTH pairs: text 10-60 tokens, 10-36 regions, the padding / key-mask /
+        # gather contract of the reference's collates -- timed, not only parity-tested.  Same pairs per step;
+        # the encoder runs on B x max(txt_len + num_bb) positions like the reference, padded positions are masked as keys only.
+        vb, vstat = [], []
+        for i in range(2):
+            b_, valid_, padded_ = synth_batch_varlen(a.batch, a.task, 8000 * (rank + 1) + i, dev)
+            vb.append(b_)
+            vstat.append((valid_, padded_, b_["attn_masks"].size(1)))
+        ops.gemm_fallbacks(reset=True)
+        d7, _ = timed(lambda i: opt_step([vb[i % 2]], a.task), max(w2, 3), k2)
+        v7 = a.batch * world * k2 / d7
+        workloads["%s_variable_length" % a.task] = {
+            "pairs_per_s": round(v7, 1), "ms_per_step": round(d7 / k2 * 1e3, 2), "pairs_per_gpu_per_step": a.batch,
+            "padded_seq_len": [v[2] for v in vstat], "valid_tokens": [v[0] for v in vstat], "padded_tokens": [v[1] for v in vstat],
+            "padding_fraction": round(1.0 - sum(v[0] for v in vstat) / float(sum(v[1] for v in vstat)), 4),
+            "valid_tokens_per_s": round(sum(v[0] for v in vstat) / 2.0 * world * k2 / d7, 1),
+            "gemm_fallbacks": ops.gemm_fallbacks(),
+            "mfma_frac_encoder_padded": round(v7 * ENC_GFLOP_PER_PAIR * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
+            "note": "the headline step on variable-length pairs (text 10-60 tokens, 10-36 regions; input_ids padded with <pad>, regions "
+                    "zero-padded, attn_masks / gather_index as data/data.py:360-384 builds them): the all-ones number above pays for no "
+                    "padding, this one computes B x max(len) positions like the reference does; mfma_frac_encoder_padded counts the "
+                    "flops of a 96-position pair for every pair, padding included"}
+        del vb
         rb = {t: [synth_batch(REF_MICRO, t, 9000 * (rank + 1) + i, dev) for i in range(REF_ACCUM)] for t in ("itm", "mlm")}
         k3 = 4 * k2                                  # (30 ms per optimizer step: five of them are too short a sample)
         for t in ("itm", "mlm"):
@@ -608,17 +705,24 @@ def main():
                 "micro_batch_pairs": REF_MICRO, "accumulation_steps": REF_ACCUM, "steps": k3,
                 "mfma_frac_encoder": round(REF_MICRO * REF_ACCUM * world * k3 / d3 * ENC_GFLOP_PER_PAIR * 1e9
                                            / (world * PEAK_BF16_TFLOPS * 1e12), 4),
-                "note": "the reference's own regime: %d-pair micro-batches x %d accumulation micro-steps per optimizer step "
-                        "(config/uc2_pretrain.json:17-19), all-reduce + clip + AdamW once per window" % (REF_MICRO, REF_ACCUM)}
-        for t in ("itm", "mlm"):
-            d3, _ = timed(lambda i: opt_step_pipelined(rb[t], t), max(w2, 2), k3)
-            workloads["reference_regime_%s_pipelined" % t] = {
-                "pairs_per_s": round(REF_MICRO * REF_ACCUM * world * k3 / d3, 1), "ms_per_optimizer_step": round(d3 / k3 * 1e3, 2),
-                "mfma_frac_encoder": round(REF_MICRO * REF_ACCUM * world * k3 / d3 * ENC_GFLOP_PER_PAIR * 1e9
-                                           / (world * PEAK_BF16_TFLOPS * 1e12), 4),
-                "note": "the same window with the micro-batches software-pipelined over two HIP streams (forward of micro-batch i+1 "
-                        "beside the backward of micro-batch i; uc2_amd/utils/pipeline.py) -- an opt-in: the reference's loop, as "
-                        "written, runs the sequential form above"}
+                "accumulation_overlap": bool(ops.ACCUM_OVERLAP),
+                "note": "the reference's own regime, its loop as written (forward, backward, forward, backward, ...; pretrain.py:514-566): "
+                        "%d-pair micro-batches x %d accumulation micro-steps per optimizer step (config/uc2_pretrain.json:17-19), all-reduce "
+                        "+ clip + AdamW once per window; the models run forward i+1 beside backward i on two streams (ops.accum_pass)"
+                        % (REF_MICRO, REF_ACCUM)}
+        # the same windows with the accumulation overlap off (ops.ACCUM_OVERLAP: every pass on the caller's stream, the round-5
+        # behaviour) -- the in-run A/B of what the unchanged loop gains from forward i+1 running beside backward i
+        ov_was, ops.ACCUM_OVERLAP = ops.ACCUM_OVERLAP, False
+        try:
+            for t in ("itm", "mlm"):
+                d3, _ = timed(lambda i: opt_step(rb[t], t), max(w2, 2), k3)
+                workloads["reference_regime_%s_no_overlap" % t] = {
+                    "pairs_per_s": round(REF_MICRO * REF_ACCUM * world * k3 / d3, 1), "ms_per_optimizer_step": round(d3 / k3 * 1e3, 2),
+                    "mfma_frac_encoder": round(REF_MICRO * REF_ACCUM * world * k3 / d3 * ENC_GFLOP_PER_PAIR * 1e9
+                                               / (world * PEAK_BF16_TFLOPS * 1e12), 4),
+                    "note": "the same window with UC2_ACCUM_OVERLAP=0: every forward and backward on one stream (rounds 1-5)"}
+        finally:
+            ops.ACCUM_OVERLAP = ov_was
         del rb
         # ---- BASELINE.json configs[2] as SURVEY.md 8(d) specifies it, on this GPU: the pretrain task mix itm : mlm : vmlm : tlm =
         # 9 : 12 : 9 : 3 (config/uc2_pretrain.json:72-76,100-102), one task per accumulation window like MetaLoader
@@ -708,6 +812,9 @@ def main():
                        "gemm_item_queue": bool(ops.GEMM_QUEUE), "gemm_fallbacks": gemm_fallbacks,
                        "comm_exposed_ms_per_step": round(comm_exposed_ms, 3),
                        "allreduce_tail": tail_mode,
+                       "allreduce_tail_bytes": tail_elems * (2 if tail_mode == "bf16" else 4),
+                       "allreduce_overlapped_bytes_per_layer_bucket": bucket_bytes,
+                       "per_rank": per_rank,
                        "device_allocations_in_timed_region": dev_allocs, "reserved_growth_in_timed_region_MB": round(dev_alloc_mb, 1),
                        "untimed_settle_steps_before_warmup": settle,
                        "peak_device_memory_GB": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),

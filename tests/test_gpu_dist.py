@@ -103,35 +103,39 @@ def test_native_rccl_communicator_single_rank():
         torch.cuda.synchronize()
         assert torch.equal(h, h2) and torch.equal(x, y)
         assert NativeComm.world() == 1 and NativeComm.version().count(".") == 2
-        # through the reference-shaped entry point, on a gradient arena, then / rescale_denom: fp32 reduction by default
-        # (exact for one rank); with the bf16 tail opted in (UC2_ALLREDUCE_TAIL=bf16) the >= 1M-element span is staged
-        # through bf16 (one rounding)
+        # through the reference-shaped entry point, on a gradient arena, then / rescale_denom.  The exposed tail is reduced in
+        # fp32 by default (exact for one rank); the bf16 tail is an opt-in (UC2_ALLREDUCE_TAIL=bf16 / auto, D.TAIL_BF16) that
+        # applies PER STORE and only to a store that computes in bf16: its >= 1M-element span is then staged through bf16 (one
+        # rounding), while a store in fp32 parity mode is never rounded
         from uc2_amd.utils import distributed as D
         m = torch.nn.Sequential(torch.nn.Linear(1500, 1024), torch.nn.Linear(64, 8)).to(dev)
         st = ParamStore(m)
-        assert D.TAIL_BF16 is False
-        for tail_bf16 in (False, True):
-            D.TAIL_BF16 = tail_bf16
-            try:
-                for p in m.parameters():
-                    st.grad_buf(p).copy_(torch.randn_like(p))
-                ref = [p.grad.clone() for p in m.parameters()]
-                all_reduce_and_rescale_tensors([p.grad.data for p in m.parameters()], 2.0)
-                torch.cuda.synchronize()
-            finally:
-                D.TAIL_BF16 = False
-            for p, r in zip(m.parameters(), ref):       # adjacent parameters travel as one span: all of it rounds to bf16 once
-                want = (r.to(torch.bfloat16).float() if tail_bf16 else r) / 2.0
-                assert torch.allclose(p.grad, want, rtol=1e-6, atol=0)
-        # default mode "auto": once the store keeps bf16 compute copies (throughput mode) the exposed tail is reduced as bf16
-        st.sync_shadow()
-        for p in m.parameters():
-            st.grad_buf(p).copy_(torch.randn_like(p))
-        ref = [p.grad.clone() for p in m.parameters()]
-        all_reduce_and_rescale_tensors([p.grad.data for p in m.parameters()], 1.0)
-        torch.cuda.synchronize()
-        for p, r in zip(m.parameters(), ref):
-            assert torch.allclose(p.grad, r.to(torch.bfloat16).float(), rtol=1e-6, atol=0)
+        m2 = torch.nn.Sequential(torch.nn.Linear(1500, 1024)).to(dev)          # a second store that stays in fp32 parity mode
+        st2 = ParamStore(m2)
+        assert D.TAIL_BF16 is False and D._TAIL_MODE == "fp32"
+
+        def run(models, denom):
+            ps = [p for mm in models for p in mm.parameters()]
+            for p in ps:
+                p._uc2_store.grad_buf(p).copy_(torch.randn_like(p))
+            ref = [p.grad.clone() for p in ps]
+            all_reduce_and_rescale_tensors([p.grad.data for p in ps], denom)
+            torch.cuda.synchronize()
+            return ps, ref
+        for bf16_store in (False, True):
+            if bf16_store:
+                st.sync_shadow()                       # throughput mode: the store keeps bf16 compute copies from here on
+            for opt_in in (False, True):
+                D.TAIL_BF16 = opt_in
+                try:
+                    ps, ref = run([m, m2], 2.0)
+                finally:
+                    D.TAIL_BF16 = False
+                for p, r in zip(ps, ref):       # adjacent parameters travel as one span: all of it rounds to bf16 once
+                    rounded = opt_in and bf16_store and p._uc2_store is st
+                    want = (r.to(torch.bfloat16).float() if rounded else r) / 2.0
+                    assert torch.allclose(p.grad, want, rtol=1e-6, atol=0), (bf16_store, opt_in, p._uc2_store is st)
+                assert st2.shadow is None
         broadcast_tensors([p.data for p in m.parameters()], 0)
         torch.cuda.synchronize()
     finally:

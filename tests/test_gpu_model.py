@@ -1055,51 +1055,107 @@ def test_bf16_bench_path_trains_like_the_fp32_parity_mode():
 
 
 @pytest.mark.parametrize("task", ["itm", "mlm"])
-def test_pipelined_accumulation_equals_the_sequential_loop(task):
-    """utils.pipeline.accumulate: three micro-batches with forward i+1 enqueued beside backward i on a second stream against the
-    plain loop -- the same gradients (dropout off: up to the fp32 order of the weight-gradient reductions; dropout on: it runs,
-    draws distinct masks per micro-batch, and leaves the current stream ordered behind both side streams)"""
-    from uc2_amd.utils.pipeline import accumulate
+def test_accumulation_overlap_equals_the_sequential_loop(task):
+    """ops.accum_pass (round 6): the reference's accumulation loop AS WRITTEN (pretrain.py:514-566: forward, backward, forward,
+    backward, ...) with each training forward on one of the two overlap streams, so that forward i+1 runs beside backward i,
+    against the same loop on one stream (ops.ACCUM_OVERLAP off).  Same kernels, same accumulation order: bit-identical losses and
+    gradients, fp32 and bf16; the passes really ran on the overlap streams; consumers of gradients (clip, optimizer) are ordered
+    behind both streams; with dropout on, the three forwards draw distinct masks and equal the one-stream loop's."""
+    from uc2_amd.store import store_of
     geom = dict(O.BASE, num_hidden_layers=2, vocab_size=2000)
     batches = [to_dev(synth.make_batch(2000, 24, 40, 20, task=task, seed=90 + i, variable_len=(i == 1))) for i in range(3)]
 
-    def fns(model):
-        def one(b):
-            def f():
-                l = model(b, task, compute_loss=True)
-                l = l[0] if isinstance(l, tuple) else l
-                return l.mean()
-            return f
-        return [one(b) for b in batches]
-    for dtype in (torch.float32, torch.bfloat16):
-        model = build_pretrain(geom, dtype)
-        model.zero_grad()
-        ref_losses = []
-        for f in fns(model):
-            l = f()
+    def loop(model, bs):
+        losses = []
+        for b in bs:                                              # the reference's loop: nothing but forward + backward
+            l = model(b, task, compute_loss=True)
+            l = (l[0] if isinstance(l, tuple) else l).mean()
             l.backward()
-            ref_losses.append(float(l.detach()))
-        ops.join_side_streams()
+            losses.append(l.detach())
+        norm = clip_grad_norm_([p for p in model.parameters() if p.grad is not None], 1e9)      # a consumer: joins the streams
+        grads = OrderedDict((n, p.grad.detach().clone()) for n, p in model.named_parameters() if p.grad is not None)
         torch.cuda.synchronize()
-        ref = OrderedDict((n, p.grad.detach().clone()) for n, p in model.named_parameters() if p.grad is not None)
-        model.zero_grad()
-        order = []
-        losses = accumulate(fns(model), before_backward=order.append)
-        got = OrderedDict((n, p.grad.detach().clone()) for n, p in model.named_parameters() if p.grad is not None)   # (current stream: ordered)
-        torch.cuda.synchronize()
-        assert order == [0, 1, 2] and [float(l) for l in losses] == ref_losses
-        assert set(got) == set(ref)
-        for n in ref:
-            assert rel_err(got[n], ref[n]) < (1e-6 if dtype == torch.float32 else 2e-5) or ref[n].norm() < 1e-7, n
-    # dropout on: runs, finite, and the three forwards did not share a mask
-    model = VLXLMRForPretraining(make_cfg(geom, drop=0.1), img_dim=2048, img_label_dim=1601)
-    synth.det_init_(model)
-    model.to(DEV).train()
-    set_compute_dtype(model, torch.bfloat16)
-    same = [to_dev(synth.make_batch(2000, 24, 40, 20, task=task, seed=90)) for _ in range(3)]
-    outs = accumulate([(lambda b=b: (lambda l: (l[0] if isinstance(l, tuple) else l).mean())(model(b, task, compute_loss=True))) for b in same])
-    vals = [float(v) for v in outs]
-    assert all(v == v for v in vals) and len(set(vals)) == 3, vals
+        return [float(l) for l in losses], grads, float(norm)
+    was = ops.ACCUM_OVERLAP
+    try:
+        for dtype, drop in ((torch.float32, 0.0), (torch.bfloat16, 0.0), (torch.bfloat16, 0.1)):
+            res = {}
+            for overlap in (False, True):
+                ops.ACCUM_OVERLAP = overlap
+                model = VLXLMRForPretraining(make_cfg(geom, drop=drop), img_dim=2048, img_label_dim=1601)
+                synth.det_init_(model)
+                model.to(DEV).train()
+                set_compute_dtype(model, dtype)
+                st = store_of(model)
+                if dtype == torch.bfloat16:
+                    st.sync_shadow()
+                    st.auto_sync = False                       # what AdamW.step does after the first optimizer step
+                ops.rng.manual_seed(4242, DEV)
+                model.zero_grad()
+                before = sum(s_.passes for s_ in ops._accum.values())
+                res[overlap] = loop(model, batches if drop == 0.0 else [batches[0]] * 3)
+                ran = sum(s_.passes for s_ in ops._accum.values()) - before
+                assert ran == (3 if overlap else 0), ran
+                del model
+            (l0, g0, n0), (l1, g1, n1) = res[False], res[True]
+            assert l0 == l1 and n0 == n1 and set(g0) == set(g1)
+            for n in g0:
+                assert torch.equal(g0[n], g1[n]), n
+            if drop:
+                assert len(set(l1)) == 3, l1                      # three forwards of one batch: three different masks
+    finally:
+        ops.ACCUM_OVERLAP = was
+
+
+def test_accumulation_overlap_stays_off_where_it_must():
+    """ops.accum_pass is a plain pass on the caller's stream for eval / no-grad forwards, fp8 stores, stores that re-cast their bf16
+    copies at every forward (store.auto_sync) and micro-batches of ACCUM_OVERLAP_MAX_ROWS tokens or more; utils.pipeline.accumulate
+    (the round-5 opt-in API) is the plain loop on top of it."""
+    from uc2_amd.store import set_fp8, store_of
+    from uc2_amd.utils.pipeline import accumulate
+    geom = dict(O.BASE, num_hidden_layers=2, vocab_size=2000)
+    model = build_pretrain(geom, torch.bfloat16)
+    st = store_of(model)
+    b = to_dev(synth.make_batch(2000, 8, 40, 20, task="itm", seed=5))
+
+    def passes():
+        return sum(s_.passes for s_ in ops._accum.values())
+
+    def fwd():
+        l = model(b, "itm", compute_loss=True)
+        return (l[0] if isinstance(l, tuple) else l).mean()
+    n0 = passes()
+    assert st.auto_sync
+    fwd().backward()                                            # auto_sync: the bf16 copies are re-cast by every forward
+    assert passes() == n0
+    st.sync_shadow()
+    st.auto_sync = False
+    fwd().backward()
+    assert passes() == n0 + 1
+    with torch.no_grad():
+        fwd()
+    model.eval()
+    model(b, "itm", compute_loss=False)
+    model.train()
+    assert passes() == n0 + 1
+    set_fp8(model, True)
+    model.__dict__.pop("_uc2_fp8_probe", None)
+    fwd().backward()
+    set_fp8(model, False)
+    assert passes() == n0 + 1
+    was = ops.ACCUM_OVERLAP_MAX_ROWS
+    ops.ACCUM_OVERLAP_MAX_ROWS = 8 * 60                         # this batch is 8 x 60 tokens: at the threshold -> off
+    try:
+        fwd().backward()
+    finally:
+        ops.ACCUM_OVERLAP_MAX_ROWS = was
+    assert passes() == n0 + 1
+    order = []
+    out = accumulate([fwd, fwd], before_backward=order.append)
+    assert order == [0, 1] and len(out) == 2 and passes() == n0 + 3
+    ops.join_side_streams()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
 
 def test_adamw_bf16_shadow_and_fused_clip():

@@ -7,7 +7,7 @@ import torch
 from .. import ops
 from ..store import mark_all_dirty, store_of
 from .layer import Linear
-from .model import VLXLMRModel, VLXLMRPreTrainedModel
+from .model import VLXLMRModel, VLXLMRPreTrainedModel, _any_fp8
 
 
 class VLXLMRForImageTextRetrieval(VLXLMRPreTrainedModel):
@@ -29,7 +29,15 @@ class VLXLMRForImageTextRetrieval(VLXLMRPreTrainedModel):
         mark_all_dirty()
 
     def forward(self, batch, compute_loss=True):
-        store_of(self)
+        """model/itm.py:28-55 (training forwards of small micro-batches on the accumulation-overlap streams, ops.accum_pass)"""
+        st = store_of(self)
+        am = batch.get('attn_masks') if hasattr(batch, 'get') else None
+        rows = am.numel() if (self.training and torch.is_tensor(am)) else 0
+        with ops.accum_pass(st, rows, [v for v in batch.values() if torch.is_tensor(v)] if rows else (),
+                            fp8=_any_fp8(self)) as ap:
+            return ap.mark(self._forward(batch, compute_loss))
+
+    def _forward(self, batch, compute_loss=True):
         batch = defaultdict(lambda: None, batch)
         sequence_output = self.roberta(batch['input_ids'], None, batch['img_feat'], batch['img_pos_feat'],
                                        batch['attn_masks'], batch['gather_index'],

@@ -304,6 +304,7 @@ class VLXLMRModel(VLXLMRPreTrainedModel):
         # additive key mask, fp32 (the parameters are fp32 masters): model/model.py:433-436
         extended_attention_mask = attention_mask.unsqueeze(1).unsqueeze(2).to(dtype=torch.float32)
         extended_attention_mask = (1.0 - extended_attention_mask) * -10000.0
+        ops.fp8_new_forward()
         with ops.rng.scope():           # one dropout seed copy for the whole forward; the sites are told apart by ops.rng.site()
             if input_ids is None:
                 embedding_output = self._compute_img_embeddings(img_feat, img_pos_feat, img_masks, img_type_ids)
@@ -317,6 +318,16 @@ class VLXLMRModel(VLXLMRPreTrainedModel):
         if not output_all_encoded_layers:
             encoded_layers = encoded_layers[-1]
         return encoded_layers
+
+
+def _any_fp8(module):
+    """True when a BertLayer under `module` runs its GEMMs on e4m3 operands (store.set_fp8); cached per module"""
+    d = module.__dict__
+    key = d.get("_uc2_fp8_probe")
+    layers = key if key is not None else [m for m in module.modules() if m.__class__.__name__ == "BertLayer"]
+    if key is None:
+        d["_uc2_fp8_probe"] = layers
+    return any(l.__dict__.get("uc2_fp8", False) for l in layers)
 
 
 def pad_tensor_to_mul(tensor, dim=0, mul=8):
@@ -375,7 +386,16 @@ class VLXLMRForPretraining(VLXLMRPreTrainedModel):
 
     # ------------------------------------------------------------------ dispatch
     def forward(self, batch, task, compute_loss=True):
-        store_of(self)                      # one arena for the whole model
+        """model/model.py:495-568.  A training forward of a small micro-batch runs on one of the two accumulation-overlap streams
+        (ops.accum_pass: the loop's next forward then runs beside this one's backward); results and call sequence are unchanged."""
+        st = store_of(self)                 # one arena for the whole model
+        am = batch.get('attn_masks') if hasattr(batch, 'get') else None
+        rows = am.numel() if (self.training and torch.is_tensor(am)) else 0
+        with ops.accum_pass(st, rows, [v for v in batch.values() if torch.is_tensor(v)] if rows else (),
+                            fp8=_any_fp8(self)) as ap:
+            return ap.mark(self._forward(batch, task, compute_loss))
+
+    def _forward(self, batch, task, compute_loss=True):
         # fp8 mode: delayed activation scales are kept per task (the gradient magnitudes of two tasks differ by orders of magnitude:
         # their losses average over different counts -- the reference keeps one amp loss scaler per task for the same reason,
         # pretrain.py:462-465)

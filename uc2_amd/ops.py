@@ -144,7 +144,6 @@ class _Rng:
     def __init__(self):
         self.state = {}
         self._scope = None
-        self._preset = None
 
     def buf(self, device):
         device = torch.device(device)
@@ -168,20 +167,11 @@ class _Rng:
         return self._fresh(device)
 
     def _fresh(self, device):
-        fifo = self._preset
-        if fifo:                                   # seeds drawn ahead on one stream (utils/pipeline.py: forwards on two streams)
-            return fifo.pop(0)
+        # (forwards never overlap each other -- ops.accum_pass orders every pass's stream behind the caller's, which waits for the
+        #  previous forward -- so the one seed cell per device is advanced in forward order whatever stream a pass runs on)
         b = self.buf(device)
         b.add_(0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFF)
         return b.clone()
-
-    def draw(self, device, n):
-        """n seed copies in the order n consecutive forwards would draw them (all on the current stream)"""
-        was, self._preset = self._preset, None
-        try:
-            return [self._fresh(device) for _ in range(n)]
-        finally:
-            self._preset = was
 
     def site(self, imm):
         """seed offset of one dropout site.  Outside a scope: `imm` itself (every caller has its own seed copy).  Inside: the
@@ -556,7 +546,14 @@ def _st_uid(st):
     return u
 
 
-_FP8_PREQ = {}             # data_ptr of a layer output -> (e4m3 copy, scale) written by that layer's last LayerNorm for the next layer's QKV GEMM
+_FP8_PREQ = {}             # data_ptr of a layer output -> (consumer layer id, (e4m3 copy, scale)) written by that layer's last LayerNorm for the
+                           # next layer's QKV GEMM.  Cleared at the start of every top-level model forward (fp8_new_forward): an entry a
+                           # forward that raised left behind must not meet the next step's tensor at a recycled address
+
+
+def fp8_new_forward():
+    """called by VLXLMRModel.forward before the first layer: drops a hand-over left by a forward pass that did not finish"""
+    _FP8_PREQ.clear()
 FP8_TAG = None             # set by the model's forward (task name, loss or scores): part of every role key, saved by BertLayerFn for its backward
 
 
@@ -838,18 +835,34 @@ def _side_stream(device):
 _side_keep = []         # tensors the side stream reads: kept alive until the join (see _on_side_stream)
 
 
-def join_side_streams():
-    """make the current stream wait for every weight-gradient kernel enqueued on a side stream"""
+def join_side_streams(compute=True):
+    """make the current stream wait for every weight-gradient kernel enqueued on a side stream and (compute=True: what every
+    consumer of gradients asks for -- optimizer, clipping, all-reduce, zero_grad) for the forward / backward passes that the
+    accumulation overlap put on its own two streams (accum_overlap below)"""
     for key in list(_side_dirty):
         torch.cuda.current_stream(torch.device(*key)).wait_stream(_side_streams[key])
     _side_dirty.clear()
     _side_keep.clear()                 # from here on the main stream is ordered behind their last reader: the blocks may be reused
     _join_queued[0] = False            # (a backward that raised never ran its callback: the next one must queue a new join)
+    if compute:
+        join_accum_streams()
+
+
+def _queue_pass_callback(fn):
+    """autograd end-of-pass callback that runs `fn` on the stream that is current NOW (the stream of the backward node that
+    registers it).  The engine runs final callbacks in the thread and stream context of whoever called backward(); a pass whose
+    forward ran on another stream (utils/pipeline.py, accum_overlap) must flush its deferred launches there."""
+    s = torch.cuda.current_stream()
+
+    def run():
+        with torch.cuda.stream(s):
+            fn()
+    torch.autograd.Variable._execution_engine.queue_callback(run)
 
 
 def _end_of_backward_join():
     _join_queued[0] = False
-    join_side_streams()
+    join_side_streams(compute=False)
 
 
 def pending_side_stream(device):
@@ -857,6 +870,134 @@ def pending_side_stream(device):
     GradSync orders a layer's all-reduce behind it (uc2_comm_allreduce_bucket_after) instead of joining it into the main stream."""
     key = (device.type, device.index)
     return _side_streams[key] if key in _side_dirty else None
+
+
+# --------------------------------------------------------------------------------------
+# Gradient accumulation, overlapped without an API change (VERDICT r5 #2).  The reference's loop runs micro-batch after micro-batch
+# (pretrain.py:514-566: forward, backward, forward, backward, ..., all-reduce, clip, step; config/uc2_pretrain.json:17-19: 104
+# pairs x 3).  At that size most kernels of a pass leave CUs idle (9 984 tokens = 117 tiles of 256 x 256 for 256 CUs), and nothing
+# in micro-batch i+1's FORWARD depends on micro-batch i's BACKWARD: the weights only change at the optimizer step.  The top-level
+# models (VLXLMRForPretraining / VLXLMRForImageTextRetrieval) therefore run a TRAINING forward of fewer than ACCUM_OVERLAP_MAX_ROWS
+# tokens on one of two library-owned streams, alternating per call; autograd runs each node's backward on its forward's stream, so
+# backward i is on stream i & 1 and the loop's next forward, enqueued right after it on the other stream, runs beside it:
+#   * entry: the pass's stream waits for the caller's current stream (inputs, the optimizer's weights); exit: the caller's stream
+#     waits for the pass's stream (the returned losses / scores are safe to use there) -- NOT for any backward;
+#   * gradient accumulation stays in order: a pass's first backward node (_AccumMarker) makes its stream wait for the other one
+#     (the arena's += are not atomic);
+#   * every consumer of gradients (AdamW.step, clip_grad_norm_, all_reduce_and_rescale_tensors, zero_grad -- they all call
+#     join_side_streams()) makes its stream wait for both; the per-layer all-reduce hooks of GradSync run inside the pass.
+# Same micro-batches, same dropout seeds in the same order, bit-identical gradients (same kernels, same accumulation order).
+# Off for: eval / no-grad forwards, fp8 stores (delayed-scaling histories assume one in-order stream), stores whose bf16 copies
+# are re-cast at every forward (store.auto_sync: the re-cast would race with the backward beside it; AdamW.step turns auto_sync
+# off), stream capture, UC2_ACCUM_OVERLAP=0.  Measured: profiles/r06_experiments.md.
+ACCUM_OVERLAP = os.environ.get("UC2_ACCUM_OVERLAP", "1") != "0"
+ACCUM_OVERLAP_MAX_ROWS = 16384
+_accum = {}
+
+
+class _AccumState:
+    def __init__(self, device):
+        self.device = device
+        self.streams = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+        self.k = 0                         # eligible forwards since the last join
+        self.used = [False, False]
+        self.passes = 0                    # (statistics: passes that ran on the overlap streams)
+
+
+def _accum_state(device):
+    key = (device.type, device.index)
+    st = _accum.get(key)
+    if st is None:
+        st = _accum[key] = _AccumState(device)
+    return st
+
+
+def join_accum_streams():
+    """the current stream waits for every pass enqueued on the accumulation-overlap streams; the next pass starts on stream 0"""
+    for st in _accum.values():
+        if st.used[0] or st.used[1]:
+            cur = torch.cuda.current_stream(st.device)
+            for i in (0, 1):
+                if st.used[i]:
+                    cur.wait_stream(st.streams[i])
+            st.used = [False, False]
+        st.k = 0
+
+
+class _AccumMarker(torch.autograd.Function):
+    """identity on a pass's output: its backward is the first node of the pass's backward (it runs on the pass's stream) and
+    orders that stream behind the other one, i.e. behind the previous micro-batch's backward"""
+
+    @staticmethod
+    def forward(ctx, x, state, idx):
+        ctx.state, ctx.idx = state, idx
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        st, i = ctx.state, ctx.idx
+        if st.used[1 - i]:
+            st.streams[i].wait_stream(st.streams[1 - i])
+        return g, None, None
+
+
+class accum_pass:
+    """`with accum_pass(model_store, rows, tensors) as ap: out = ap.mark(forward(...))` -- see the block comment above.
+    Inactive (a plain pass on the caller's stream) whenever one of the conditions does not hold."""
+
+    def __init__(self, store, rows, tensors, fp8=False):
+        self.state = None
+        t0 = next((t for t in tensors if torch.is_tensor(t) and t.is_cuda), None)
+        if not (ACCUM_OVERLAP and t0 is not None and torch.is_grad_enabled() and 0 < rows < ACCUM_OVERLAP_MAX_ROWS and not fp8
+                and not (store.shadow is not None and store.auto_sync) and not torch.cuda.is_current_stream_capturing()):
+            return
+        self.state = _accum_state(t0.device)
+        self.store = store
+        self.tensors = [t for t in tensors if torch.is_tensor(t) and t.is_cuda]
+
+    def __enter__(self):
+        st = self.state
+        if st is None:
+            return self
+        self.store.pin_grad_accumulators()          # (on the caller's stream, before the switch: see store.py)
+        self.idx = st.k & 1
+        st.k += 1
+        st.passes += 1
+        S = st.streams[self.idx]
+        self.main = torch.cuda.current_stream(st.device)
+        S.wait_stream(self.main)
+        for t in self.tensors:                      # allocated on the caller's stream, read by this pass (and its backward) on S
+            t.record_stream(S)
+        st.used[self.idx] = True
+        self._ctx = torch.cuda.stream(S)
+        self._ctx.__enter__()
+        return self
+
+    def mark(self, out):
+        """tag the tensors of `out` that carry a graph (losses / scores) and make them usable on the caller's stream"""
+        st = self.state
+        if st is None:
+            return out
+
+        def one(t):
+            if not torch.is_tensor(t):
+                return t
+            if t.requires_grad:
+                t = _AccumMarker.apply(t, st, self.idx)
+            if t.is_cuda:
+                t.record_stream(self.main)
+            return t
+        if isinstance(out, (tuple, list)):
+            return type(out)(one(t) for t in out)
+        return one(out)
+
+    def __exit__(self, *exc):
+        st = self.state
+        if st is None:
+            return False
+        self._ctx.__exit__(*exc)
+        self.main.wait_stream(st.streams[self.idx])
+        return False
 
 
 WGRAD_SIDE_MIN_ROWS = 16384      # below this many tokens the step is close to host-bound and the extra event / stream traffic makes it
@@ -887,7 +1028,7 @@ def _on_side_stream(dev, fn, inputs):
         # (keyed on the dirty set going non-empty, not only on the flag: a backward that raised after queueing never runs its
         #  callback, and a flag left set would keep every later backward from registering the join)
         try:
-            torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward_join)
+            _queue_pass_callback(_end_of_backward_join)
             _join_queued[0] = True
         except RuntimeError:                     # not inside a backward pass: join right away
             join_side_streams()
@@ -1091,7 +1232,7 @@ def _defer_ln_reduction(d, M, H, ws, dgamma, dbeta, dbias):
     if _ln_pending_task[0] != task:
         del _ln_pending[:]                       # (left by a pass that raised)
         try:
-            torch.autograd.Variable._execution_engine.queue_callback(flush_ln_reductions)
+            _queue_pass_callback(flush_ln_reductions)
         except RuntimeError:
             return False
         _ln_pending_task[0] = task
@@ -1393,8 +1534,8 @@ class BertLayerFn(torch.autograd.Function):
             ky = (_st_uid(st), ("layer", cfg["layer_id"] + 1), "fwd", "x", FP8_TAG)
             ka = (_st_uid(st), st.offsets[id(P["iw"])], "fwd", "a", FP8_TAG)
             xq = _FP8_PREQ.pop(x2.data_ptr(), None)
-            if xq is not None and tuple(xq[0].shape) != (M, H):
-                xq = None
+            if xq is not None:                         # written for THIS layer (id) by the layer below, same shape -- or not used
+                xq = xq[1] if (xq[0] == cfg["layer_id"] and tuple(xq[1][0].shape) == (M, H)) else None
             w8_, sw_ = _fp8_weight(st, P["qw"], P["vw"], (3 * H, H), False)
             x8_, sx_ = xq if xq is not None else fp8_quantize_act(x2, kx)
             qkv = gemm_fp8(x8_, sx_, w8_, sw_, bias=bqkv)
@@ -1434,7 +1575,7 @@ class BertLayerFn(torch.autograd.Function):
             y, mean2, rstd2, yq = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, s_ln2, q_key=ky)
             _FP8_PREQ.clear()                          # (at most one hand-over alive: the last layer's copy has no fp8 consumer)
             if yq is not None:
-                _FP8_PREQ[y.data_ptr()] = yq
+                _FP8_PREQ[y.data_ptr()] = (cfg["layer_id"] + 1, yq)
         elif fused2:
             y, mean2, rstd2 = ln_fwd(o2, None, P["g2"].data, P["b2"].data, 1e-12)
         else:

@@ -193,6 +193,10 @@ class AdamW(Optimizer):
             st.version += 1
             if want_p16 and st.shadow is not None:
                 st.shadow_version = st.version         # the kernel refreshed every updated bf16 copy
+                # from the first optimizer step on the store trusts its own bookkeeping (this pass, load_state_dict,
+                # broadcast_tensors, mark_all_dirty) instead of re-casting 285 M parameters at every top-level forward; the
+                # accumulation overlap (ops.accum_pass) needs that too.  Manual edits of parameter values: mark_all_dirty().
+                st.auto_sync = False
             if zero_grad:
                 st.grad_epoch += 1
                 for p in st.params:

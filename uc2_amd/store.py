@@ -168,6 +168,19 @@ class ParamStore:
             p.grad = None
             p._uc2_gepoch = self.grad_epoch
 
+    def pin_grad_accumulators(self):
+        """keep every parameter's AccumulateGrad node alive, created under the stream that is current NOW.  The kernels write
+        gradients straight into the arena and the autograd Functions return None for their parameter inputs, but the graph still
+        ends in those nodes, and autograd makes the stream that called backward() wait for the stream each of them was created on
+        (torch/csrc/autograd/engine.cpp, exec_post_processing: leaf streams).  A node is created at a parameter's first use in a
+        graph and dies with the graph -- re-created inside a pass that ops.accum_pass runs on its own stream, it would make the
+        caller's stream wait for that pass's whole backward and serialise the next forward behind it.  Pinned here, on the
+        caller's stream, the wait is a no-op."""
+        if getattr(self, "_accs_for", None) != len(self.params):
+            with torch.enable_grad():
+                self._accs = [p.expand_as(p).grad_fn.next_functions[0][0] for p in self.params if p.requires_grad]
+            self._accs_for = len(self.params)
+
     # ---- bf16 compute copies ----
     def mark_dirty(self):
         self.version += 1

@@ -17,23 +17,27 @@ import torch.distributed as dist
 
 from .. import _lib
 
-# The gradient tail (embeddings + heads: 0.77 GB of fp32, final only when backward ends, so its all-reduce is exposed) is
-# reduced as bf16 on the GPU data paths when the model COMPUTES in bf16 (UC2_ALLREDUCE_TAIL=auto, the default): half the bytes
-# of the one collective nothing overlaps.  The reference reduces fp16 gradients throughout (apex O2 + Horovod, pretrain.py:557-566);
-# here only the tail is rounded (8 significant bits; the sum over ranks is taken by RCCL in bf16, the result is cast back and
-# the fp32 master gradients of the encoder layers are never rounded), and only in the mode whose activations and weight copies
-# are bf16 anyway.  fp32 parity mode always reduces fp32; UC2_ALLREDUCE_TAIL=fp32 / bf16 force either.  No run with more than
-# one rank has compared the two yet (one GPU per lease): INTEGRATION.md, behavioural notes.
-_TAIL_MODE = os.environ.get("UC2_ALLREDUCE_TAIL", "auto")
+# The gradient tail (embeddings + heads: 0.77 GB of fp32, final only when backward ends, so its all-reduce is exposed) is reduced
+# in fp32 by default: the library never rounds gradients on its own.  UC2_ALLREDUCE_TAIL=bf16 (or TAIL_BF16 = True) opts a store
+# that COMPUTES in bf16 into casting its tail to bf16 for the collective -- half the bytes of the one collective nothing overlaps;
+# the sum over ranks is then taken by RCCL in bf16 (8 significant bits; the reference reduces fp16 gradients, 11 bits, under a loss
+# scaler: apex O2 + Horovod, pretrain.py:557-566) and cast back; the fp32 master gradients of the encoder layers are never rounded.
+# `auto` = bf16 for bf16 stores (round 5's default; no run with more than one rank has compared loss curves or gradient norms of
+# the two yet, one GPU per lease, so it is an opt-in again -- ADVICE r5).  The decision is taken PER STORE: a store in fp32 parity
+# mode always reduces fp32.  The mode in use is logged once on rank 0.
+_TAIL_MODE = os.environ.get("UC2_ALLREDUCE_TAIL", "fp32")
 TAIL_BF16 = _TAIL_MODE == "bf16"                 # (kept as a module attribute: tests and tools flip it)
 COMM_TIMER = None                # bench.py: a list that receives (start, end) HIP events around the EXPOSED part of the gradient all-reduce
+_tail_logged = [False]
 
 
 def _tail_bf16(st):
-    if _TAIL_MODE == "auto" and not TAIL_BF16:
-        from ..store import compute_dtype_of_store
-        return compute_dtype_of_store(st) == torch.bfloat16
-    return TAIL_BF16
+    """True when store `st`'s exposed tail travels as bf16: opted in (UC2_ALLREDUCE_TAIL=bf16 / auto, or TAIL_BF16) AND the store
+    keeps bf16 compute copies.  A store in fp32 parity mode is never rounded."""
+    if not (TAIL_BF16 or _TAIL_MODE in ("bf16", "auto")):
+        return False
+    from ..store import compute_dtype_of_store
+    return compute_dtype_of_store(st) == torch.bfloat16
 
 
 _TAIL_MIN = 1 << 20              # elements; smaller spans are not worth two cast passes
@@ -296,10 +300,28 @@ def all_reduce_and_rescale_tensors(tensors, rescale_denom):
     else:
         e_exp0 = None
     if W > 1 or NativeComm.active:
-        tail_half = any(_tail_bf16(st) for st, _ in by_store.values())
+        # dtype of the exposed tail, decided per owning store (a store in fp32 parity mode is never rounded because another
+        # store of the process computes in bf16)
+        half_ids = set()
+        for st, _ in by_store.values():
+            if _tail_bf16(st):
+                half_ids.add(st.grad.data_ptr())
+        if not _tail_logged[0] and _rank() == 0 and by_store:
+            _tail_logged[0] = True
+            import logging
+            logging.getLogger("uc2_amd").info("gradient all-reduce: per-layer buckets fp32, embedding / head tail %s (UC2_ALLREDUCE_TAIL=%s)",
+                                              "bf16" if half_ids else "fp32", _TAIL_MODE)
+
+        def _owner_half(v):
+            p = v.data_ptr()
+            for st, _ in by_store.values():
+                lo = st.grad.data_ptr()
+                if lo <= p < lo + 4 * st.total:
+                    return lo in half_ids
+            return False
 
         def half(v):
-            return tail_half and v.is_cuda and v.numel() >= _TAIL_MIN and \
+            return bool(half_ids) and v.is_cuda and v.numel() >= _TAIL_MIN and _owner_half(v) and \
                 (NativeComm.active or dist.get_backend() == "nccl")
         n_half = sum((v.numel() + 63) // 64 * 64 for v in todo if half(v))
         stage = _tail_stage(todo[0].device, n_half) if n_half else None
