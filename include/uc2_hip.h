@@ -101,6 +101,9 @@ int uc2_gemm_drop_residual(int M, int N, int K, const void* A, int lda, const vo
  * (variant 8 / 9 / 12) and were run by another kernel because the shape, an alignment or the 32-bit staging-offset limit
  * (an operand of 4 GiB or more) did not qualify.  bench.py prints it as config.gemm_fallbacks; nothing selects a kernel from it. */
 long long uc2_gemm_fallback_count(int reset);
+/* Diagnostics only: e4m3 GEMM calls (uc2_gemm_fp8 / uc2_gemm_fp8_q) since the last reset that ran on the ring kernel (which = 0:
+ * the shape is not made of whole 256 x 256 tiles, or UC2_GEMM_FP8_RING) or on the ping-pong kernel gemm_pp8.hip (which = 1). */
+long long uc2_gemm_fp8_route_count(int which, int reset);
 /* Grouped weight gradients: dW_i[n_out_i, n_in_i] (fp32) += dY_i[rows, n_out_i]^T X_i[rows, n_in_i] for up to four linear
  * layers that share the token axis -- the four dense layers of one BertLayer (model/layer.py:75-156; autograd issues their
  * weight gradients one GEMM at a time) -- as ONE launch of the persistent ping-pong kernel over all (tile, k-split) items

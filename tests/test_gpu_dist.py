@@ -56,6 +56,31 @@ def test_bench_two_ranks_side_stream_route_stays_in_sync():
     assert d["n_gpus"] == 2 and d["config"]["replicas_in_sync"] is True and d["config"]["global_batch"] == 352
 
 
+def test_two_ranks_mean_gradient_equals_oracle_mean_of_single_rank_runs():
+    """SURVEY.md 8(a) a20 on the GPU, by VALUE (VERDICT r5 #6a): two ranks on distinct seeded batches through the product path
+    (GradSync per-layer hooks + all_reduce_and_rescale_tensors, utils/distributed.py:15-42) must end with every gradient equal to
+    oracle.allreduce_mean of the two ranks' single-rank gradients divided by rescale_denom -- fp32 mode and bf16 mode, ITM and MLM,
+    1e-6 relative L2 -- not only with replicas that agree.  tests/dist_value_worker.py is the rank process; gloo data plane on the
+    one-GPU test box, the library's RCCL communicator when two GPUs are visible."""
+    import socket
+    import torch
+    if torch.cuda.is_initialized():
+        pytest.skip("the GPU is already initialised in this pytest process")
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    env = dict(os.environ, UC2_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0", UC2_AUTOTUNE="0", MASTER_ADDR="127.0.0.1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "tests", "dist_value_worker.py")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "dist_value_worker ok" in r.stdout, r.stdout[-1500:]
+
+
 def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible():
     """the real data plane -- backend nccl (= RCCL) with the library's own communicator -- needs one GPU per rank: runs
     on a multi-GPU node, skipped on the 1-GPU test box.  Same assertions as the gloo run + the communicator in use."""

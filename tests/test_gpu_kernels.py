@@ -207,6 +207,15 @@ def test_layernorm_dropout_consistency():
     assert abs(rect - p ** 4) < 3e-5, rect
     rows, cols = d.float().sum(1), d.float().sum(0)
     assert 0.8 < rows.var().item() / (H * p * (1 - p)) < 1.2 and 0.8 < cols.var().item() / (8192 * p * (1 - p)) < 1.2
+    # per-row and per-column drop RATE: no row / column of the separable variate is off by more than 5.5 sigma of the
+    # binomial (8192 rows, 768 columns: the expected maximum of that many standard normals is ~4), and the pair statistics hold
+    # for a row pair and a column pair taken alone as well (the XOR structure couples 2 x 2 rectangles, not pairs)
+    assert (rows / H - p).abs().max().item() < 5.5 * (p * (1 - p) / H) ** 0.5
+    assert (cols / 8192 - p).abs().max().item() < 5.5 * (p * (1 - p) / 8192) ** 0.5
+    pr = (d[0::2] & d[1::2]).float().mean(1)                     # joint drop frequency of every adjacent row pair, over its 768 columns
+    pc = (d[:, 0::2] & d[:, 1::2]).float().mean(0)               # ... of every adjacent column pair, over 8192 rows
+    assert (pr - p * p).abs().max().item() < 6.0 * (p * p * (1 - p * p) / H) ** 0.5
+    assert (pc - p * p).abs().max().item() < 6.0 * (p * p * (1 - p * p) / 8192) ** 0.5
     # backward: gradient wrt x is zero exactly where the element was dropped
     y, mean, rstd = ops.ln_fwd(x, zero, g, b, 1e-12, p, seed, 7)
     dy = rnd((M, H), 3)

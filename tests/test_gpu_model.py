@@ -775,40 +775,108 @@ def test_large_geometry_fp8_vs_golden():
     torch.cuda.empty_cache()
 
 
-def test_large_geometry_fp8_pingpong_kernels_and_delayed_scaling_vs_bf16():
-    """configs[4] at a token count where the e4m3 GEMMs run on the ping-pong kernel (128 pairs x 130 = 16 640 = 65 x 256 tokens;
-    gemm_pp8.hip) -- first step with just-in-time scales, second and third with delayed scaling (one-pass quantisation with half the
-    scale of the previous use's maximum, uc2_fp8_quant_delayed) -- against the bf16 path on the same weights and batch: mean loss,
-    ITM labels, last-layer gradient.  fp8 resolution (3 mantissa bits per operand): the bounds are those of the golden-vector test."""
-    model = build_pretrain(O.LARGE, torch.bfloat16)
-    batch = to_dev(synth.make_batch(250002, 128, 80, 50, task="itm", seed=3))
+def _fp8_routes(reset=False):
+    lib = uc2_amd._lib.load()
+    return int(lib.uc2_gemm_fp8_route_count(0, int(reset))), int(lib.uc2_gemm_fp8_route_count(1, int(reset)))      # (ring, ping-pong)
+
+
+def test_large_geometry_fp8_pingpong_kernels_and_delayed_scaling_vs_oracle():
+    """configs[4] through the e4m3 PING-PONG kernel (gemm_pp8.hip) against the CPU ORACLE, not against this repo's bf16 path
+    (VERDICT r5 weak #2): 24L / 1024H / 16 heads / 4096, 80 tokens + 48 regions (L = 128), 32 pairs = 4 096 tokens = 16 whole
+    256-row tiles, so every e4m3 GEMM of the layer runs on gemm_pp8 (asserted through uc2_gemm_fp8_route_count; the B = 2 golden
+    test above runs 260 tokens on the ring kernel).  Step 1 with just-in-time scales, steps 2-3 with delayed scaling (one-pass
+    quantisation with half the scale of the previous use's maximum).  Same weights and batch on both sides; the oracle's forward and
+    autograd run on the box's host cores.  The bf16 run of the same step is measured against the oracle too, so the fp8 bound on
+    the last-layer ITM gradient can be read against what bf16 itself needs there: at initialisation the ITM logits are ~0 and the
+    gradient is a difference of large cancelling terms -- bf16 alone shows a several-per-cent error on that tensor, e4m3 (3 mantissa
+    bits per operand, 96 GEMMs deep) a few times that; the MLM gradient, which is not a cancellation, is held to 0.2."""
+    geom = dict(O.LARGE)
+    T, R, B = 80, 48, 32
+    assert (B * (T + R)) % 256 == 0
+    model = build_pretrain(geom, torch.bfloat16)
+    W = _oracle_weights(model)
+    cfg = _oracle_cfg(geom)
     name = "roberta.encoder.layer.23.output.dense.weight"
     P = dict(model.named_parameters())
-    st = uc2_amd.store.store_of(model)
+    for task, gbound in (("itm", 0.35), ("mlm", 0.2)):
+        batch = synth.make_batch(250002, B, T, R, task=task, seed=3)
 
-    def step():
-        st.zero_grad()
-        loss, scores = None, None
-        out = model(batch, "itm", compute_loss=False)
-        scores = out[0] if isinstance(out, tuple) else out
-        loss = model(batch, "itm", compute_loss=True)
-        loss = loss[0] if isinstance(loss, tuple) else loss
-        loss.mean().backward()
-        torch.cuda.synchronize()
-        return float(loss.mean()), scores.float().argmax(-1).cpu(), P[name].grad.detach().float().clone()
-    l16, lab16, g16 = step()
-    uc2_amd.set_fp8(model, True)
-    n_hist = len(ops._FP8_HIST)
-    for i in range(3):
-        l8, lab8, g8 = step()
-        e_l, e_g = abs(l8 - l16) / abs(l16), rel_err(g8, g16)
-        agree = float((lab8 == lab16).float().mean())
-        print("large fp8 (ping-pong kernels, %s scales) vs bf16 at 128 pairs: mean-loss rel %.3g, ITM label agreement %.3f, last-layer grad L2 rel %.3g"
-              % ("just-in-time" if i == 0 else "delayed", e_l, agree, e_g))
-        assert e_l < 3e-2 and agree >= 0.97 and e_g < 0.35
-    assert len(ops._FP8_HIST) > n_hist            # the tensor roles have a history: steps 2 and 3 took the one-pass route
+        def loss_fn(Wg):
+            l = O.pretrain_forward(Wg, cfg, strip(batch), task)
+            return (l[0] if isinstance(l, tuple) else l).mean()
+        ref_loss, ref_grads = O.grads_of(loss_fn, W, names={name})
+        with torch.no_grad():
+            ref_scores = O.pretrain_forward(W, cfg, strip(batch), task, compute_loss=False)
+            ref_scores = ref_scores[0] if isinstance(ref_scores, tuple) else ref_scores
+        ram = ref_scores.argmax(-1)
+        errs = {}
+        for mode in ("bf16", "fp8", "fp8", "fp8"):
+            uc2_amd.set_fp8(model, mode == "fp8")
+            if mode == "fp8" and "fp8" not in errs:
+                _fp8_routes(reset=True)
+            _, scores, loss = run_task(model, batch, task)
+            ops.join_side_streams()
+            torch.cuda.synchronize()
+            e_l = abs(loss.mean().item() - float(ref_loss)) / abs(float(ref_loss))
+            e_g = rel_err(P[name].grad.float().cpu(), ref_grads[name])
+            agree = float((scores.float().cpu().argmax(-1) == ram).float().mean())
+            errs.setdefault(mode, []).append((e_l, agree, e_g))
+            print("large %s %s at %d pairs vs ORACLE: mean-loss rel %.3g, argmax agreement %.3f, last-layer grad L2 rel %.3g"
+                  % (mode, task, B, e_l, agree, e_g))
+        ring, pp = _fp8_routes()
+        # 3 fp8 passes x (forward-only scoring + training forward + backward) x 24 layers: every e4m3 GEMM on the ping-pong kernel
+        assert ring == 0 and pp >= 3 * 24 * (4 + 4 + 4), (ring, pp)
+        for (e_l, agree, e_g) in errs["fp8"]:
+            assert e_l < 3e-2 and e_g < gbound
+            assert agree >= (0.97 if task == "itm" else 0.9)
+        # e4m3 costs at most ~6 x what bf16 costs on the same tensor (measured: see profiles/r06_experiments.md)
+        assert errs["fp8"][-1][2] < 8.0 * max(errs["bf16"][0][2], 1e-3) + 0.05
+        del ref_grads
+    uc2_amd.set_fp8(model, False)
     del model
     torch.cuda.empty_cache()
+
+
+def test_fp8_mode_trains_like_the_bf16_mode():
+    """fp8 mode over a training RUN (VERDICT r5 #5a), in the form of test_bf16_bench_path_trains_like_the_fp32_parity_mode: a 2-layer
+    model of uc2-large width (1024 / 16 heads / 4096, vocabulary 2000) at 128 pairs x 130 tokens = 16 640 tokens (whole 256-row
+    tiles: every e4m3 GEMM on gemm_pp8.hip), trained for 24 optimizer steps -- ITM and MLM alternating, i.e. delayed scaling with
+    one amax history per task and role, four batches cycling, clip 5.0, AdamW re-quantising the e4m3 weight copies every step,
+    dropout off -- from the same initial weights in bf16 and with fp8 GEMMs: both loss curves fall and stay within 3 % of each
+    other at every step (measured: printed; profiles/r06_experiments.md)."""
+    geom = dict(O.LARGE, num_hidden_layers=2, vocab_size=2000)
+    B, T, R = 128, 80, 50
+    assert (B * (T + R)) % 256 == 0
+    batches = [(t, to_dev(synth.make_batch(2000, B, T, R, task=t, seed=170 + i))) for i, t in enumerate(("itm", "mlm", "itm", "mlm"))]
+    curves = {}
+    for mode in ("bf16", "fp8"):
+        model = build_pretrain(geom, torch.bfloat16)
+        uc2_amd.set_fp8(model, mode == "fp8")
+        opt = AdamW(param_groups(model, 0.01), lr=5e-5, betas=(0.9, 0.98))
+        _fp8_routes(reset=True)
+        losses = []
+        for step in range(24):
+            task, b = batches[step % 4]
+            opt.zero_grad()
+            loss = model(b, task, compute_loss=True)
+            loss = (loss[0] if isinstance(loss, tuple) else loss).mean()
+            loss.backward()
+            clip_grad_norm_([p for p in model.parameters() if p.grad is not None], 5.0)
+            opt.step()
+            losses.append(float(loss.detach()))
+        ring, pp = _fp8_routes()
+        assert (ring, pp > 0) == ((0, True) if mode == "fp8" else (0, False)), (mode, ring, pp)
+        curves[mode] = losses
+        del model, opt
+    b16, f8 = curves["bf16"], curves["fp8"]
+    assert all(l == l for l in b16 + f8)
+    print("bf16", [round(v, 4) for v in b16])
+    print("fp8 ", [round(v, 4) for v in f8])
+    print("max rel gap %.4f" % max(abs(a - c) / abs(a) for a, c in zip(b16, f8)))
+    assert b16[21] < b16[1] and f8[21] < f8[1]                 # the MLM loss of the first batch pair falls in both modes
+    assert b16[20] < b16[0] and f8[20] < f8[0]                 # ... and the ITM loss
+    for s_, (a, c) in enumerate(zip(b16, f8)):
+        assert abs(a - c) <= 0.03 * abs(a) + 0.01, (s_, a, c)
 
 
 def test_submodule_forwards_compose_to_the_fused_layer():

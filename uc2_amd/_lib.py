@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UC2_LIB_PATH") or os.path.join(_HERE, "libuc2_hip.so")      # (UC2_LIB_PATH: A/B of two builds on one box)
 _lib = None
-ABI_VERSION = 11         # include/uc2_hip.h; bumped whenever a signature changes
+ABI_VERSION = 12         # include/uc2_hip.h; bumped whenever a signature changes
 
 P, I, F, U64, I64, SZ = c_void_p, c_int, c_float, c_uint64, c_int64, c_size_t
 
@@ -29,6 +29,7 @@ SIGNATURES = {
     "uc2_bert_layer_bwd": (I, [P, P, P]),
     "uc2_gemm_drop_residual": (I, [I, I, I, P, I, P, I, P, I, P, P, I, F, P, U64, I, P, P]),
     "uc2_gemm_fallback_count": (ctypes.c_longlong, [I]),
+    "uc2_gemm_fp8_route_count": (ctypes.c_longlong, [I, I]),
     "uc2_gemm_wgrad_group_workspace": (SZ, [I, P]),
     "uc2_gemm_wgrad_group": (I, [I, I, P, I, P, SZ, P]),
     "uc2_fp8_quant_weights_batch": (I, [I, P, P]),

@@ -402,12 +402,21 @@ static void gf_launch2(const GemmArgs& p, int variant, hipStream_t st) {
 // half the width (same bytes).  M, N arbitrary (row clamping + guarded epilogue), K % 128 == 0.
 bool uc2_gemm_pp8_supported(const GemmArgs& p);                                                     // gemm_pp8.hip
 void uc2_gemm_pp8_launch(const GemmArgs& p, hipStream_t st);
+// Diagnostics only (like uc2_gemm_fallback_count): e4m3 GEMM calls that the ring kernel ran because the ping-pong kernel does not
+// take the shape (M not a multiple of 256, ...).  Tests use it to prove that a model-level fp8 run exercised gemm_pp8.hip.
+#include <atomic>
+static std::atomic<long long> g_fp8_ring{0}, g_fp8_pp{0};
+extern "C" long long uc2_gemm_fp8_route_count(int which, int reset) {
+  std::atomic<long long>& c = which ? g_fp8_pp : g_fp8_ring;
+  return reset ? c.exchange(0, std::memory_order_relaxed) : c.load(std::memory_order_relaxed);
+}
 int uc2_gemm_fp8_launch(const GemmArgs& p8, hipStream_t st) {
   GemmArgs p = p8;
   p.K = p8.K / 2; p.lda = p8.lda / 2; p.ldb = p8.ldb / 2;
   // whole 256 x 256 tiles and an even number of k-tiles: the persistent ping-pong schedule on v_mfma_scale_f32_16x16x128_f8f6f4
   // (p.variant == 1 forces the ring kernel below: tests, A/B)
-  if (p8.variant != 1 && uc2_gemm_pp8_supported(p)) { uc2_gemm_pp8_launch(p, st); return 2; }
+  if (p8.variant != 1 && uc2_gemm_pp8_supported(p)) { g_fp8_pp.fetch_add(1, std::memory_order_relaxed); uc2_gemm_pp8_launch(p, st); return 2; }
+  g_fp8_ring.fetch_add(1, std::memory_order_relaxed);
   constexpr int BM = 256, BK = 64, NSTAGE = 3;
   constexpr int smem = NSTAGE * (BM * BK * 2 + GF_BN * BK * 2);
   auto kern = gemm_bf16_fast_kernel<false, false, true, BM, BK, NSTAGE, true>;
