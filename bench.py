@@ -453,6 +453,7 @@ def main():
     import torch.distributed as dist
     beat()                                             # (the first import of torch on a fresh box can take minutes)
     from uc2_amd import ops
+    from uc2_amd.config import cfg as knobs, state
     from uc2_amd.model.model import VLXLMRForPretraining
     from uc2_amd.optim.adamw import AdamW, clip_grad_norm_
     from uc2_amd.optim.misc import param_groups
@@ -500,8 +501,8 @@ def main():
     # the all-reduces overlap the backward GEMMs and hold CUs while they run: the persistent GEMM takes its work items from
     # the per-XCD queue then (include/uc2_hip.h uc2_gemm_queued; scratch/exp9.py: +25 % per launch with the static stride
     # under contention, +0 % with the queue).  At N = 1 nothing competes for CUs and the static stride is kept.
-    if world > 1 and os.environ.get("UC2_GEMM_QUEUE", "1") != "0":
-        ops.GEMM_QUEUE = True
+    if world > 1 and knobs.gemm_queue_allowed:
+        knobs.gemm_queue = True
     beat()
     ops.rng.manual_seed(20260101 + rank, dev)              # dropout streams differ per rank
     torch.manual_seed(0)                                   # weights seed 0 (random init, N(0, 0.02))
@@ -583,10 +584,9 @@ def main():
         opt_step([batches[i % 2]], a.task)
     gtimer, htimer = ops.GemmTimer(), ops.HbmTimer()
     fence()
-    ops.GEMM_TIMER, ops.HBM_TIMER = gtimer, htimer
+    state.gemm_timer, state.hbm_timer = gtimer, htimer
     ms0 = torch.cuda.memory_stats(dev)
-    from uc2_amd.utils import distributed as D
-    D.COMM_TIMER = comm_events = []     # HIP events around what is left of the gradient all-reduce when backward has ended (exposed)
+    state.comm_timer = comm_events = []     # HIP events around what is left of the gradient all-reduce when backward has ended (exposed)
     ops.gemm_fallbacks(reset=True)
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -595,12 +595,12 @@ def main():
     dt = time.perf_counter() - t0
     ms1 = torch.cuda.memory_stats(dev)
     # device allocations (hipMalloc calls of the caching allocator) inside the timed region: 0 in a settled run
-    D.COMM_TIMER = None
+    state.comm_timer = None
     comm_exposed_ms = sum(e0.elapsed_time(e1) for e0, e1 in comm_events) / max(a.steps, 1)
     gemm_fallbacks = ops.gemm_fallbacks()          # GEMM calls of the timed region whose ping-pong plan another kernel ran (0 expected)
     dev_allocs = int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0))
     dev_alloc_mb = (ms1.get("reserved_bytes.all.peak", 0) - ms0.get("reserved_bytes.all.current", 0)) / 2 ** 20
-    ops.GEMM_TIMER, ops.HBM_TIMER = None, None
+    state.gemm_timer, state.hbm_timer = None, None
     # per-rank record of the timed region (the first SCALE run must be diagnosable from the one line rank 0 prints): each rank's own
     # wall time per step, the exposed part of its all-reduce, and what the exposed tail carried
     tail_elems = 0
@@ -622,27 +622,27 @@ def main():
     assert lossv == lossv, "loss is NaN"
 
     # ------------------------------------------------------------------ per-kernel pass (roofline object)
-    # In the timed region the weight-gradient GEMMs run on a side stream beside the main stream's kernels (ops.WGRAD_SIDE_STREAM):
+    # In the timed region the weight-gradient GEMMs run on a side stream beside the main stream's kernels (knobs.wgrad_side_stream):
     # a launch's begin-to-end time then includes time in which the kernel shared the chip, and flops / duration says nothing
     # about the kernel.  The per-kernel figures therefore come from `k_pass` extra steps of the SAME step with the weight
     # gradients on the main stream (one kernel at a time), directly after the timed region; `value` is the timed region's.
-    overlapped = bool(ops.WGRAD_SIDE_STREAM) and a.batch * (T_TXT + N_REG) >= ops.WGRAD_SIDE_MIN_ROWS
+    overlapped = bool(knobs.wgrad_side_stream) and a.batch * (T_TXT + N_REG) >= knobs.wgrad_side_min_rows
     gtimer_tr, htimer_tr = gtimer, htimer
     k_pass = 0
     if overlapped:
         k_pass = max(2, min(a.steps, 5))
-        side_was, ops.WGRAD_SIDE_STREAM = ops.WGRAD_SIDE_STREAM, False
+        side_was, knobs.wgrad_side_stream = knobs.wgrad_side_stream, False
         opt_step([batches[0]], a.task)                        # (one untimed step in the serial mode)
         gtimer, htimer = ops.GemmTimer(), ops.HbmTimer()
         fence()
-        ops.GEMM_TIMER, ops.HBM_TIMER = gtimer, htimer
+        state.gemm_timer, state.hbm_timer = gtimer, htimer
         t1 = time.perf_counter()
         for i in range(k_pass):
             opt_step([batches[i % 2]], a.task)
         fence()
         dt_pass = time.perf_counter() - t1
-        ops.GEMM_TIMER, ops.HBM_TIMER = None, None
-        ops.WGRAD_SIDE_STREAM = side_was
+        state.gemm_timer, state.hbm_timer = None, None
+        knobs.wgrad_side_stream = side_was
 
     # ------------------------------------------------------------------ other workloads (extra keys, not `value`)
     workloads = {}
@@ -705,14 +705,14 @@ def main():
                 "micro_batch_pairs": REF_MICRO, "accumulation_steps": REF_ACCUM, "steps": k3,
                 "mfma_frac_encoder": round(REF_MICRO * REF_ACCUM * world * k3 / d3 * ENC_GFLOP_PER_PAIR * 1e9
                                            / (world * PEAK_BF16_TFLOPS * 1e12), 4),
-                "accumulation_overlap": bool(ops.ACCUM_OVERLAP),
+                "accumulation_overlap": bool(knobs.accum_overlap),
                 "note": "the reference's own regime, its loop as written (forward, backward, forward, backward, ...; pretrain.py:514-566): "
                         "%d-pair micro-batches x %d accumulation micro-steps per optimizer step (config/uc2_pretrain.json:17-19), all-reduce "
                         "+ clip + AdamW once per window; the models run forward i+1 beside backward i on two streams (ops.accum_pass)"
                         % (REF_MICRO, REF_ACCUM)}
-        # the same windows with the accumulation overlap off (ops.ACCUM_OVERLAP: every pass on the caller's stream, the round-5
+        # the same windows with the accumulation overlap off (knobs.accum_overlap: every pass on the caller's stream, the round-5
         # behaviour) -- the in-run A/B of what the unchanged loop gains from forward i+1 running beside backward i
-        ov_was, ops.ACCUM_OVERLAP = ops.ACCUM_OVERLAP, False
+        ov_was, knobs.accum_overlap = knobs.accum_overlap, False
         try:
             for t in ("itm", "mlm"):
                 d3, _ = timed(lambda i: opt_step(rb[t], t), max(w2, 2), k3)
@@ -722,7 +722,7 @@ def main():
                                                / (world * PEAK_BF16_TFLOPS * 1e12), 4),
                     "note": "the same window with UC2_ACCUM_OVERLAP=0: every forward and backward on one stream (rounds 1-5)"}
         finally:
-            ops.ACCUM_OVERLAP = ov_was
+            knobs.accum_overlap = ov_was
         del rb
         # ---- BASELINE.json configs[2] as SURVEY.md 8(d) specifies it, on this GPU: the pretrain task mix itm : mlm : vmlm : tlm =
         # 9 : 12 : 9 : 3 (config/uc2_pretrain.json:72-76,100-102), one task per accumulation window like MetaLoader
@@ -809,7 +809,7 @@ def main():
                        "pairs_per_gpu_per_step": a.batch, "global_batch": a.batch * world,
                        "seq_len": T_TXT + N_REG, "parallelism": "dp%d" % world, "final_loss": round(lossv, 4), "replicas_in_sync": in_sync,
                        "gradient_allreduce": comm_path, "rccl_ranks": rccl_ranks, "rccl_version": rccl_version,
-                       "gemm_item_queue": bool(ops.GEMM_QUEUE), "gemm_fallbacks": gemm_fallbacks,
+                       "gemm_item_queue": bool(knobs.gemm_queue), "gemm_fallbacks": gemm_fallbacks,
                        "comm_exposed_ms_per_step": round(comm_exposed_ms, 3),
                        "allreduce_tail": tail_mode,
                        "allreduce_tail_bytes": tail_elems * (2 if tail_mode == "bf16" else 4),

@@ -57,7 +57,7 @@ int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, const voi
  *              10, 11, 13 and 14 were experiment kernels -- rolling epilogue, two phases per k-tile, one wave per SIMD with and without
  *              the epilogue in the next item's MFMA gaps: experiments/csrc/, built only by `make EXPERIMENTS=1` -- and are
  *              argument errors in the shipped library, like every other number not listed).  A variant that does not
- *              support the shape falls back to the generic kernel.  uc2_amd/ops.py::gemm_plan picks it per shape.
+ *              support the shape falls back to the generic kernel.  uc2_amd/ops/gemm.py::gemm_plan picks it per shape.
  *   workspace  optional caller-owned device memory (>= split_k*M*N*4 bytes, 16-byte aligned) for split-K weight
  *              gradients: partial tiles are stored plainly and reduced in a second pass instead of fp32 atomics
  *              (bit-reproducible); NULL = atomics.
@@ -163,7 +163,7 @@ int uc2_gemm_fp8(int M, int N, int K, const void* A8, int lda, const void* B8, i
                  int ldaux, int flags, void* stream);
 
 /* ---- One BertLayer per call (model/layer.py:159-170: BertAttention -> BertIntermediate -> BertOutput) ---------------------------
- * The launch sequence of uc2_amd/ops.py BertLayerFn -- 7 launches forward, 8 backward -- enqueued by one C call per direction: the same
+ * The launch sequence of uc2_amd/ops/layer.py BertLayerFn -- 7 launches forward, 8 backward -- enqueued by one C call per direction: the same
  * kernels with the same arguments in the same order as the per-kernel entry points above, hence the same bits.  It exists for the host:
  * at the reference's 104-pair micro-batches (config/uc2_pretrain.json:17-19) an optimizer step is ~700 launches of 10-170 us and the
  * per-launch Python/ctypes path is within 15 % of the device time.  The caller keeps every decision: it allocates all activations and
@@ -171,7 +171,7 @@ int uc2_gemm_fp8(int M, int N, int K, const void* A8, int lda, const void* B8, i
  * for uc2_gemm: the library holds no kernel-selection state), runs the four weight gradients itself (uc2_gemm_wgrad_group on
  * (d_o2, u), (d_pre, a), (d_o1, ctx), (dqkv, x)) and the second stage of the two LayerNorm backwards (uc2_ln_bwd_reduce* on ws2 ->
  * dg2 / db2 / d(bf), ws1 -> dg1 / db1 / d(bo)).  Weights in the compute dtype ([out, in], q|k|v stacked), biases / LayerNorm fp32.
- * The plain route only: no fp8, no head-interleaved q|k|v, no fused dropout-residual tails (those stay in uc2_amd/ops.py). */
+ * The plain route only: no fp8, no head-interleaved q|k|v, no fused dropout-residual tails (those stay in uc2_amd/ops/layer.py). */
 typedef struct Uc2GemmPlan { int variant, split_k, flags; } Uc2GemmPlan;
 typedef struct Uc2BertLayer {
   int dtype, B, L, H, nh, I, attn_impl;                 /* I: intermediate size; attn_impl as uc2_attn_fwd */
@@ -220,7 +220,7 @@ int uc2_ln_bwd(int dtype, int M, int H, const void* dy, const void* x, const voi
                void* stream);
 /* uc2_ln_bwd in its two stages: _partial writes dx / dres and per-workgroup partial column sums into ws (want_dbias: those of dx
  * too); _reduce adds them into dgamma / dbeta / dbias (+=).  Nothing downstream in a backward pass reads the three vectors, so the
- * second stage may run on another stream (the caller orders it after the first): uc2_amd/ops.py puts it on the weight-gradient
+ * second stage may run on another stream (the caller orders it after the first): uc2_amd/ops/kernels.py puts it on the weight-gradient
  * side stream, off the input-gradient chain.  uc2_ln_bwd == both on one stream. */
 int uc2_ln_bwd_partial(int dtype, int M, int H, const void* dy, const void* x, const void* residual, const float* gamma,
                        const float* mean, const float* rstd, float drop_p, int drop_after, const uint64_t* seed_ptr,

@@ -40,7 +40,7 @@ def test_bench_self_launches_ranks_and_replicas_stay_in_sync(ranks, batch):
 
 
 def test_bench_two_ranks_side_stream_route_stays_in_sync():
-    """2 ranks at 176 pairs each (16 896 tokens >= ops.WGRAD_SIDE_MIN_ROWS): the route the 8-GPU bench takes -- weight gradients on
+    """2 ranks at 176 pairs each (16 896 tokens >= knobs.wgrad_side_min_rows): the route the 8-GPU bench takes -- weight gradients on
     the side stream, each layer's all-reduce ordered behind BOTH streams (ops.pending_side_stream; the main stream is not joined),
     W^T input gradients, attention backward on its work queue -- with the replicas bit-identical afterwards"""
     import torch

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from uc2_amd import ops
+from uc2_amd.config import cfg as knobs, state
 from uc2_amd.utils import synth
 from util import max_rel, rel_err
 
@@ -106,7 +107,7 @@ def test_layernorm_fwd_bwd(dtype, M, H, with_res):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_layernorm_deferred_reductions_one_launch(dtype):
-    """the micro-batch route (ops.LN_REDUCE_BATCH): inside a backward pass the second stages of the LayerNorm backwards are collected
+    """the micro-batch route (knobs.ln_reduce_batch): inside a backward pass the second stages of the LayerNorm backwards are collected
     and go out as one uc2_ln_bwd_reduce_batch launch from the end-of-pass callback -- same dgamma / dbeta / dbias as the immediate
     reductions (sums of the same partial rows; the atomics' order differs), different M and NULL outputs in one batch, nothing
     left pending afterwards; outside a pass nothing is deferred"""
@@ -810,17 +811,17 @@ def test_gemm_item_queue_gives_the_same_result_and_is_left_zeroed(ta, tb, M, N, 
         for _ in range(3):                               # repeated launches reuse the queue
             ops.gemm(a, b, M, N, K, ta=ta, tb=tb, bias=bias, out=out, accumulate=wg, split_k=split, variant=8)
         return out
-    was = ops.GEMM_QUEUE
-    ops.GEMM_QUEUE = False
+    was = knobs.gemm_queue
+    knobs.gemm_queue = False
     try:
         ref = run()
-        ops.GEMM_QUEUE = True
+        knobs.gemm_queue = True
         got = run()
         q = ops._gemm_queue(a.device)
         torch.cuda.synchronize()
         assert int(q.abs().sum()) == 0
     finally:
-        ops.GEMM_QUEUE = was
+        knobs.gemm_queue = was
     assert torch.equal(got, ref)
 
 
@@ -944,9 +945,9 @@ def test_attention_bwd_work_queue_matches_static_partition():
     ctx, lse = ops.attn_fwd(qkv, mask, B, L, nh, D, 0.1, seed, 5, impl=2)
     ref_db = torch.zeros(3 * H, device=DEV)
     ref = ops.attn_bwd(qkv, mask, ctx, dctx, lse, B, L, nh, D, 0.1, seed, 5, impl=2, dbias=ref_db)
-    was = ops.GEMM_QUEUE
+    was = knobs.gemm_queue
     try:
-        ops.GEMM_QUEUE = True
+        knobs.gemm_queue = True
         for _ in range(3):
             db = torch.zeros(3 * H, device=DEV)
             got = ops.attn_bwd(qkv, mask, ctx, dctx, lse, B, L, nh, D, 0.1, seed, 5, impl=2, dbias=db)
@@ -955,7 +956,7 @@ def test_attention_bwd_work_queue_matches_static_partition():
             assert rel_err(db, ref_db) < 1e-5
             assert int(ops._gemm_queue(qkv.device).abs().sum()) == 0
     finally:
-        ops.GEMM_QUEUE = was
+        knobs.gemm_queue = was
 
 
 @pytest.mark.parametrize("impl,dtype", [(2, torch.bfloat16), (1, torch.bfloat16), (1, torch.float32)])
@@ -1101,10 +1102,10 @@ def test_gemm_pingpong_skew_and_deferred_reduce():
     acc = rnd((Mo, No), 7)
     fused = ops.gemm(x, y, Mo, No, Kt, ta=True, tb=True, out=acc.clone(), accumulate=True, split_k=8, variant=8)
     try:
-        ops.GEMM_TIMER = ops.GemmTimer()                 # the timer path defers the reduction pass
+        state.gemm_timer = ops.GemmTimer()                 # the timer path defers the reduction pass
         deferred = ops.gemm(x, y, Mo, No, Kt, ta=True, tb=True, out=acc.clone(), accumulate=True, split_k=8, variant=8)
     finally:
-        ops.GEMM_TIMER = None
+        state.gemm_timer = None
     assert torch.equal(fused, deferred)
     # raw C-ABI call without a workspace: atomics
     out = acc.clone()
@@ -1380,7 +1381,7 @@ def test_attention_fused_e4m3_outputs(B, L, nh, D, p, request):
     ctx0, lse0 = ops.attn_fwd(qkv, mask, B, L, nh, D, p, seed if p else None, 3)
     dq0 = ops.attn_bwd(qkv, mask, ctx0, dctx, lse0, B, L, nh, D, p, seed if p else None, 3)
     C = ops.AMAX_CELLS
-    was, ops.FP8_ATTN_FUSED = ops.FP8_ATTN_FUSED, True                   # (off by default: measured break-even on uc2-large)
+    was, knobs.fp8_attn_fused = knobs.fp8_attn_fused, True                   # (off by default: measured break-even on uc2-large)
     request.addfinalizer(lambda: setattr(ops, "FP8_ATTN_FUSED", was))
     for which in ("fwd", "bwd"):
         key = ("test-attn-q", which, B, L)

@@ -15,6 +15,7 @@ import uc2_amd
 from oracle import specs
 from oracle import uc2_oracle as O
 from uc2_amd import ops
+from uc2_amd.config import cfg as knobs, state
 from uc2_amd.model.itm import VLXLMRForImageTextRetrieval
 from uc2_amd.model.layer import BertLayer
 from uc2_amd.model.model import VLXLMRConfig, VLXLMRForPretraining
@@ -109,7 +110,7 @@ def test_bert_layer_dropout_runs_and_is_reproducible():
 
 
 def test_bert_layer_backward_paths_at_bench_token_counts():
-    """One base-geometry BertLayer at 176 x 96 = 16 896 tokens (>= ops.WGRAD_SIDE_MIN_ROWS): the backward the bench step runs --
+    """One base-geometry BertLayer at 176 x 96 = 16 896 tokens (>= knobs.wgrad_side_min_rows): the backward the bench step runs --
     input gradients on the k-contiguous weight copies W^T (ParamStore.compute_t), weight gradients on the side stream -- against the
     same layer with W read k-strided and everything on one stream, and against the grouped weight-gradient launch forced on at
     this size.  Same dropout masks (same seed), bf16: dx and every parameter gradient agree to bf16 rounding of the GEMM outputs."""
@@ -124,10 +125,10 @@ def test_bert_layer_backward_paths_at_bench_token_counts():
     dy = (synth.det_normal((B, L, H), 4) * 0.1).to(DEV).to(torch.bfloat16)
 
     def run(wt, side, group_rows):
-        saved = (ops.DGRAD_TRANSPOSED_W, ops.WGRAD_SIDE_STREAM, ops.WGRAD_SIDE_MIN_ROWS)
-        ops.DGRAD_TRANSPOSED_W, ops.WGRAD_SIDE_STREAM = wt, side
+        saved = (knobs.dgrad_transposed_w, knobs.wgrad_side_stream, knobs.wgrad_side_min_rows)
+        knobs.dgrad_transposed_w, knobs.wgrad_side_stream = wt, side
         if group_rows is not None:
-            ops.WGRAD_SIDE_MIN_ROWS = group_rows          # (the grouped launch and W^T are both gated by this threshold)
+            knobs.wgrad_side_min_rows = group_rows          # (the grouped launch and W^T are both gated by this threshold)
         try:
             layer.zero_grad()
             x = x0.clone().requires_grad_(True)
@@ -138,7 +139,7 @@ def test_bert_layer_backward_paths_at_bench_token_counts():
             torch.cuda.synchronize()
             return y.detach().clone(), x.grad.clone(), OrderedDict((n, p.grad.detach().clone()) for n, p in layer.named_parameters())
         finally:
-            ops.DGRAD_TRANSPOSED_W, ops.WGRAD_SIDE_STREAM, ops.WGRAD_SIDE_MIN_ROWS = saved
+            knobs.dgrad_transposed_w, knobs.wgrad_side_stream, knobs.wgrad_side_min_rows = saved
     y_ref, dx_ref, g_ref = run(False, False, None)                  # W k-strided, one stream, one GEMM per weight gradient
     for (wt, side, rows) in ((True, True, None), (False, False, 1 << 30)):          # bench path; grouped weight gradients
         y, dx, g = run(wt, side, rows)
@@ -151,7 +152,7 @@ def test_bert_layer_backward_paths_at_bench_token_counts():
 
 
 def test_bert_layer_fused_dropout_residual_tails_vs_unfused():
-    """ops.LN_FUSE (from ops.LN_FUSE_MIN_ROWS tokens): the Wo and FFN2 GEMMs write dropout(dense) + residual, the LayerNorm kernels
+    """knobs.ln_fuse (from knobs.ln_fuse_min_rows tokens): the Wo and FFN2 GEMMs write dropout(dense) + residual, the LayerNorm kernels
     read that one tensor.  Same dropout masks as the unfused tails (same seed and sites); the sum is rounded to bf16 once where the
     unfused form rounds the dense output: layer output, dx and every parameter gradient agree to bf16 rounding
     (base geometry, 176 x 96 tokens, dropout on; forward-only route too)"""
@@ -161,14 +162,14 @@ def test_bert_layer_fused_dropout_residual_tails_vs_unfused():
     layer.to(DEV).train()
     set_compute_dtype(layer, torch.bfloat16)
     B, L, H = 176, 96, 768
-    assert B * L >= ops.LN_FUSE_MIN_ROWS
+    assert B * L >= knobs.ln_fuse_min_rows
     x0 = (synth.det_normal((B, L, H), 3) * 0.5).to(DEV).to(torch.bfloat16)
     ext = torch.zeros(B, 1, 1, L, device=DEV)
     ext[::5, :, :, L - 11:] = -10000.0
     dy = (synth.det_normal((B, L, H), 4) * 0.1).to(DEV).to(torch.bfloat16)
 
     def run(on):
-        was, ops.LN_FUSE = ops.LN_FUSE, (3 if on else 0)
+        was, knobs.ln_fuse = knobs.ln_fuse, (3 if on else 0)
         try:
             layer.zero_grad()
             x = x0.clone().requires_grad_(True)
@@ -182,7 +183,7 @@ def test_bert_layer_fused_dropout_residual_tails_vs_unfused():
                 yf = layer(x0, ext)
             return y.detach().clone(), x.grad.clone(), OrderedDict((n, p.grad.detach().clone()) for n, p in layer.named_parameters()), yf
         finally:
-            ops.LN_FUSE = was
+            knobs.ln_fuse = was
     y0, dx0, g0, yf0 = run(False)
     y1, dx1, g1, yf1 = run(True)
     assert not torch.equal(y1, y0)                                   # (the fused route really ran: another rounding point)
@@ -197,7 +198,7 @@ def test_bert_layer_fused_dropout_residual_tails_vs_unfused():
 
 @pytest.mark.parametrize("dtype,geom,B,L", [(torch.bfloat16, O.BASE, 104, 96), (torch.bfloat16, O.TINY, 5, 68), (torch.float32, O.TINY, 5, 68)])
 def test_bert_layer_native_entry_is_bit_identical(dtype, geom, B, L):
-    """uc2_bert_layer_fwd / uc2_bert_layer_bwd (ops.NATIVE_LAYER: one C call per layer and direction at the reference's micro-batch
+    """uc2_bert_layer_fwd / uc2_bert_layer_bwd (knobs.native_layer: one C call per layer and direction at the reference's micro-batch
     sizes, config/uc2_pretrain.json:17-19) against the per-kernel calls of BertLayerFn: the same kernels with the same arguments in
     the same order -- layer output, dx and every weight gradient bit-identical (dropout on, key mask, forward-only route unchanged)"""
     cfg = make_cfg(geom, drop=0.1)
@@ -215,7 +216,7 @@ def test_bert_layer_native_entry_is_bit_identical(dtype, geom, B, L):
     lib = _lib.load()
 
     def run(on):
-        was, ops.NATIVE_LAYER = ops.NATIVE_LAYER, on
+        was, knobs.native_layer = knobs.native_layer, on
         try:
             outs = []
             for need_dx in (True, False):
@@ -230,8 +231,8 @@ def test_bert_layer_native_entry_is_bit_identical(dtype, geom, B, L):
                              OrderedDict((n, p.grad.detach().clone()) for n, p in layer.named_parameters())))
             return outs
         finally:
-            ops.NATIVE_LAYER = was
-    assert ops._native_layer_ok(dtype, B * L, False, None) == ops.NATIVE_LAYER
+            knobs.native_layer = was
+    assert ops._native_layer_ok(dtype, B * L, False, None) == knobs.native_layer
     ref = run(False)
     nat = run(True)
     for (y0, dx0, g0), (y1, dx1, g1) in zip(ref, nat):
@@ -248,7 +249,7 @@ def test_bert_layer_native_entry_is_bit_identical(dtype, geom, B, L):
 
 
 def test_bert_layer_interleaved_qkv_route_is_bit_identical():
-    """ops.QKV_INTERLEAVED (from 16 384 tokens): the QKV GEMM on the row-permuted weight copy, attention on head-interleaved q|k|v,
+    """knobs.qkv_interleaved (from 16 384 tokens): the QKV GEMM on the row-permuted weight copy, attention on head-interleaved q|k|v,
     dWqkv un-permuted by its split-K reduction, dX through W'^T -- same dot products in the same order as the plain layout: the
     layer output and every parameter gradient bit-identical, dx up to the summation order of its contraction over the interleaved
     index (base geometry, 176 x 96 tokens, dropout on, side stream on)"""
@@ -264,7 +265,7 @@ def test_bert_layer_interleaved_qkv_route_is_bit_identical():
     dy = (synth.det_normal((B, L, H), 4) * 0.1).to(DEV).to(torch.bfloat16)
 
     def run(on):
-        was, ops.QKV_INTERLEAVED = ops.QKV_INTERLEAVED, on
+        was, knobs.qkv_interleaved = knobs.qkv_interleaved, on
         try:
             layer.zero_grad()
             x = x0.clone().requires_grad_(True)
@@ -275,7 +276,7 @@ def test_bert_layer_interleaved_qkv_route_is_bit_identical():
             torch.cuda.synchronize()
             return y.detach().clone(), x.grad.clone(), OrderedDict((n, p.grad.detach().clone()) for n, p in layer.named_parameters())
         finally:
-            ops.QKV_INTERLEAVED = was
+            knobs.qkv_interleaved = was
     y0, dx0, g0 = run(False)
     y1, dx1, g1 = run(True)
     assert torch.equal(y1, y0)
@@ -289,11 +290,11 @@ def test_bert_layer_interleaved_qkv_route_is_bit_identical():
     with torch.no_grad():                                                       # forward-only route (scoring / validation)
         layer.eval()
         a = layer(x0, ext)
-        was, ops.QKV_INTERLEAVED = ops.QKV_INTERLEAVED, False
+        was, knobs.qkv_interleaved = knobs.qkv_interleaved, False
         try:
             b = layer(x0, ext)
         finally:
-            ops.QKV_INTERLEAVED = was
+            knobs.qkv_interleaved = was
         assert torch.equal(a, b)
 
 
@@ -669,7 +670,7 @@ def test_bf16_measured_kernels_vs_oracle_at_128_pairs():
 
 def test_bf16_measured_kernels_gradients_vs_oracle_at_176_pairs():
     """GRADIENTS through the measured kernels against the oracle's backward (not against another path of this repo): 176 pairs =
-    16 896 tokens >= ops.WGRAD_SIDE_MIN_ROWS, so the backward is the one bench.py times -- input gradients on the k-contiguous
+    16 896 tokens >= knobs.wgrad_side_min_rows, so the backward is the one bench.py times -- input gradients on the k-contiguous
     W^T copies (variant 12 with the gelu'-multiply / residual epilogues), weight gradients as split-K launches of the ping-pong
     kernel on the side stream, attention backward with the fused q|k|v bias gradient, LayerNorm backward with the dense-bias column
     sums.  12 layers, vocabulary 250 002, dropout 0, same weights and batch on both sides; the oracle's autograd runs on the box's
@@ -677,7 +678,7 @@ def test_bf16_measured_kernels_gradients_vs_oracle_at_176_pairs():
     tensor <= 7 % (ITM) / 3 % (MLM); measured values are printed.  Reference: model/layer.py:159-170, model/model.py:571-598,690-735."""
     B = 176
     M = B * 96
-    assert M >= ops.WGRAD_SIDE_MIN_ROWS and ops.WGRAD_SIDE_STREAM and ops.DGRAD_TRANSPOSED_W
+    assert M >= knobs.wgrad_side_min_rows and knobs.wgrad_side_stream and knobs.dgrad_transposed_w
     model = build_pretrain(O.BASE, torch.bfloat16)
     W = _oracle_weights(model)
     cfg = _oracle_cfg(O.BASE)
@@ -1094,7 +1095,7 @@ def test_bf16_bench_path_trains_like_the_fp32_parity_mode():
     weights in fp32 and in bf16: the two loss curves stay together and both fall."""
     geom = dict(O.BASE, num_hidden_layers=2, vocab_size=2000)
     B, T, R = 176, 60, 36
-    assert B * (T + R) >= max(ops.LN_FUSE_MIN_ROWS, ops.WGRAD_SIDE_MIN_ROWS)
+    assert B * (T + R) >= max(knobs.ln_fuse_min_rows, knobs.wgrad_side_min_rows)
     batches = [(t, to_dev(synth.make_batch(2000, B, T, R, task=t, seed=70 + i))) for i, t in enumerate(("itm", "mlm", "itm", "mlm"))]
     curves = {}
     for dtype in (torch.float32, torch.bfloat16):
@@ -1126,7 +1127,7 @@ def test_bf16_bench_path_trains_like_the_fp32_parity_mode():
 def test_accumulation_overlap_equals_the_sequential_loop(task):
     """ops.accum_pass (round 6): the reference's accumulation loop AS WRITTEN (pretrain.py:514-566: forward, backward, forward,
     backward, ...) with each training forward on one of the two overlap streams, so that forward i+1 runs beside backward i,
-    against the same loop on one stream (ops.ACCUM_OVERLAP off).  Same kernels, same accumulation order: bit-identical losses and
+    against the same loop on one stream (knobs.accum_overlap off).  Same kernels, same accumulation order: bit-identical losses and
     gradients, fp32 and bf16; the passes really ran on the overlap streams; consumers of gradients (clip, optimizer) are ordered
     behind both streams; with dropout on, the three forwards draw distinct masks and equal the one-stream loop's."""
     from uc2_amd.store import store_of
@@ -1144,12 +1145,12 @@ def test_accumulation_overlap_equals_the_sequential_loop(task):
         grads = OrderedDict((n, p.grad.detach().clone()) for n, p in model.named_parameters() if p.grad is not None)
         torch.cuda.synchronize()
         return [float(l) for l in losses], grads, float(norm)
-    was = ops.ACCUM_OVERLAP
+    was = knobs.accum_overlap
     try:
         for dtype, drop in ((torch.float32, 0.0), (torch.bfloat16, 0.0), (torch.bfloat16, 0.1)):
             res = {}
             for overlap in (False, True):
-                ops.ACCUM_OVERLAP = overlap
+                knobs.accum_overlap = overlap
                 model = VLXLMRForPretraining(make_cfg(geom, drop=drop), img_dim=2048, img_label_dim=1601)
                 synth.det_init_(model)
                 model.to(DEV).train()
@@ -1172,7 +1173,7 @@ def test_accumulation_overlap_equals_the_sequential_loop(task):
             if drop:
                 assert len(set(l1)) == 3, l1                      # three forwards of one batch: three different masks
     finally:
-        ops.ACCUM_OVERLAP = was
+        knobs.accum_overlap = was
 
 
 def test_accumulation_overlap_stays_off_where_it_must():
@@ -1211,12 +1212,12 @@ def test_accumulation_overlap_stays_off_where_it_must():
     fwd().backward()
     set_fp8(model, False)
     assert passes() == n0 + 1
-    was = ops.ACCUM_OVERLAP_MAX_ROWS
-    ops.ACCUM_OVERLAP_MAX_ROWS = 8 * 60                         # this batch is 8 x 60 tokens: at the threshold -> off
+    was = knobs.accum_overlap_max_rows
+    knobs.accum_overlap_max_rows = 8 * 60                         # this batch is 8 x 60 tokens: at the threshold -> off
     try:
         fwd().backward()
     finally:
-        ops.ACCUM_OVERLAP_MAX_ROWS = was
+        knobs.accum_overlap_max_rows = was
     assert passes() == n0 + 1
     order = []
     out = accumulate([fwd, fwd], before_backward=order.append)

@@ -10,8 +10,10 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void
 
 import torch
 
+from .config import cfg
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("UC2_LIB_PATH") or os.path.join(_HERE, "libuc2_hip.so")      # (UC2_LIB_PATH: A/B of two builds on one box)
+LIB_PATH = cfg.lib_path      # (UC2_LIB_PATH: A/B of two builds on one box)
 _lib = None
 ABI_VERSION = 12         # include/uc2_hip.h; bumped whenever a signature changes
 

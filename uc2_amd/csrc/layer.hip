@@ -1,4 +1,4 @@
-// One BertLayer per call: the launch sequences of uc2_amd/ops.py BertLayerFn (model/layer.py:159-170 of the reference:
+// One BertLayer per call: the launch sequences of uc2_amd/ops/layer.py BertLayerFn (model/layer.py:159-170 of the reference:
 // BertAttention -> BertIntermediate -> BertOutput) enqueued by ONE C call per direction instead of ~10 / ~12 ctypes calls.
 // Nothing new runs on the device: the same kernels with the same arguments in the same order, so the results are those of the
 // Python route bit for bit.  What moves is the host: at the reference's 104-pair micro-batches (config/uc2_pretrain.json:17-19) a

@@ -539,7 +539,7 @@ extern "C" int uc2_ln_bwd_reduce(int dtype, int M, int H, const void* ws, float*
 // The second stage of up to UC2_LN_BATCH_MAX LayerNorm backwards in ONE launch (blockIdx.z = item).  At the reference's micro-batch
 // (9 984 tokens) a backward pass runs 28 of these 5.7 us reductions, each a launch of its own on the input-gradient chain
 // (profiles/r04_2048pairs_regime_itm_kernel_stats.csv: 1.7 % of the step); nothing reads dgamma / dbeta / dbias before the end of the pass,
-// so uc2_amd/ops.py collects the partial-sum workspaces and reduces them together at the end of the backward pass.
+// so uc2_amd/ops/kernels.py collects the partial-sum workspaces and reduces them together at the end of the backward pass.
 #define UC2_LN_BATCH_MAX 32
 struct LnReduceBatch {
   const float* ws[UC2_LN_BATCH_MAX];

@@ -19,6 +19,7 @@ import torch
 from torch import nn
 
 from .. import ops
+from ..config import cfg as knobs, state
 from ..store import compute_dtype_of, mark_all_dirty, store_of
 from .layer import (GELU, BertLayer, BertLayerNorm, BertPooler, Linear, RobertaLMHead, VisualRobertaLMHead)
 
@@ -399,8 +400,7 @@ class VLXLMRForPretraining(VLXLMRPreTrainedModel):
         # fp8 mode: delayed activation scales are kept per task (the gradient magnitudes of two tasks differ by orders of magnitude:
         # their losses average over different counts -- the reference keeps one amp loss scaler per task for the same reason,
         # pretrain.py:462-465)
-        from .. import ops as _ops
-        _ops.FP8_TAG = (task, bool(compute_loss))
+        state.fp8_tag = (task, bool(compute_loss))
         batch = defaultdict(lambda: None, batch)
         input_ids = batch['input_ids']
         position_ids = batch['position_ids'] if task == 'tlm' else None
@@ -459,7 +459,7 @@ class VLXLMRForPretraining(VLXLMRPreTrainedModel):
             return torch.nonzero(flat, as_tuple=False).view(-1)
         n = int(n_hint)
         cnt = flat.sum()
-        if os.environ.get("UC2_CHECK_HINTS"):
+        if knobs.check_hints:
             assert int(cnt.item()) == n, "batch count hint %d != %d masked entries" % (n, int(cnt.item()))
         key = str(flat.device)
         acc = cls.HINT_MISMATCH.get(key)

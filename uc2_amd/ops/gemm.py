@@ -1,0 +1,280 @@
+"""uc2_gemm wrapper and GEMM planning: per-shape (kernel variant, split-K) plans, the committed plan table, the tuner.
+Part of uc2_amd.ops."""
+import os
+
+import torch
+
+from .. import _lib
+from .._lib import call, dt, ptr, stream
+from ..config import cfg, state
+from .base import EPI_DGELU, EPI_GELU, EPI_NONE, GEMM_AUTO, GEMM_AUX_DERIV, GEMM_DEFER_REDUCE, _FORCED, _require_cuda
+
+
+# --------------------------------------------------------------------------------------
+# raw kernel wrappers
+# --------------------------------------------------------------------------------------
+# Item queue of the persistent ping-pong GEMM (include/uc2_hip.h uc2_gemm_queued): dynamic work distribution from the third
+# item of a workgroup on, for steps that overlap GEMMs with a communication kernel.  One 9-int queue per (device, stream):
+# launches on one stream are serialised and the kernel leaves its queue zeroed.  UC2_GEMM_QUEUE=1 / config.cfg.gemm_queue = True.
+_GEMM_QUEUES = {}
+
+
+def _gemm_queue(device):
+    key = (device.index, stream())
+    q = _GEMM_QUEUES.get(key)
+    if q is None:
+        q = torch.zeros(16, dtype=torch.int32, device=device)
+        _GEMM_QUEUES[key] = q
+    return q
+
+
+def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=None, epi=EPI_NONE,
+         aux_in=None, aux_out=None, accumulate=False, split_k=1, lda=None, ldb=None, ldc=None, variant=None, flags=0,
+         qkv_rows_d=0):
+    """C[M,N] (=|+=) epi(sum_k A(m,k) B(n,k) + bias[n]); see uc2_amd/csrc/gemm.hip.
+    variant: kernel to use for THIS call (None = the library's default for the shape); the plan travels with the
+    call, the library holds no kernel-selection state."""
+    _require_cuda(a)
+    dtype = a.dtype
+    assert b.dtype == dtype
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else dtype, device=a.device)
+    c_f32 = out.dtype == torch.float32
+    lda = lda if lda is not None else a.stride(0)
+    ldb = ldb if ldb is not None else b.stride(0)
+    ldc = ldc if ldc is not None else out.stride(0)
+    ldaux = 0
+    for x in (aux_in, aux_out):
+        if x is not None and x.dim() == 2:
+            ldaux = x.stride(0)
+    flags |= cfg.gemm_extra_flags
+    if variant is None:
+        if _FORCED[0] is not None:
+            variant, fflags = _FORCED[0]
+            flags |= fflags
+        else:
+            variant = GEMM_AUTO
+    ws = None
+    if variant in (8, 12) and c_f32 and split_k > 1:
+        ws = _splitk_workspace(a.device, split_k * M * N * 4)
+    two_stage = ws is not None
+    timer = state.gemm_timer
+    if timer is not None and dtype == torch.bfloat16 and variant != GEMM_AUTO:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()                # on torch's current stream == the stream the kernel is launched on
+    else:
+        e0 = None
+    # qkv_rows_d = D > 0: a weight gradient whose rows come out in the head-interleaved q|k|v order (dW = dqkv^T x with interleaved
+    # dqkv): the reduction pass puts them back into the parameter arena's order (uc2_gemm_splitk_reduce_qkv); two-stage only
+    if qkv_rows_d and not two_stage:
+        raise _lib.Uc2Error("qkv_rows_d needs the two-stage split-K path (variant 8 / 12, fp32 output, split_k > 1)")
+    defer = two_stage and (e0 is not None or qkv_rows_d > 0)         # (timing: the GEMM kernel alone, the reduction pass separately)
+    if defer:
+        flags |= GEMM_DEFER_REDUCE
+    if cfg.gemm_queue and dtype == torch.bfloat16:
+        call("uc2_gemm_queued", dt(dtype), int(ta), int(tb), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc, int(c_f32),
+             ptr(bias), epi, ptr(aux_in), ptr(aux_out), ldaux, int(accumulate), split_k, variant,
+             ptr(ws), 0 if ws is None else ws.numel(), flags, ptr(_gemm_queue(a.device)), stream())
+    else:
+        call("uc2_gemm", dt(dtype), int(ta), int(tb), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc, int(c_f32),
+             ptr(bias), epi, ptr(aux_in), ptr(aux_out), ldaux, int(accumulate), split_k, variant,
+             ptr(ws), 0 if ws is None else ws.numel(), flags, stream())
+    if e0 is not None:
+        e1.record()
+    if defer:
+        if qkv_rows_d:
+            call("uc2_gemm_splitk_reduce_qkv", M, N, ptr(out), ldc, split_k, int(accumulate), ptr(ws), ws.numel(), int(qkv_rows_d), stream())
+        else:
+            call("uc2_gemm_splitk_reduce", M, N, ptr(out), ldc, split_k, int(accumulate), ptr(ws), ws.numel(), stream())
+    if e0 is not None:
+        if variant in (8, 9, 12):  # ping-pong kernels: transposed accumulators unless fp32 atomics; the epilogue kind is a template argument
+            epi_t = int(epi) + 4 if (flags & GEMM_AUX_DERIV and epi in (EPI_GELU, EPI_DGELU)) else int(epi)   # EPI_GELU_D = 5, EPI_MUL = 6
+            key = (bool(ta), bool(tb), variant, bool(c_f32 and not two_stage), epi_t)
+        else:
+            key = (bool(ta), bool(tb), variant, bool(c_f32 and split_k > 1), 0)
+        esz = a.element_size()
+        nbytes = esz * (M * K + N * K) + out.element_size() * M * N * (split_k if two_stage else (2 if accumulate else 1))
+        for x in (aux_in, aux_out):
+            if x is not None:
+                nbytes += x.element_size() * x.numel()
+        timer.add(key, 2.0 * M * N * K, e0, e1, float(nbytes))
+    return out
+
+
+_SPLITK_WS = {}
+
+
+def _splitk_workspace(device, nbytes):
+    """caller-owned device scratch for the two-stage split-K reduction of the ping-pong kernel, handed to uc2_gemm with
+    each call: grown on demand, one per (device, stream); every user runs on that stream, in order.  None when it
+    cannot be (re)allocated (stream capture): the kernel then reduces with fp32 atomics."""
+    key = (device.type, device.index, stream())      # per stream, like the item queues: two streams that both run split-K
+    ws = _SPLITK_WS.get(key)                          # GEMMs (WGRAD_SIDE_STREAM) must not share one set of partial tiles
+    if ws is None or ws.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        new = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        if ws is not None:
+            ws.record_stream(torch.cuda.current_stream(device))      # the old buffer may still be read by kernels in flight
+        _SPLITK_WS[key] = ws = new
+    return ws
+
+
+def _wgrad_split(dtype, n_out, n_in, rows):
+    """split-K factor for a weight-gradient GEMM (contraction over `rows` tokens): the output is small
+    (n_out x n_in), so the token axis is split until there are ~2 workgroups per CU (256 CUs); each slice keeps
+    >= 1024 rows so the fp32 atomic reduction stays a small fraction of the traffic"""
+    tm, tn = (64, 64) if dtype == torch.float32 else (256, 128)
+    tiles = ((n_out + tm - 1) // tm) * ((n_in + tn - 1) // tn)
+    s = (512 + tiles - 1) // max(tiles, 1)
+    return max(1, min(s, (rows + 1023) // 1024))
+
+
+# ---- per-shape kernel selection: measured once per (layout, shape) on the device, then cached ----------
+_TUNE = {}
+_BORROWED = {}            # shapes without a measured plan that run on the plan of the nearest tuned token count (linear_dgrad)
+
+
+def gemm_fallbacks(reset=False):
+    """calls since load (or the last reset) whose plan named a ping-pong kernel but ran on another one (library counter)"""
+    return int(_lib.load().uc2_gemm_fallback_count(int(bool(reset))))
+_MAX_TUNED = 256          # cap on tuned shapes (each tuning costs ~30 candidates x 7 launches + a host sync)
+
+
+def _bucket_key(key):
+    ta, tb, M, N, K, wgrad = key
+    r = lambda x: (x + 511) // 512 * 512
+    return (ta, tb, M, N, r(K), wgrad) if wgrad else (ta, tb, r(M), N, K, wgrad)
+
+
+def _plan_fits(plan, key):
+    """can the kernel of `plan` run the shape `key` (else the library would silently take its generic kernel)"""
+    v, sp = plan
+    ta, tb, M, N, K, wgrad = key
+    if v in (8, 9, 12, 13):
+        rows = 192 if v == 9 else 256
+        kt = K // 64
+        per = ((kt + sp - 1) // sp + 1) & ~1
+        # 32-bit staging offsets: an operand of 4 GiB or more does not run on the ping-pong kernels (gemm_fast.hip); contiguous
+        # operands assumed here -- the library re-checks with the real leading dimensions, counts what it re-routes
+        # (uc2_gemm_fallback_count) and refuses a UC2_GEMM_DEFER_REDUCE call it cannot honour
+        if 2 * M * K >= 1 << 32 or 2 * N * K >= 1 << 32:
+            return False
+        return M % rows == 0 and N % 256 == 0 and K % 128 == 0 and kt - (sp - 1) * per >= 2
+    if wgrad and sp * 1024 > K:
+        return False
+    return K % 64 == 0
+_FWD_CANDIDATES = ((99, 1), (0, 1), (1, 1), (2, 1), (6, 1), (7, 1), (8, 1), (12, 1))     # (kernel variant, split_k); 99 = generic kernel, 8 = ping-pong, 12 = ping-pong on the 16x16x32 MFMA
+_WGRAD_SPLITS = (2, 3, 4, 6, 8, 12, 16)
+
+
+def _plan_key_str(key):
+    ta, tb, M, N, K, wgrad = key
+    return "%s%s %dx%dx%d%s" % ("T" if ta else "N", "T" if tb else "N", M, N, K, " wgrad" if wgrad else "")
+
+
+def save_plans(path):
+    """write the tuned (variant, split_k) table; a committed copy (uc2_amd/gemm_plans.json) is preloaded at
+    import so that steady-state runs and profiles start without tuning launches"""
+    import json
+    with open(path, "w") as f:
+        json.dump({_plan_key_str(k): list(v) for k, v in sorted(_TUNE.items())}, f, indent=1)
+
+
+def load_plans(path):
+    import json
+    import os
+    if not os.path.exists(path):
+        return 0
+    with open(path) as f:
+        table = json.load(f)
+    n = 0
+    for ks, v in table.items():
+        parts = ks.split()
+        ta, tb = parts[0][0] == "T", parts[0][1] == "T"
+        M, N, K = (int(x) for x in parts[1].split("x"))
+        _TUNE[(ta, tb, M, N, K, len(parts) > 2)] = (int(v[0]), int(v[1]))
+        n += 1
+    return n
+
+
+def _time_gemm(fn, reps=5):
+    fn()
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def gemm_plan(dtype, ta, tb, M, N, K, wgrad=False):
+    """(variant, split_k) for one bf16 GEMM shape.  The first call for a shape times the candidate kernels
+    (gemm.hip generic, gemm_fast.hip ring variants, split-K factors for weight gradients) on scratch buffers
+    and caches the winner; later calls are a dict lookup.  fp32 (parity mode) and small shapes use defaults."""
+    if dtype != torch.bfloat16:
+        return -2, (_wgrad_split(dtype, M, N, K) if wgrad else 1)
+    key = (bool(ta), bool(tb), M, N, K, wgrad)
+    hit = _TUNE.get(key)
+    if hit is not None:
+        return hit
+    default = (-2, _wgrad_split(dtype, M, N, K) if wgrad else 1)
+    if (not cfg.autotune) or float(M) * N * K < 2.0 ** 31 or torch.cuda.is_current_stream_capturing():
+        return default
+    # The token dimension (M forward / dgrad, K for weight gradients) changes almost every step under the reference's
+    # token-bucket batching (data/sampler.py:11-59): tune one representative per 512-token bucket and reuse its plan
+    # if the kernel accepts the real shape (tile divisibility is re-checked by the library, which falls back to the
+    # generic kernel), and stop tuning after _MAX_TUNED shapes.
+    bkey = _bucket_key(key)
+    hit = _TUNE.get(bkey)
+    if hit is not None and _plan_fits(hit, key):
+        _TUNE[key] = hit
+        return hit
+    if len(_TUNE) >= _MAX_TUNED:
+        return default
+    dev = torch.device("cuda", torch.cuda.current_device())
+    a = torch.randn((K, M) if ta else (M, K), device=dev).to(torch.bfloat16)
+    b = torch.randn((K, N) if tb else (N, K), device=dev).to(torch.bfloat16)
+    out = torch.zeros((M, N), dtype=torch.float32 if wgrad else torch.bfloat16, device=dev)
+    lib = _lib.load()
+    cands = [(v, s) for v in (99, 1, 0, 6) for s in _WGRAD_SPLITS if s * 1024 <= K] if wgrad else list(_FWD_CANDIDATES)
+    if (not wgrad) and M % 192 == 0 and N % 256 == 0 and not ta:
+        cands.append((9, 1))                      # ping-pong kernel with 192-row tiles (tile-count quantisation at N = 768)
+    if wgrad and M % 256 == 0 and N % 256 == 0:
+        # persistent ping-pong kernel: one (tile, split) item per CU, or two
+        # (a split must leave every slice an even number >= 2 of k-tiles -- _plan_fits -- so the candidates are the valid
+        #  factors closest to one item per CU, two, and a half: K = 9984 admits 13 and 26 but not 28, 14 or 56)
+        tiles = (M // 256) * (N // 256)
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        valid = [s for s in range(1, 129) if s * 256 <= K and _plan_fits((8, s), key)]
+        for target in (cus, 2 * cus, cus // 2):
+            if valid:
+                sp_t = min(valid, key=lambda s: (abs(tiles * s - target), s))
+                cands.append((8, sp_t))
+                cands.append((12, sp_t))              # the same schedule on the 16x16x32 MFMA (within a few % of 8 either way here)
+        cands = list(dict.fromkeys(cands))
+    best, best_t = default, None
+    timer_was, state.gemm_timer = state.gemm_timer, None          # tuning launches are not part of anybody's timed region
+    # forward GEMMs (X W^T) are timed with a bias like the encoder's (the rolling-epilogue kernel only takes those)
+    tbias = torch.zeros(N, dtype=torch.float32, device=dev) if (not wgrad and not ta and not tb) else None
+    try:
+        for v, sp in cands:
+            t = _time_gemm(lambda: gemm(a, b, M, N, K, ta=ta, tb=tb, out=out, bias=tbias, accumulate=wgrad, split_k=sp, variant=v))
+            if best_t is None or t < best_t:
+                best, best_t = (v, sp), t
+    finally:
+        state.gemm_timer = timer_was
+    _TUNE[key] = best
+    _TUNE.setdefault(bkey, best)
+    return best
+
+
+def _gemm_planned(a, b, M, N, K, ta, tb, wgrad=False, **kw):
+    """one GEMM with its tuned (variant, split_k) plan, passed to the library with the call"""
+    v, sp = gemm_plan(a.dtype, ta, tb, M, N, K, wgrad)
+    flags = kw.pop("flags", 0)
+    if cfg.pp_skew and v in (8, 9, 12):
+        flags |= (cfg.pp_skew.get(kw.get("epi", EPI_NONE), 0) & 15) << 4
+    return gemm(a, b, M, N, K, ta=ta, tb=tb, split_k=sp, variant=v, flags=flags, **kw)

@@ -237,7 +237,7 @@ class ParamStore:
     def qkv_interleaved(self, qw, vw, qb, nh, want_t=True):
         """(W' [3H, H] bf16, W'^T [H, 3H] bf16 or None, b' [3H] fp32): the adjacent query | key | value weights and biases with
         row w nh D + h D + d moved to row h 3D + w D + d.  The QKV GEMM on W' writes a head's q | k | v adjacent per token, which
-        is what the attention kernels want to read (uc2_amd/ops.py::BertLayerFn).  Copies of all registered blocks are refreshed
+        is what the attention kernels want to read (uc2_amd/ops/layer.py::BertLayerFn).  Copies of all registered blocks are refreshed
         by one interleave launch + one transpose launch whenever the weights changed (once per optimizer step)."""
         import ctypes
         self.sync_shadow()

@@ -16,6 +16,7 @@ import torch
 import torch.distributed as dist
 
 from .. import _lib
+from ..config import cfg, state
 
 # The gradient tail (embeddings + heads: 0.77 GB of fp32, final only when backward ends, so its all-reduce is exposed) is reduced
 # in fp32 by default: the library never rounds gradients on its own.  UC2_ALLREDUCE_TAIL=bf16 (or TAIL_BF16 = True) opts a store
@@ -25,9 +26,8 @@ from .. import _lib
 # `auto` = bf16 for bf16 stores (round 5's default; no run with more than one rank has compared loss curves or gradient norms of
 # the two yet, one GPU per lease, so it is an opt-in again -- ADVICE r5).  The decision is taken PER STORE: a store in fp32 parity
 # mode always reduces fp32.  The mode in use is logged once on rank 0.
-_TAIL_MODE = os.environ.get("UC2_ALLREDUCE_TAIL", "fp32")
+_TAIL_MODE = cfg.allreduce_tail
 TAIL_BF16 = _TAIL_MODE == "bf16"                 # (kept as a module attribute: tests and tools flip it)
-COMM_TIMER = None                # bench.py: a list that receives (start, end) HIP events around the EXPOSED part of the gradient all-reduce
 _tail_logged = [False]
 
 
@@ -177,7 +177,7 @@ class _Reducer:
         if _native_ok(v):
             NativeComm.allreduce_avg(v, after)
             self.native_used = True
-        elif v.is_cuda and dist.get_backend() == "gloo" and os.environ.get("UC2_GLOO_DIRECT", "0") != "1":
+        elif v.is_cuda and dist.get_backend() == "gloo" and not cfg.gloo_direct:
             # gloo is the functional-test data plane (several ranks sharing the one GPU of a test box; the product path is RCCL).
             # Its own handling of device tensors (internal streams + events per collective) stopped making progress with 4
             # processes on one MI355X (every rank parked in work.wait(), round 4; 2 ranks and a bare 4-rank all-reduce of the same
@@ -292,7 +292,7 @@ def all_reduce_and_rescale_tensors(tensors, rescale_denom):
         if sync is not None:
             sync.merge_into(red)
             views.extend(sync.take_views())
-    timer = COMM_TIMER
+    timer = state.comm_timer          # bench.py: receives (start, end) HIP events around the EXPOSED part of the all-reduce
     if timer is not None and tensors[0].is_cuda:
         # from here on nothing of this step's compute is left to overlap with: what the stream waits for below is exposed
         e_exp0, e_exp1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -400,10 +400,8 @@ class GradSync:
             l.grad_ready_hook = self._on_layer_done
         if _world() > 1:
             # collectives will run beside the backward GEMMs and hold CUs: persistent GEMMs take their items from the queue
-            import os
-            from .. import ops
-            if os.environ.get("UC2_GEMM_QUEUE", "1") != "0":
-                ops.GEMM_QUEUE = True
+            if cfg.gemm_queue_allowed:
+                cfg.gemm_queue = True
 
     def arm(self):
         self.armed = True
