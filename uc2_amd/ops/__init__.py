@@ -15,6 +15,7 @@ here, so `from uc2_amd import ops; ops.gemm(...)` keeps working."""
 from .. import _lib  # noqa: F401
 from .._lib import call, dt, ptr, stream  # noqa: F401
 from ..config import cfg, state  # noqa: F401
+from ..config import cfg as knobs  # noqa: F401
 from .base import (  # noqa: F401
     EPI_ADD, EPI_DGELU, EPI_GELU, EPI_NONE, EPI_TANH, GEMM_AUTO, GEMM_AUX_DERIV, GEMM_DEFER_REDUCE, GEMM_GENERIC, GemmTimer,
     HbmTimer, _FORCED, _Rng, _Timed, _require_cuda, force_variant, rng,
@@ -51,5 +52,5 @@ from .functions import (  # noqa: F401
     TripletFn, _DEC_ROWS, _dec_chunks, _dgelu, add_rowvec, attn_general_probs_mean, attn_probs_mean,
 )
 
-if cfg.gemm_plans:
-    load_plans(cfg.gemm_plans_file)
+if knobs.gemm_plans:
+    load_plans(knobs.gemm_plans_file)

@@ -6,7 +6,7 @@ import torch
 
 from .. import _lib
 from .._lib import call, dt, ptr, stream
-from ..config import cfg, state
+from ..config import cfg as knobs, state
 from .base import EPI_NONE
 
 
@@ -88,7 +88,7 @@ def fp8_quantize_act(x2, key=None):
     """e4m3 copy + scale of an activation.  key = the tensor's role (store, layer, name): the first use computes the maximum just in
     time (two passes); every later use quantises with half the scale of the PREVIOUS use's maximum while accumulating its own for the
     next one -- one pass, no amax launch (uc2_fp8_quant_delayed)."""
-    if key is None or not cfg.fp8_delayed or torch.cuda.is_current_stream_capturing():
+    if key is None or not knobs.fp8_delayed or torch.cuda.is_current_stream_capturing():
         return fp8_quantize(x2)
     h = _FP8_HIST.get(key)
     if h is None:
@@ -131,7 +131,7 @@ def gemm_fp8_q(a8, sa, b8, sb, q_key, bias=None, epi=EPI_NONE, aux_in=None, aux_
     """gemm_fp8 whose epilogue also writes the e4m3 copy of its output for the next GEMM (uc2_gemm_fp8_q; delayed scaling on the
     history of the CONSUMER's tensor role q_key).  -> (out, (q8, scale)), or None when that role has no history yet (its first use
     initialises it just in time, fp8_quantize_act) or the ping-pong kernel does not take the call."""
-    h = _FP8_HIST.get(q_key) if (cfg.fp8_delayed and q_key is not None and not torch.cuda.is_current_stream_capturing()) else None
+    h = _FP8_HIST.get(q_key) if (knobs.fp8_delayed and q_key is not None and not torch.cuda.is_current_stream_capturing()) else None
     if h is None:
         return None
     M, K = a8.shape
@@ -182,7 +182,7 @@ def _fp8_weight(st, p_first, p_last, shape, transpose):
         return hit[0], hit[1]
     w = st.span(st.data, p_first, p_last, shape)
     rows, cols = w.shape
-    if cfg.fp8_weight_batch and rows % 64 == 0 and cols % 64 == 0 and w.is_contiguous() and not torch.cuda.is_current_stream_capturing():
+    if knobs.fp8_weight_batch and rows % 64 == 0 and cols % 64 == 0 and w.is_contiguous() and not torch.cuda.is_current_stream_capturing():
         spans = st.__dict__.setdefault("_fp8_spans", {})
         skey = key[:2]
         if skey not in spans:
@@ -242,6 +242,6 @@ def linear_dgrad_fp8(dy2, st, p_first, p_last, shape, epi=EPI_NONE, aux_in=None,
 
 def _fp8_hist_for(q_key, device):
     """the history of a tensor role if a producer may fuse its quantisation now (fp8 delayed scaling on, the role has been used)"""
-    if q_key is None or not cfg.fp8_delayed or torch.cuda.is_current_stream_capturing():
+    if q_key is None or not knobs.fp8_delayed or torch.cuda.is_current_stream_capturing():
         return None
     return _FP8_HIST.get(q_key)

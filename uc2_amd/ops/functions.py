@@ -6,7 +6,7 @@ import torch
 
 from .. import _lib
 from .._lib import call, dt, ptr, stream
-from ..config import cfg
+from ..config import cfg as knobs
 from ..store import store_of
 from .base import EPI_GELU, EPI_TANH, rng
 from .gemm import _gemm_planned, _wgrad_split, gemm
@@ -276,7 +276,7 @@ class EmbedTextFn(torch.autograd.Function):
         # taken, the row-per-wave kernel then adds every token's row with atomics
         Bn, Tn = ids.shape
         rc = _lib.load().uc2_embed_bwd_seq(dt(d2.dtype), Bn, Tn, H, ptr(ids), ptr(pos_ids), ptr(type_ids), ptr(d2), ptr(st.grad_buf(word)),
-                                           ptr(st.grad_buf(pos)), ptr(dtyp), ctx.pads[0], ctx.pads[1], stream()) if cfg.embed_bwd_seq else -2
+                                           ptr(st.grad_buf(pos)), ptr(dtyp), ctx.pads[0], ctx.pads[1], stream()) if knobs.embed_bwd_seq else -2
         if rc == -2:
             call("uc2_embed_bwd", dt(d2.dtype), rows, H, ptr(ids), ptr(pos_ids), ptr(type_ids), ptr(d2),
                  ptr(st.grad_buf(word)), ptr(st.grad_buf(pos)), ptr(dtyp), ctx.pads[0], ctx.pads[1], stream())

@@ -6,7 +6,7 @@ import torch
 
 from .. import _lib
 from .._lib import call, dt, ptr, stream
-from ..config import cfg, state
+from ..config import cfg as knobs, state
 from .base import EPI_DGELU, EPI_GELU, EPI_NONE, GEMM_AUTO, GEMM_AUX_DERIV, GEMM_DEFER_REDUCE, _FORCED, _require_cuda
 
 
@@ -15,7 +15,7 @@ from .base import EPI_DGELU, EPI_GELU, EPI_NONE, GEMM_AUTO, GEMM_AUX_DERIV, GEMM
 # --------------------------------------------------------------------------------------
 # Item queue of the persistent ping-pong GEMM (include/uc2_hip.h uc2_gemm_queued): dynamic work distribution from the third
 # item of a workgroup on, for steps that overlap GEMMs with a communication kernel.  One 9-int queue per (device, stream):
-# launches on one stream are serialised and the kernel leaves its queue zeroed.  UC2_GEMM_QUEUE=1 / config.cfg.gemm_queue = True.
+# launches on one stream are serialised and the kernel leaves its queue zeroed.  UC2_GEMM_QUEUE=1 / config.knobs.gemm_queue = True.
 _GEMM_QUEUES = {}
 
 
@@ -47,7 +47,7 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
     for x in (aux_in, aux_out):
         if x is not None and x.dim() == 2:
             ldaux = x.stride(0)
-    flags |= cfg.gemm_extra_flags
+    flags |= knobs.gemm_extra_flags
     if variant is None:
         if _FORCED[0] is not None:
             variant, fflags = _FORCED[0]
@@ -71,7 +71,7 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
     defer = two_stage and (e0 is not None or qkv_rows_d > 0)         # (timing: the GEMM kernel alone, the reduction pass separately)
     if defer:
         flags |= GEMM_DEFER_REDUCE
-    if cfg.gemm_queue and dtype == torch.bfloat16:
+    if knobs.gemm_queue and dtype == torch.bfloat16:
         call("uc2_gemm_queued", dt(dtype), int(ta), int(tb), M, N, K, ptr(a), lda, ptr(b), ldb, ptr(out), ldc, int(c_f32),
              ptr(bias), epi, ptr(aux_in), ptr(aux_out), ldaux, int(accumulate), split_k, variant,
              ptr(ws), 0 if ws is None else ws.numel(), flags, ptr(_gemm_queue(a.device)), stream())
@@ -221,7 +221,7 @@ def gemm_plan(dtype, ta, tb, M, N, K, wgrad=False):
     if hit is not None:
         return hit
     default = (-2, _wgrad_split(dtype, M, N, K) if wgrad else 1)
-    if (not cfg.autotune) or float(M) * N * K < 2.0 ** 31 or torch.cuda.is_current_stream_capturing():
+    if (not knobs.autotune) or float(M) * N * K < 2.0 ** 31 or torch.cuda.is_current_stream_capturing():
         return default
     # The token dimension (M forward / dgrad, K for weight gradients) changes almost every step under the reference's
     # token-bucket batching (data/sampler.py:11-59): tune one representative per 512-token bucket and reuse its plan
@@ -275,6 +275,6 @@ def _gemm_planned(a, b, M, N, K, ta, tb, wgrad=False, **kw):
     """one GEMM with its tuned (variant, split_k) plan, passed to the library with the call"""
     v, sp = gemm_plan(a.dtype, ta, tb, M, N, K, wgrad)
     flags = kw.pop("flags", 0)
-    if cfg.pp_skew and v in (8, 9, 12):
-        flags |= (cfg.pp_skew.get(kw.get("epi", EPI_NONE), 0) & 15) << 4
+    if knobs.pp_skew and v in (8, 9, 12):
+        flags |= (knobs.pp_skew.get(kw.get("epi", EPI_NONE), 0) & 15) << 4
     return gemm(a, b, M, N, K, ta=ta, tb=tb, split_k=sp, variant=v, flags=flags, **kw)

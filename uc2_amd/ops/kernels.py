@@ -7,7 +7,7 @@ import torch
 
 from .. import _lib
 from .._lib import call, dt, ptr, stream
-from ..config import cfg
+from ..config import cfg as knobs
 from .base import _Timed
 from .streams import _on_side_stream, _queue_pass_callback, _side_route
 from .gemm import _gemm_queue
@@ -93,9 +93,9 @@ def _ln_bwd_second_stage(d, M, H, ws, dgamma, dbeta, dbias, device):
     def reduce():
         call("uc2_ln_bwd_reduce", d, M, H, ptr(ws), ptr(dgamma), ptr(dbeta), ptr(dbias), stream())
     if dgamma is not None or dbeta is not None or dbias is not None:
-        if cfg.ln_reduce_side and _side_route(M):      # (below WGRAD_SIDE_MIN_ROWS tokens it made the regime erratic: 27.0-30.8 ms against 27.0-27.1)
+        if knobs.ln_reduce_side and _side_route(M):      # (below WGRAD_SIDE_MIN_ROWS tokens it made the regime erratic: 27.0-30.8 ms against 27.0-27.1)
             _on_side_stream(device, reduce, (ws,))
-        elif not (cfg.ln_reduce_batch and M < cfg.wgrad_side_min_rows and _defer_ln_reduction(d, M, H, ws, dgamma, dbeta, dbias)):
+        elif not (knobs.ln_reduce_batch and M < knobs.wgrad_side_min_rows and _defer_ln_reduction(d, M, H, ws, dgamma, dbeta, dbias)):
             reduce()
 
 
@@ -156,7 +156,7 @@ ATTN_QKV_INTERLEAVED = 16          # include/uc2_hip.h UC2_ATTN_QKV_INTERLEAVED,
 
 def _attn_q(q_key, qkv, impl, ilv):
     """the delayed-scaling history of the tensor role `q_key` if the attention kernel may write the e4m3 copy itself"""
-    if q_key is None or not cfg.fp8_attn_fused or qkv.dtype != torch.bfloat16 or ilv or (cfg.attn_impl if impl is None else impl) == 1:
+    if q_key is None or not knobs.fp8_attn_fused or qkv.dtype != torch.bfloat16 or ilv or (knobs.attn_impl if impl is None else impl) == 1:
         return None
     return _fp8_hist_for(q_key, qkv.device)
 
@@ -183,7 +183,7 @@ def attn_fwd(qkv, mask2d, B, L, nh, D, drop_p=0.0, seed=None, seed_imm=0, impl=N
         if rc != -2:
             _lib.check(rc)
     with _Timed("attn_fwd", B * L * H * qkv.element_size() * 4 + B * nh * L * 4):       # q,k,v in; ctx, lse out
-        call("uc2_attn_fwd", dt(qkv.dtype), (cfg.attn_impl if impl is None else impl) | (ATTN_QKV_INTERLEAVED if ilv else 0), B, L, nh, D, ptr(qkv), ptr(mask2d),
+        call("uc2_attn_fwd", dt(qkv.dtype), (knobs.attn_impl if impl is None else impl) | (ATTN_QKV_INTERLEAVED if ilv else 0), B, L, nh, D, ptr(qkv), ptr(mask2d),
              1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(lse), stream())
     return (ctx, lse, None) if q_key is not None else (ctx, lse)
 
@@ -201,16 +201,16 @@ def attn_bwd(qkv, mask2d, ctx, dctx, lse, B, L, nh, D, drop_p=0.0, seed=None, se
         prev, nxt, clr = _fp8_rotate(h)
         with _Timed("attn_bwd", B * L * nh * D * qkv.element_size() * 8 + B * nh * L * 4 + B * L * nh * D * 3):
             rc = _lib.load().uc2_attn_bwd_q(B, L, nh, D, ptr(qkv), ptr(mask2d), 1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(dctx),
-                                            ptr(lse), ptr(dqkv), ptr(dbias), ptr(_gemm_queue(qkv.device)[12:14]) if cfg.gemm_queue else None,
+                                            ptr(lse), ptr(dqkv), ptr(dbias), ptr(_gemm_queue(qkv.device)[12:14]) if knobs.gemm_queue else None,
                                             ptr(d8), prev, nxt, clr, ptr(scale), stream())
         if rc == 0:
             return dqkv, (d8, scale)
         h[1] = i_was
         if rc != -2:
             _lib.check(rc)
-    impl = (cfg.attn_impl if impl is None else impl) | (ATTN_QKV_INTERLEAVED if ilv else 0)
+    impl = (knobs.attn_impl if impl is None else impl) | (ATTN_QKV_INTERLEAVED if ilv else 0)
     with _Timed("attn_bwd", B * L * nh * D * qkv.element_size() * 8 + B * nh * L * 4):   # qkv, ctx, dctx, lse in; dqkv out
-        if cfg.gemm_queue and qkv.dtype == torch.bfloat16:       # N > 1: the persistent kernels share the chip with the all-reduce kernels
+        if knobs.gemm_queue and qkv.dtype == torch.bfloat16:       # N > 1: the persistent kernels share the chip with the all-reduce kernels
             call("uc2_attn_bwd_queued", dt(qkv.dtype), impl, B, L, nh, D, ptr(qkv), ptr(mask2d),
                  1.0 / math.sqrt(D), drop_p, ptr(seed), seed_imm, ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(dbias),
                  ptr(_gemm_queue(qkv.device)[12:14]), stream())

@@ -6,7 +6,7 @@ import torch
 
 from .. import _lib
 from .._lib import dt, ptr, stream
-from ..config import cfg, state
+from ..config import cfg as knobs, state
 from ..store import store_of
 from .base import EPI_ADD, EPI_DGELU, EPI_GELU, EPI_NONE, GEMM_AUX_DERIV, _FORCED, rng
 from .streams import _on_side_stream, _side_route
@@ -78,15 +78,15 @@ class _BertLayerGradC(ctypes.Structure):        # Uc2BertLayerGrad
 def _plan_c(dtype, tb, M, N, K, epi=EPI_NONE, flags=0):
     """the (variant, split_k, flags) _gemm_planned + gemm would pass for this GEMM"""
     v, sp = gemm_plan(dtype, False, tb, M, N, K, False)
-    if cfg.pp_skew and v in (8, 9, 12):
-        flags |= (cfg.pp_skew.get(epi, 0) & 15) << 4
-    return _GemmPlanC(v, sp, flags | cfg.gemm_extra_flags)
+    if knobs.pp_skew and v in (8, 9, 12):
+        flags |= (knobs.pp_skew.get(epi, 0) & 15) << 4
+    return _GemmPlanC(v, sp, flags | knobs.gemm_extra_flags)
 
 
 def _native_layer_ok(dtype, M, fp8, ilv):
-    return (cfg.native_layer and not fp8 and ilv is None and state.gemm_timer is None and state.hbm_timer is None and _FORCED[0] is None
-            and not (cfg.ln_fuse and dtype == torch.bfloat16 and M >= cfg.ln_fuse_min_rows)
-            and not (cfg.dgrad_transposed_w and dtype == torch.bfloat16 and M >= cfg.dgrad_wt_min_rows))
+    return (knobs.native_layer and not fp8 and ilv is None and state.gemm_timer is None and state.hbm_timer is None and _FORCED[0] is None
+            and not (knobs.ln_fuse and dtype == torch.bfloat16 and M >= knobs.ln_fuse_min_rows)
+            and not (knobs.dgrad_transposed_w and dtype == torch.bfloat16 and M >= knobs.dgrad_wt_min_rows))
 
 
 class BertLayerFn(torch.autograd.Function):
@@ -123,8 +123,8 @@ class BertLayerFn(torch.autograd.Function):
         # ctx and every gradient are bit-identical to the plain layout.  Needs the MFMA attention kernels and, for the backward,
         # the two-stage ping-pong weight-gradient GEMM (its reduction pass un-permutes the rows of dWqkv).
         ilv = None
-        if (cfg.qkv_interleaved and dtype == torch.bfloat16 and M >= cfg.qkv_ilv_min_rows and M % 128 == 0 and not cfg.get("fp8")
-                and cfg.attn_impl in (0, 2) and D in (32, 64) and _lib.load().uc2_attn_mfma_supported(L, D)
+        if (knobs.qkv_interleaved and dtype == torch.bfloat16 and M >= knobs.qkv_ilv_min_rows and M % 128 == 0 and not cfg.get("fp8")
+                and knobs.attn_impl in (0, 2) and D in (32, 64) and _lib.load().uc2_attn_mfma_supported(L, D)
                 and not torch.cuda.is_current_stream_capturing()):
             plan = _ilv_wgrad_plan(3 * H, H, M, x.device) if any(ctx.needs_input_grad) or training else (12, 2)
             pack = st.qkv_interleaved(P["qw"], P["vw"], P["qb"], nh) if plan is not None else None
@@ -137,7 +137,7 @@ class BertLayerFn(torch.autograd.Function):
             qkv = linear_fwd(x2, wqkv, bqkv)
             ctxv, _ = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn, want_lse=False, ilv=ilv is not None)
             del qkv
-            fuse = int(cfg.ln_fuse) if (dtype == torch.bfloat16 and M >= cfg.ln_fuse_min_rows) else 0
+            fuse = int(knobs.ln_fuse) if (dtype == torch.bfloat16 and M >= knobs.ln_fuse_min_rows) else 0
             o1 = linear_drop_residual(ctxv, st.compute(P["ow"], dtype), P["ob"].data, x2, p_h, seed, s_ln1) if fuse & 1 else None
             if o1 is not None:
                 a, _, _ = ln_fwd(o1, None, P["g1"].data, P["b1"].data, 1e-12, want_stats=False)
@@ -166,7 +166,7 @@ class BertLayerFn(torch.autograd.Function):
             o1, mean1, rstd1, a = e(M, H), e(M, dt_=f32), e(M, dt_=f32), e(M, H)
             u, o2, mean2, rstd2, y = e(M, I_), e(M, H), e(M, dt_=f32), e(M, dt_=f32), e(M, H)
             c = _BertLayerC()
-            c.dtype, c.B, c.L, c.H, c.nh, c.I, c.attn_impl = dt(dtype), B, L, H, nh, I_, cfg.attn_impl
+            c.dtype, c.B, c.L, c.H, c.nh, c.I, c.attn_impl = dt(dtype), B, L, H, nh, I_, knobs.attn_impl
             c.eps, c.p_hidden, c.p_attn = 1e-12, p_h, p_a
             c.seed, c.site_attn, c.site_ln1, c.site_ln2 = ptr(seed), s_attn, s_ln1, s_ln2
             c.wqkv, c.wo, c.wi, c.wf = wqkv.data_ptr(), st.compute(P["ow"], dtype).data_ptr(), st.compute(P["iw"], dtype).data_ptr(), st.compute(P["fw"], dtype).data_ptr()
@@ -178,7 +178,7 @@ class BertLayerFn(torch.autograd.Function):
             c.pre, c.u, c.o2, c.mean2, c.rstd2, c.y = pre.data_ptr(), u.data_ptr(), o2.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), y.data_ptr()
             c.plan_qkv, c.plan_o = _plan_c(dtype, False, M, 3 * H, H), _plan_c(dtype, False, M, H, H)
             c.plan_i, c.plan_f = _plan_c(dtype, False, M, I_, H, EPI_GELU, GEMM_AUX_DERIV), _plan_c(dtype, False, M, H, I_)
-            c.queue = ptr(_gemm_queue(dev)) if (cfg.gemm_queue and dtype == torch.bfloat16) else None
+            c.queue = ptr(_gemm_queue(dev)) if (knobs.gemm_queue and dtype == torch.bfloat16) else None
             _lib.check(_lib.load().uc2_bert_layer_fwd(ctypes.byref(c), stream()))
             ctx.native_c = c
             fused1 = fused2 = False
@@ -209,7 +209,7 @@ class BertLayerFn(torch.autograd.Function):
             # The dense -> dropout -> + residual tails: with LN_FUSE the Wo / FFN2 GEMM writes the pre-LayerNorm SUM (dropout mask and
             # residual in its epilogue), the LayerNorm reads one tensor and hashes no mask; o1 / o2 then hold the sums and the
             # backward runs the LayerNorm in its drop_after = 2 form (fused1 / fused2 say which form each tail took)
-            fuse = int(cfg.ln_fuse) if M >= cfg.ln_fuse_min_rows else 0
+            fuse = int(knobs.ln_fuse) if M >= knobs.ln_fuse_min_rows else 0
             o1 = linear_drop_residual(ctxv, st.compute(P["ow"], dtype), P["ob"].data, x2, p_h, seed, s_ln1) if fuse & 1 else None
             fused1 = o1 is not None
             if fused1:
@@ -279,7 +279,7 @@ class BertLayerFn(torch.autograd.Function):
             g.ws1, g.ws2 = ws1.data_ptr(), ws2.data_ptr()
             g.dbi = G(P["ib"]).data_ptr()
             g.dbqkv = st.grad_span(P["qb"], P["vb"], (3 * H,)).data_ptr()
-            g.attn_queue = ptr(_gemm_queue(dev)[12:14]) if (cfg.gemm_queue and dtype == torch.bfloat16) else None
+            g.attn_queue = ptr(_gemm_queue(dev)[12:14]) if (knobs.gemm_queue and dtype == torch.bfloat16) else None
             g.plan_df = _plan_c(dtype, True, M, I_, H, EPI_DGELU, GEMM_AUX_DERIV)
             g.plan_di, g.plan_do, g.plan_dqkv = _plan_c(dtype, True, M, H, I_, EPI_ADD), _plan_c(dtype, True, M, H, H), _plan_c(dtype, True, M, H, 3 * H, EPI_ADD)
             c = ctx.native_c
@@ -304,10 +304,10 @@ class BertLayerFn(torch.autograd.Function):
         I_ = P["iw"].shape[0]
         # k-contiguous copies W^T for the input-gradient GEMMs (bf16; refreshed once per optimizer step, one launch for all)
         # (from DGRAD_WT_MIN_ROWS tokens)
-        use_wt = cfg.dgrad_transposed_w and dtype == torch.bfloat16 and not fp8 and M >= cfg.dgrad_wt_min_rows
+        use_wt = knobs.dgrad_transposed_w and dtype == torch.bfloat16 and not fp8 and M >= knobs.dgrad_wt_min_rows
         WT = (lambda pf, pl=None, shp=None: st.compute_t(pf, pl, shp)) if use_wt else (lambda *a_: None)
         # small token counts: the four weight gradients go out as ONE grouped launch at the end (wgrad_group)
-        grouped = [] if (cfg.wgrad_group and dtype == torch.bfloat16 and M < cfg.wgrad_side_min_rows and M % 128 == 0) else None
+        grouped = [] if (knobs.wgrad_group and dtype == torch.bfloat16 and M < knobs.wgrad_side_min_rows and M % 128 == 0) else None
         wgrad = (lambda dyv, xv, dwv: grouped.append((dyv, xv, dwv))) if grouped is not None else (lambda dyv, xv, dwv: linear_wgrad(dyv, xv, dwv, None))
         wgrad(d_o2, u, G(P["fw"]))
         if nat is not None:
@@ -384,7 +384,7 @@ class BertLayerFn(torch.autograd.Function):
     def _finish_backward(ctx, grouped, dy2, dx):
         """the layer's grouped weight-gradient launch and the gradient-ready hook (both routes of backward end here)"""
         if grouped:
-            if cfg.wgrad_group_side and cfg.wgrad_side_stream and not torch.cuda.is_current_stream_capturing():
+            if knobs.wgrad_group_side and knobs.wgrad_side_stream and not torch.cuda.is_current_stream_capturing():
                 # the layer's grouped weight-gradient launch beside the next layer's backward (small token counts: the main chain's
                 # kernels leave CUs idle at their round tails and between launches)
                 trip = list(grouped)

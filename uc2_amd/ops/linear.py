@@ -6,7 +6,7 @@ import torch
 
 from .. import _lib
 from .._lib import call, dt, ptr, stream
-from ..config import cfg, state
+from ..config import cfg as knobs, state
 from .base import EPI_ADD, EPI_DGELU, EPI_NONE
 from .streams import _on_side_stream, _side_route
 from .gemm import _BORROWED, _TUNE, _bucket_key, _gemm_planned, _gemm_queue, _plan_fits, _splitk_workspace, gemm
@@ -35,12 +35,12 @@ def linear_drop_residual(x2, w, bias, res2, drop_p, seed, seed_imm):
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    flags = cfg.gemm_extra_flags
-    if cfg.pp_skew:
-        flags |= (cfg.pp_skew.get(EPI_ADD, 0) & 15) << 4
+    flags = knobs.gemm_extra_flags
+    if knobs.pp_skew:
+        flags |= (knobs.pp_skew.get(EPI_ADD, 0) & 15) << 4
     rc = _lib.load().uc2_gemm_drop_residual(M, N, K, ptr(x2), x2.stride(0), ptr(w), w.stride(0), ptr(out), N, ptr(bias), ptr(res2),
                                             res2.stride(0), float(drop_p), ptr(seed), seed_imm, flags,
-                                            ptr(_gemm_queue(x2.device)) if cfg.gemm_queue else None, stream())
+                                            ptr(_gemm_queue(x2.device)) if knobs.gemm_queue else None, stream())
     if rc == -2:
         return None
     _lib.check(rc)
@@ -67,11 +67,11 @@ def linear_dgrad(dy2, w, epi=EPI_NONE, aux_in=None, colsum_out=None, flags=0, wt
     if wt is not None:
         key = (False, False, M, K, N, False)
         hit = _TUNE.get(key) or _TUNE.get(_bucket_key(key)) or _BORROWED.get(key)
-        if hit is None and M >= cfg.dgrad_wt_min_rows:
+        if hit is None and M >= knobs.dgrad_wt_min_rows:
             # no plan for this token count: take the plan of the nearest tuned token count of the same (N, K) -- above the
             # threshold the choice between the kernels does not depend on M any more (every committed plan there is variant 12)
             near = [(abs(k[2] - M), v) for k, v in _TUNE.items() if not k[0] and not k[1] and not k[5] and k[3] == K and k[4] == N
-                    and k[2] >= cfg.dgrad_wt_min_rows]
+                    and k[2] >= knobs.dgrad_wt_min_rows]
             if near:
                 hit = min(near, key=lambda t: t[0])[1]
                 _BORROWED[key] = hit                    # not a measured plan: kept out of _TUNE (save_plans, bench.py's gemm_plans)
@@ -80,8 +80,8 @@ def linear_dgrad(dy2, w, epi=EPI_NONE, aux_in=None, colsum_out=None, flags=0, wt
     if wt is not None:
         DGRAD_ROUTES[(M, K, N, int(epi))] = route
     if route == "W^T":
-        if cfg.pp_skew:
-            flags |= (cfg.pp_skew.get(epi, 0) & 15) << 4
+        if knobs.pp_skew:
+            flags |= (knobs.pp_skew.get(epi, 0) & 15) << 4
         return gemm(dy2, wt, M, K, N, split_k=1, variant=hit[0], epi=epi, aux_in=aux_in, aux_out=colsum_out, flags=flags)
     return _gemm_planned(dy2, w, M, K, N, False, True, epi=epi, aux_in=aux_in, aux_out=colsum_out, flags=flags)
 
@@ -89,7 +89,7 @@ def linear_dgrad(dy2, w, epi=EPI_NONE, aux_in=None, colsum_out=None, flags=0, wt
 def _linear_wgrad_now(dy2, x2, dw, db):
     M, N = dy2.shape
     K = x2.shape[1]
-    _gemm_planned(dy2, x2, N, K, M, True, True, wgrad=True, out=dw, accumulate=True, flags=(cfg.wgrad_spare & 7) << 28)
+    _gemm_planned(dy2, x2, N, K, M, True, True, wgrad=True, out=dw, accumulate=True, flags=(knobs.wgrad_spare & 7) << 28)
     if db is not None:
         colsum_accum(dy2, db)
 
@@ -143,7 +143,7 @@ def wgrad_group(triples):
     falls back to one GEMM per item where the grouped kernel does not apply"""
     dy0 = triples[0][0]
     rows = dy0.shape[0]
-    ok = (cfg.wgrad_group and dy0.dtype == torch.bfloat16 and 1 <= len(triples) <= 4 and rows % 128 == 0
+    ok = (knobs.wgrad_group and dy0.dtype == torch.bfloat16 and 1 <= len(triples) <= 4 and rows % 128 == 0
           and all(dy.shape[0] == rows and x.shape[0] == rows and dy.shape[1] % 256 == 0 and x.shape[1] % 256 == 0
                   and dy.is_contiguous() and x.is_contiguous() and dw.dtype == torch.float32 for dy, x, dw in triples))
     if ok:

@@ -3,7 +3,7 @@ consumer of gradients performs.  Part of uc2_amd.ops."""
 
 import torch
 
-from ..config import cfg
+from ..config import cfg as knobs
 
 
 # Weight-gradient GEMMs are off the critical path of backward (nothing downstream in the same backward pass reads
@@ -137,7 +137,7 @@ class accum_pass:
     def __init__(self, store, rows, tensors, fp8=False):
         self.state = None
         t0 = next((t for t in tensors if torch.is_tensor(t) and t.is_cuda), None)
-        if not (cfg.accum_overlap and t0 is not None and torch.is_grad_enabled() and 0 < rows < cfg.accum_overlap_max_rows and not fp8
+        if not (knobs.accum_overlap and t0 is not None and torch.is_grad_enabled() and 0 < rows < knobs.accum_overlap_max_rows and not fp8
                 and not (store.shadow is not None and store.auto_sync) and not torch.cuda.is_current_stream_capturing()):
             return
         self.state = _accum_state(t0.device)
@@ -190,7 +190,7 @@ class accum_pass:
 
 
 def _side_route(rows):
-    return cfg.wgrad_side_stream and rows >= cfg.wgrad_side_min_rows and not torch.cuda.is_current_stream_capturing()
+    return knobs.wgrad_side_stream and rows >= knobs.wgrad_side_min_rows and not torch.cuda.is_current_stream_capturing()
 
 
 def _on_side_stream(dev, fn, inputs):
