@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the MLM and reference-regime workloads")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--layers", type=int, default=12, help=argparse.SUPPRESS)   # debugging only; 12 = the metric's config
+    ap.add_argument("--micro", type=int, default=1, help="the --batch pairs of a step as this many accumulated micro-batches (gradients summed "
+                                                         "like pretrain.py:553-559, one all-reduce + clip + AdamW per step)")
     return ap.parse_args()
 
 
@@ -573,15 +575,17 @@ def main():
             NativeComm.mark_failed()
         raise SystemExit("bench.py: --batch %d needs about %.0f GB of free HBM on %s, %.0f GB are free (another process on the device?); "
                          "use a smaller --batch" % (a.batch, need_b / 2 ** 30, dev, free_b / 2 ** 30))
-    batches = [synth_batch(a.batch, a.task, 1000 * (rank + 1) + i, dev) for i in range(2)]
+    assert a.batch % a.micro == 0, "--batch must be a multiple of --micro"
+    # two alternating step inputs; each is a list of --micro micro-batches of batch / micro pairs (one micro-batch by default)
+    batches = [[synth_batch(a.batch // a.micro, a.task, 1000 * (rank + 1) + i + 100 * j, dev) for j in range(a.micro)] for i in range(2)]
     # (untimed, before the W warm-up steps: the caching allocator's pool -- ~190 GB of hipMalloc at the default batch -- and the
     #  GEMM plans of any untuned shape settle in the first two steps of a process; with --warmup 1 they would otherwise fall into
     #  the timed region)
     settle = max(0, 3 - a.warmup)
     for i in range(settle):
-        opt_step([batches[i % 2]], a.task)
+        opt_step(batches[i % 2], a.task)
     for i in range(a.warmup):
-        opt_step([batches[i % 2]], a.task)
+        opt_step(batches[i % 2], a.task)
     gtimer, htimer = ops.GemmTimer(), ops.HbmTimer()
     fence()
     state.gemm_timer, state.hbm_timer = gtimer, htimer
@@ -590,7 +594,7 @@ def main():
     ops.gemm_fallbacks(reset=True)
     t0 = time.perf_counter()
     for i in range(a.steps):
-        loss = opt_step([batches[(a.warmup + i) % 2]], a.task)
+        loss = opt_step(batches[(a.warmup + i) % 2], a.task)
     fence()
     dt = time.perf_counter() - t0
     ms1 = torch.cuda.memory_stats(dev)
@@ -626,19 +630,19 @@ def main():
     # a launch's begin-to-end time then includes time in which the kernel shared the chip, and flops / duration says nothing
     # about the kernel.  The per-kernel figures therefore come from `k_pass` extra steps of the SAME step with the weight
     # gradients on the main stream (one kernel at a time), directly after the timed region; `value` is the timed region's.
-    overlapped = bool(knobs.wgrad_side_stream) and a.batch * (T_TXT + N_REG) >= knobs.wgrad_side_min_rows
+    overlapped = bool(knobs.wgrad_side_stream) and a.batch // a.micro * (T_TXT + N_REG) >= knobs.wgrad_side_min_rows
     gtimer_tr, htimer_tr = gtimer, htimer
     k_pass = 0
     if overlapped:
         k_pass = max(2, min(a.steps, 5))
         side_was, knobs.wgrad_side_stream = knobs.wgrad_side_stream, False
-        opt_step([batches[0]], a.task)                        # (one untimed step in the serial mode)
+        opt_step(batches[0], a.task)                        # (one untimed step in the serial mode)
         gtimer, htimer = ops.GemmTimer(), ops.HbmTimer()
         fence()
         state.gemm_timer, state.hbm_timer = gtimer, htimer
         t1 = time.perf_counter()
         for i in range(k_pass):
-            opt_step([batches[i % 2]], a.task)
+            opt_step(batches[i % 2], a.task)
         fence()
         dt_pass = time.perf_counter() - t1
         state.gemm_timer, state.hbm_timer = None, None
@@ -806,7 +810,7 @@ def main():
             "config": {"workload": "uc2-base %dL/768H vocab 250002, CC-shaped pairs (60 tokens + 36 regions x 2048-d, "
                                    "L=96), %s training step: fwd + bwd + grad all-reduce + clip + AdamW, dropout 0.1"
                                    % (a.layers, a.task.upper()),
-                       "pairs_per_gpu_per_step": a.batch, "global_batch": a.batch * world,
+                       "pairs_per_gpu_per_step": a.batch, "global_batch": a.batch * world, "accumulation_micro_batches": a.micro,
                        "seq_len": T_TXT + N_REG, "parallelism": "dp%d" % world, "final_loss": round(lossv, 4), "replicas_in_sync": in_sync,
                        "gradient_allreduce": comm_path, "rccl_ranks": rccl_ranks, "rccl_version": rccl_version,
                        "gemm_item_queue": bool(knobs.gemm_queue), "gemm_fallbacks": gemm_fallbacks,

@@ -105,4 +105,9 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException:                                           # noqa: BLE001 -- the launcher's own error summary hides the cause
+        import traceback
+        print("dist_value_worker FAILED on rank %s:\n%s" % (os.environ.get("RANK"), traceback.format_exc()), flush=True)
+        raise

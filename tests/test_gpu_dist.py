@@ -77,7 +77,8 @@ def test_two_ranks_mean_gradient_equals_oracle_mean_of_single_rank_runs():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "tests", "dist_value_worker.py")],
                        env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    fail = r.stdout.find("dist_value_worker FAILED")
+    assert r.returncode == 0, (r.stdout[fail:fail + 3000] if fail >= 0 else r.stdout[-1500:], r.stderr[-1500:])
     assert "dist_value_worker ok" in r.stdout, r.stdout[-1500:]
 
 

@@ -43,6 +43,9 @@ class Config:
         self.qkv_ilv_min_rows = 16384
         self.native_layer = _flag(env, "UC2_NATIVE_LAYER", True)         # below 16 384 tokens: one C call per layer and direction
         self.embed_bwd_seq = _flag(env, "UC2_EMBED_BWD_SEQ", True)       # per-position embedding backward (uc2_embed_bwd_seq)
+        # bf16 encoder passes over a ragged token count B L run on B L rounded up to whole 256-row GEMM tiles (zero rows appended
+        # once in VLXLMREncoder.forward: ops.PadRowsFn), so that every GEMM stays on its planned ping-pong kernel
+        self.pad_rows = _flag(env, "UC2_PAD_ROWS", True)
         # ---------------------------------------------------------------- streams
         # weight-gradient GEMMs on a second HIP stream (round 3, 1024-pair step on one box: 63.1-63.3 ms against 63.8-64.4);
         # UC2_WGRAD_SIDE = "0" | "1" | "1:<n>" (n: they leave 8 n CUs free -- measured slower, 65.5 ms at 16-24 CUs)
@@ -58,7 +61,7 @@ class Config:
         self.ln_reduce_batch = _flag(env, "UC2_LN_REDUCE_BATCH", True)   # ... or batched into one launch per backward pass (small token counts)
         # gradient accumulation overlapped inside the top-level models (ops/streams.py accum_pass): forward i+1 beside backward i
         self.accum_overlap = _flag(env, "UC2_ACCUM_OVERLAP", True)
-        self.accum_overlap_max_rows = 16384
+        self.accum_overlap_max_rows = int(env.get("UC2_ACCUM_OVERLAP_MAX_ROWS", "16384"))
         # ---------------------------------------------------------------- fp8 mode
         self.fp8_delayed = _flag(env, "UC2_FP8_DELAYED", True)           # delayed (one-pass, producer-fused) activation scaling
         self.fp8_weight_batch = _flag(env, "UC2_FP8_WEIGHT_BATCH", True)  # all e4m3 weight copies of a store from one call per optimizer step

@@ -5,7 +5,7 @@ from collections import defaultdict
 import torch
 
 from .. import ops
-from ..store import mark_all_dirty, store_of
+from ..store import compute_dtype_of, mark_all_dirty, store_of
 from .layer import Linear
 from .model import VLXLMRModel, VLXLMRPreTrainedModel, _any_fp8
 
@@ -34,7 +34,7 @@ class VLXLMRForImageTextRetrieval(VLXLMRPreTrainedModel):
         am = batch.get('attn_masks') if hasattr(batch, 'get') else None
         rows = am.numel() if (self.training and torch.is_tensor(am)) else 0
         with ops.accum_pass(st, rows, [v for v in batch.values() if torch.is_tensor(v)] if rows else (),
-                            fp8=_any_fp8(self)) as ap:
+                            fp8=_any_fp8(self), bf16=compute_dtype_of(self) == torch.bfloat16) as ap:
             return ap.mark(self._forward(batch, compute_loss))
 
     def _forward(self, batch, compute_loss=True):

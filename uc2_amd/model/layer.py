@@ -181,7 +181,12 @@ class BertLayer(nn.Module):
     def forward(self, hidden_states, attention_mask):
         cd = compute_dtype_of(self)
         x = hidden_states if hidden_states.dtype == cd else ops.cast(hidden_states, cd)
-        B, L, H = x.shape
+        if x.dim() == 2:
+            # [rows, H] with rows >= B L: the padded-rows form VLXLMREncoder.forward passes from layer to layer when B L is not a
+            # whole number of GEMM tiles (ops.PadRowsFn); B and L are the mask's
+            B, L = attention_mask.shape[0], attention_mask.shape[-1]
+        else:
+            B, L, H = x.shape
         mask2d = ops._mask2d(attention_mask, B, L)
         a = self.attention
         cfg = {"nh": a.self.num_attention_heads, "training": self.training,

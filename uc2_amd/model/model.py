@@ -258,12 +258,20 @@ class VLXLMREncoder(nn.Module):
     def forward(self, input_, attention_mask, output_all_encoded_layers=True):
         all_encoder_layers = []
         hidden_states = input_
+        # A ragged token count (the reference's token-bucket batches have a new B x L every step, data/sampler.py:11-59) would take
+        # every GEMM of every layer off its planned kernel: in bf16 the layers then run on B L rounded up to whole 256-row tiles --
+        # zero rows appended ONCE here, carried from layer to layer as [rows, H], dropped at the end (ops.padded_rows)
+        B, L = input_.shape[0], input_.shape[1]
+        rows = ops.padded_rows(B * L, input_.dtype) if input_.dim() == 3 and len(self.layer) else B * L
+        padded = rows != B * L
+        if padded:
+            hidden_states = ops.PadRowsFn.apply(hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous(), rows)
         for layer_module in self.layer:
             hidden_states = layer_module(hidden_states, attention_mask)
             if output_all_encoded_layers:
-                all_encoder_layers.append(hidden_states)
+                all_encoder_layers.append(ops.UnpadRowsFn.apply(hidden_states, B, L) if padded else hidden_states)
         if not output_all_encoded_layers:
-            all_encoder_layers.append(hidden_states)
+            all_encoder_layers.append(ops.UnpadRowsFn.apply(hidden_states, B, L) if padded else hidden_states)
         return all_encoder_layers
 
 
@@ -393,7 +401,7 @@ class VLXLMRForPretraining(VLXLMRPreTrainedModel):
         am = batch.get('attn_masks') if hasattr(batch, 'get') else None
         rows = am.numel() if (self.training and torch.is_tensor(am)) else 0
         with ops.accum_pass(st, rows, [v for v in batch.values() if torch.is_tensor(v)] if rows else (),
-                            fp8=_any_fp8(self)) as ap:
+                            fp8=_any_fp8(self), bf16=compute_dtype_of(self) == torch.bfloat16) as ap:
             return ap.mark(self._forward(batch, task, compute_loss))
 
     def _forward(self, batch, task, compute_loss=True):

@@ -48,7 +48,7 @@ from .layer import (  # noqa: F401
 )
 from .functions import (  # noqa: F401
     AddRowFn, AttentionFn, AttentionGeneralFn, CrossEntropyFn, DecoderCEFn, EmbedTextFn, FusedQKVFn, GatherCatRowsFn,
-    GatherRowsFn, GeluFn, KLDivFn, LayerNormFn, LinearFn, MSEFn, MaskEmbedFn, OTDistFn, SelectRowsFn, TiedSubsetDecoderFn,
+    GatherRowsFn, GeluFn, KLDivFn, LayerNormFn, LinearFn, MSEFn, MaskEmbedFn, OTDistFn, PadRowsFn, UnpadRowsFn, padded_rows, SelectRowsFn, TiedSubsetDecoderFn,
     TripletFn, _DEC_ROWS, _dec_chunks, _dgelu, add_rowvec, attn_general_probs_mean, attn_probs_mean,
 )
 

@@ -287,6 +287,52 @@ class EmbedTextFn(torch.autograd.Function):
         return (None,) * 10
 
 
+def padded_rows(M, dtype):
+    """token rows an encoder pass over M = B L tokens runs on: M rounded up to a whole number of 256-row GEMM tiles (bf16, from
+    1 024 tokens, UC2_PAD_ROWS=0 off), else M.  The reference's token-bucket batches have a new B x L every step
+    (data/sampler.py:11-59); a ragged M used to push every GEMM of the step off the ping-pong kernels' plans (bench.py
+    itm_rank_finetune: 612 re-routed calls per 8 steps) and to tune a new shape per step."""
+    if dtype != torch.bfloat16 or not knobs.pad_rows or M < 1024 or M % 256 == 0 or torch.cuda.is_current_stream_capturing():
+        return M
+    return (M + 255) // 256 * 256
+
+
+class PadRowsFn(torch.autograd.Function):
+    """[B, L, H] -> [rows, H], rows >= B L: the tokens followed by zero rows (see padded_rows, BertLayerFn)"""
+
+    @staticmethod
+    def forward(ctx, x, rows):
+        B, L, H = x.shape
+        M = B * L
+        out = torch.empty((rows, H), dtype=x.dtype, device=x.device)
+        out[:M].copy_(x.reshape(M, H))
+        out[M:].zero_()
+        ctx.shape = (B, L, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, L, H = ctx.shape
+        return dy[:B * L].view(B, L, H), None
+
+
+class UnpadRowsFn(torch.autograd.Function):
+    """[rows, H] -> the first B L rows as [B, L, H] (a view); the gradient of the dropped rows is zero"""
+
+    @staticmethod
+    def forward(ctx, x2, B, L):
+        ctx.rows = x2.shape[0]
+        return x2[:B * L].view(B, L, x2.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, L, H = dy.shape
+        out = torch.empty((ctx.rows, H), dtype=dy.dtype, device=dy.device)
+        out[:B * L].copy_(dy.reshape(B * L, H))
+        out[B * L:].zero_()
+        return out, None, None
+
+
 class GatherRowsFn(torch.autograd.Function):
     """torch.gather(src, 1, index[..., None].expand(H)) (model/model.py:420-425)"""
 

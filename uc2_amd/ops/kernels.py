@@ -161,14 +161,17 @@ def _attn_q(q_key, qkv, impl, ilv):
     return _fp8_hist_for(q_key, qkv.device)
 
 
-def attn_fwd(qkv, mask2d, B, L, nh, D, drop_p=0.0, seed=None, seed_imm=0, impl=None, want_lse=True, ilv=False, q_key=None):
+def attn_fwd(qkv, mask2d, B, L, nh, D, drop_p=0.0, seed=None, seed_imm=0, impl=None, want_lse=True, ilv=False, q_key=None, rows=None):
     """ilv: qkv is [B L, nh, 3, D] (q|k|v of a head adjacent per token) instead of [B L, 3, nh, D].
     q_key (fp8 mode): the tensor role of ctx at the GEMM that reads it -- returns a third value, (ctx8, scale) written by the same
     kernel (uc2_attn_fwd_q, delayed scaling) or None when that role has no history yet / the MFMA kernels do not take the shape"""
     H = nh * D
-    ctx = torch.empty((B * L, H), dtype=qkv.dtype, device=qkv.device)
+    rows = B * L if rows is None else rows           # rows > B L: qkv / ctx carry zero-filled rows beyond the batch (BertLayerFn, padded rows)
+    ctx = torch.empty((rows, H), dtype=qkv.dtype, device=qkv.device)
+    if rows > B * L:
+        ctx[B * L:].zero_()
     lse = torch.empty((B, nh, L), dtype=torch.float32, device=qkv.device) if want_lse else None
-    h = _attn_q(q_key, qkv, impl, ilv)
+    h = _attn_q(q_key, qkv, impl, ilv) if rows == B * L else None
     if h is not None:
         c8 = torch.empty((B * L, H), dtype=torch.uint8, device=qkv.device)
         scale = _fp8_cell(qkv.device)[1]
@@ -193,7 +196,9 @@ def attn_bwd(qkv, mask2d, ctx, dctx, lse, B, L, nh, D, drop_p=0.0, seed=None, se
     reference order q | k | v).  ilv: qkv and dqkv are in the head-interleaved layout (see attn_fwd).
     q_key (fp8 mode): returns (dqkv, (dqkv8, scale) or None), the e4m3 copy written by the same kernel (uc2_attn_bwd_q)"""
     dqkv = torch.empty_like(qkv)
-    h = _attn_q(q_key, qkv, impl, ilv)
+    if qkv.shape[0] > B * L:                         # padded rows: their gradient is exactly zero (it is contracted over tokens in dWqkv)
+        dqkv[B * L:].zero_()
+    h = _attn_q(q_key, qkv, impl, ilv) if qkv.shape[0] == B * L else None
     if h is not None:
         d8 = torch.empty(qkv.shape, dtype=torch.uint8, device=qkv.device)
         scale = _fp8_cell(qkv.device)[1]

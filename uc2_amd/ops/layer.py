@@ -101,10 +101,20 @@ class BertLayerFn(torch.autograd.Function):
         if dtype == torch.bfloat16:
             st.sync_shadow()
         P = dict(zip(_P_NAMES, params))
-        B, L, H = x.shape
+        # x is [B, L, H] or -- inside VLXLMREncoder when B L is not a whole number of 256-row GEMM tiles -- [rows, H] with
+        # rows = B L rounded up to 256 (functions.PadRowsFn): every GEMM / LayerNorm of the layer then runs over `rows` token rows (the
+        # planned ping-pong kernels instead of the generic kernel a ragged token count falls back to), attention over the B x L
+        # structure of the mask.  Rows beyond B L hold finite junk in the forward (bias, LayerNorm beta) and exact zeros in every
+        # gradient that is contracted over tokens (the attention tails are zero-filled), so they add nothing to any weight gradient.
+        rows2d = x.dim() == 2
+        if rows2d:
+            (M, H), (B, L) = x.shape, mask2d.shape
+            assert M >= B * L
+        else:
+            B, L, H = x.shape
+            M = B * L
         nh = cfg["nh"]
         D = H // nh
-        M = B * L
         x2 = x.reshape(M, H)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
@@ -135,7 +145,7 @@ class BertLayerFn(torch.autograd.Function):
             # forward-only (retrieval scoring, validation, the hard-negative scoring pass): nothing is kept for a
             # backward -- no gelu' stream out of the FFN1 GEMM, no LayerNorm statistics, no log-sum-exp
             qkv = linear_fwd(x2, wqkv, bqkv)
-            ctxv, _ = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn, want_lse=False, ilv=ilv is not None)
+            ctxv, _ = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn, want_lse=False, ilv=ilv is not None, rows=M)
             del qkv
             fuse = int(knobs.ln_fuse) if (dtype == torch.bfloat16 and M >= knobs.ln_fuse_min_rows) else 0
             o1 = linear_drop_residual(ctxv, st.compute(P["ow"], dtype), P["ob"].data, x2, p_h, seed, s_ln1) if fuse & 1 else None
@@ -153,11 +163,11 @@ class BertLayerFn(torch.autograd.Function):
                 o2 = linear_fwd(u, st.compute(P["fw"], dtype), P["fb"].data)
                 y, _, _ = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, s_ln2, want_stats=False)
             del u
-            return y.view(B, L, H)
+            return y if rows2d else y.view(B, L, H)
         fp8 = bool(cfg.get("fp8")) and dtype == torch.bfloat16 and H % 128 == 0 and P["iw"].shape[0] % 128 == 0
         I_ = P["iw"].shape[0]
         pre = torch.empty((M, I_), dtype=dtype, device=x.device)
-        native = _native_layer_ok(dtype, M, fp8, ilv)
+        native = _native_layer_ok(dtype, M, fp8, ilv) and M == B * L
         if native:
             dev = x.device
             e = lambda *shape, dt_=dtype: torch.empty(shape, dtype=dt_, device=dev)
@@ -196,7 +206,7 @@ class BertLayerFn(torch.autograd.Function):
             x8_, sx_ = xq if xq is not None else fp8_quantize_act(x2, kx)
             qkv = gemm_fp8(x8_, sx_, w8_, sw_, bias=bqkv)
             # (the attention kernel writes the e4m3 copy of ctx the output projection reads; same role key as the stand-alone pass)
-            ctxv, lse, cq = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn, q_key=(_st_uid(st), st.offsets[id(P["ow"])], "fwd", "ctx", state.fp8_tag))
+            ctxv, lse, cq = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn, q_key=(_st_uid(st), st.offsets[id(P["ow"])], "fwd", "ctx", state.fp8_tag), rows=M)
             o1 = linear_fwd_fp8(ctxv, st, P["ow"], P["ow"], (H, H), P["ob"].data, role="ctx", tag=state.fp8_tag, pre_q=cq)
             a, mean1, rstd1, aq = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, s_ln1, q_key=ka)
             # (the FFN1 GEMM's epilogue writes the e4m3 copy of u that FFN2 reads: no quantisation pass over [tokens, 4H])
@@ -205,7 +215,7 @@ class BertLayerFn(torch.autograd.Function):
             o2 = linear_fwd_fp8(u, st, P["fw"], P["fw"], (H, I_), P["fb"].data, role="u", tag=state.fp8_tag, pre_q=uq)
         else:
             qkv = linear_fwd(x2, wqkv, bqkv)
-            ctxv, lse = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn, ilv=ilv is not None)
+            ctxv, lse = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn, ilv=ilv is not None, rows=M)
             # The dense -> dropout -> + residual tails: with LN_FUSE the Wo / FFN2 GEMM writes the pre-LayerNorm SUM (dropout mask and
             # residual in its epilogue), the LayerNorm reads one tensor and hashes no mask; o1 / o2 then hold the sums and the
             # backward runs the LayerNorm in its drop_after = 2 form (fused1 / fused2 say which form each tail took)
@@ -242,8 +252,9 @@ class BertLayerFn(torch.autograd.Function):
         ctx.layer, ctx.cfg, ctx.shape, ctx.p = layer, cfg, (B, L, H, nh, D), (p_h, p_a, (s_attn, s_ln1, s_ln2))
         ctx.params, ctx.fp8, ctx.fp8_tag = params, fp8, state.fp8_tag
         ctx.native = native
+        ctx.rows2d = rows2d
         ctx.ilv_plan = ilv[1] if ilv is not None else None
-        return y.view(B, L, H)
+        return y if rows2d else y.view(B, L, H)
 
     @staticmethod
     def backward(ctx, dy):
@@ -253,7 +264,9 @@ class BertLayerFn(torch.autograd.Function):
         P = dict(zip(_P_NAMES, ctx.params))
         st = store_of(ctx.layer)
         dtype = x2.dtype
-        M = B * L
+        M = x2.shape[0]                         # B L, or B L rounded up to 256 rows (see forward)
+        rows2d = ctx.rows2d
+        out_shape = (M, H) if rows2d else (B, L, H)
         dy2 = dy.reshape(M, H)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
@@ -339,7 +352,7 @@ class BertLayerFn(torch.autograd.Function):
         dwqkv = st.grad_span(P["qw"], P["vw"], (3 * H, H))
         if nat is not None:
             wgrad(dqkv, x2, dwqkv)
-            return BertLayerFn._finish_backward(ctx, grouped, dy2, None if dxn is None else dxn.view(B, L, H))
+            return BertLayerFn._finish_backward(ctx, grouped, dy2, None if dxn is None else dxn.view(out_shape))
         dctx = linear_dgrad_fp8(d_o1, st, P["ow"], P["ow"], (H, H), role="d_o1", tag=ctx.fp8_tag, pre_q=dq1) if fp8 else linear_dgrad(d_o1, st.compute(P["ow"], dtype), wt=WT(P["ow"]))
         dwqkv = st.grad_span(P["qw"], P["vw"], (3 * H, H))
         dbqkv = st.grad_span(P["qb"], P["vb"], (3 * H,))
@@ -368,16 +381,16 @@ class BertLayerFn(torch.autograd.Function):
                 _wg()
             dx = None
             if ctx.needs_input_grad[0]:
-                dx = linear_dgrad(dqkv, w_ilv, EPI_ADD, dz1, wt=wt_ilv if use_wt else None).view(B, L, H)
+                dx = linear_dgrad(dqkv, w_ilv, EPI_ADD, dz1, wt=wt_ilv if use_wt else None).view(out_shape)
         else:
             wgrad(dqkv, x2, dwqkv)
             dx = None
             if ctx.needs_input_grad[0]:
                 if fp8:
-                    dx = linear_dgrad_fp8(dqkv, st, P["qw"], P["vw"], (3 * H, H), EPI_ADD, dz1, role="dqkv", tag=ctx.fp8_tag, pre_q=dqq).view(B, L, H)
+                    dx = linear_dgrad_fp8(dqkv, st, P["qw"], P["vw"], (3 * H, H), EPI_ADD, dz1, role="dqkv", tag=ctx.fp8_tag, pre_q=dqq).view(out_shape)
                 else:
                     dx = linear_dgrad(dqkv, st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype), EPI_ADD, dz1,
-                                      wt=WT(P["qw"], P["vw"], (3 * H, H))).view(B, L, H)
+                                      wt=WT(P["qw"], P["vw"], (3 * H, H))).view(out_shape)
         return BertLayerFn._finish_backward(ctx, grouped, dy2, dx)
 
     @staticmethod

@@ -134,11 +134,11 @@ class accum_pass:
     """`with accum_pass(model_store, rows, tensors) as ap: out = ap.mark(forward(...))` -- see the block comment above.
     Inactive (a plain pass on the caller's stream) whenever one of the conditions does not hold."""
 
-    def __init__(self, store, rows, tensors, fp8=False):
+    def __init__(self, store, rows, tensors, fp8=False, bf16=True):
         self.state = None
         t0 = next((t for t in tensors if torch.is_tensor(t) and t.is_cuda), None)
         if not (knobs.accum_overlap and t0 is not None and torch.is_grad_enabled() and 0 < rows < knobs.accum_overlap_max_rows and not fp8
-                and not (store.shadow is not None and store.auto_sync) and not torch.cuda.is_current_stream_capturing()):
+                and not (bf16 and store.auto_sync) and not torch.cuda.is_current_stream_capturing()):
             return
         self.state = _accum_state(t0.device)
         self.store = store
