@@ -83,8 +83,8 @@ def main():
                 n_h = max(2, int(n_g * t_g / (t_h * slow)))
                 torch.cuda.synchronize()
                 cur = torch.cuda.current_stream()
-                w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                w0.record()
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
                 A.wait_stream(cur)
                 Bs.wait_stream(cur)
                 with torch.cuda.stream(A):
@@ -93,10 +93,10 @@ def main():
                 eb = timed(Bs, hfn, n_h)
                 cur.wait_stream(A)
                 cur.wait_stream(Bs)
-                w1.record()
+                ev1.record()
                 torch.cuda.synchronize()
                 ta, tb = ea[0].elapsed_time(ea[1]) / n_g * 1e3, eb[0].elapsed_time(eb[1]) / n_h * 1e3
-                wall = w0.elapsed_time(w1) * 1e3
+                wall = ev0.elapsed_time(ev1) * 1e3
                 serial = (n_g + 1) * t_g + n_h * t_h
                 print("   spare %2d CUs: GEMM alone %.1f us, beside %.1f us (x%.3f) | HBM kernel beside the GEMM %.1f us (x%.2f of alone) | "
                       "%d GEMMs + %d HBM launches: together %.0f us, one after the other %.0f us (x%.3f)"
