@@ -77,7 +77,8 @@ def pending_side_stream(device):
 #     (the arena's += are not atomic);
 #   * every consumer of gradients (AdamW.step, clip_grad_norm_, all_reduce_and_rescale_tensors, zero_grad -- they all call
 #     join_side_streams()) makes its stream wait for both; the per-layer all-reduce hooks of GradSync run inside the pass.
-# Same micro-batches, same dropout seeds in the same order, bit-identical gradients (same kernels, same accumulation order).
+# Same micro-batches, same dropout seeds in the same order, same kernels, same accumulation order: gradients equal to the order of
+# the float atomics (what two runs on one stream differ by).
 # Off for: eval / no-grad forwards, fp8 stores (delayed-scaling histories assume one in-order stream), stores whose bf16 copies
 # are re-cast at every forward (store.auto_sync: the re-cast would race with the backward beside it; AdamW.step turns auto_sync
 # off), stream capture, UC2_ACCUM_OVERLAP=0.  Measured: profiles/r06_experiments.md.
