@@ -30,11 +30,14 @@ def _dev(b):
 
 @pytest.mark.parametrize("task,drop", [("itm", 0.0), ("mlm", 0.0), ("itm", 0.1)])
 def test_padded_rows_are_invisible(task, drop):
-    """A variable-length batch whose B x L is NOT a multiple of 256 (56 pairs x 37..60 positions), 3 layers of base width, bf16:
-    with the rows padded (default) against UC2_PAD_ROWS=0 -- the SAME dropout masks (a function of seed, site, row, column), scores,
-    losses and every gradient equal to bf16 kernel-choice noise (the padded run takes the ping-pong kernels, the ragged one the
-    ring / generic kernels: other summation orders), nothing non-finite; with all_encoded_layers the per-layer outputs come back
-    as [B, L, H]; and the padded run leaves no GEMM off its plan."""
+    """A variable-length batch whose B x L is NOT a multiple of 256 (56 pairs x 60 positions = 3 360 tokens -> 3 584 rows), 3 layers
+    of base width, ONE model: bf16 with the rows padded (default) and with UC2_PAD_ROWS=0, and -- dropout off -- the fp32 parity
+    mode of the same weights as the reference both are measured against.  The padded run takes other GEMM kernels (whole 256-row
+    tiles: other summation orders, other bf16 roundings), so it is held to what bf16 itself costs: losses and the last hidden state
+    equal to bf16 rounding, every gradient as close to the fp32 gradient as the ragged run's is (the softmax-invariant key bias,
+    whose true gradient is zero, excepted).  With dropout on (same model, same seed: the same masks, a function of seed, site, row,
+    column) losses agree and the dense weights' gradients agree to bf16 noise.  Nothing non-finite; with all_encoded_layers the
+    per-layer outputs come back as [B, L, H]; the padded run leaves no GEMM off its plan."""
     geom = dict(O.BASE, num_hidden_layers=3, vocab_size=2000)
     batch = _dev(synth.make_batch(2000, 56, 40, 20, task=task, seed=31, variable_len=True))
     B, L = batch["attn_masks"].shape
@@ -42,15 +45,17 @@ def test_padded_rows_are_invisible(task, drop):
     assert M >= 1024 and M % 256 != 0, (B, L)
     res = {}
     was = knobs.pad_rows
-    # ONE model for both runs (dropout sites are keyed by the layers' process-wide ids: two instances draw different masks)
+    # ONE model for all runs (dropout sites are keyed by the layers' process-wide ids: two instances draw different masks)
     model = VLXLMRForPretraining(_cfg(geom, drop), img_dim=2048, img_label_dim=1601)
     synth.det_init_(model)
     model.to(DEV)
-    set_compute_dtype(model, torch.bfloat16)
     try:
-        for pad in (False, True):
+        for tag, dtype, pad in (("f32", torch.float32, False), ("ragged", torch.bfloat16, False), ("padded", torch.bfloat16, True)):
+            if tag == "f32" and drop:
+                continue
             knobs.pad_rows = pad
-            assert ops.padded_rows(M, torch.bfloat16) == ((M + 255) // 256 * 256 if pad else M)
+            set_compute_dtype(model, dtype)
+            assert ops.padded_rows(M, dtype) == ((M + 255) // 256 * 256 if tag == "padded" else M)
             model.train()
             ops.rng.manual_seed(99, DEV)
             model.zero_grad()
@@ -67,27 +72,34 @@ def test_padded_rows_are_invisible(task, drop):
                 seqs = model.roberta(batch["input_ids"], None, batch["img_feat"], batch["img_pos_feat"], batch["attn_masks"],
                                      batch["gather_index"], output_all_encoded_layers=True)
             assert len(seqs) == 3 and all(tuple(s_.shape) == (B, L, 768) for s_ in seqs)
-            res[pad] = (loss.detach().float().clone(), grads, seqs[-1].float().clone(), fb)
+            res[tag] = (loss.detach().float().clone(), grads, seqs[-1].float().clone(), fb)
     finally:
         knobs.pad_rows = was
     del model
-    (l0, g0, s0, _), (l1, g1, s1, fb1) = res[False], res[True]
+    (l0, g0, s0, _), (l1, g1, s1, fb1) = res["ragged"], res["padded"]
     assert fb1 == 0, fb1
-    assert torch.isfinite(l1).all() and torch.isfinite(s1).all()
+    assert torch.isfinite(l1).all() and torch.isfinite(s1).all() and all(torch.isfinite(v).all() for v in g1.values())
     assert rel_err(l1, l0) < 2e-3, rel_err(l1, l0)
     assert rel_err(s1, s0) < 1e-2, rel_err(s1, s0)
     assert set(g0) == set(g1)
-    worst = ("", 0.0)
+    worst = ("", 0.0, 0.0)
     for n in g0:
-        assert torch.isfinite(g1[n]).all(), n
-        if g0[n].norm() < 1e-7:
-            assert g1[n].norm() < 1e-6, n
+        if ".key.bias" in n:
+            continue                            # softmax is invariant to a constant added to every key: the true gradient is 0, both runs hold noise
+        if drop:
+            if n.endswith(".weight") and g0[n].dim() == 2 and "encoder.layer" in n:
+                e = rel_err(g1[n], g0[n])
+                worst = max(worst, (n, e, 0.0), key=lambda t: t[1])
+                assert e < 0.06, (n, e)
             continue
-        e = rel_err(g1[n], g0[n])
-        worst = max(worst, (n, e), key=lambda t: t[1])
-        assert e < (3e-2 if drop == 0.0 else 5e-2), (n, e)
-    print("padded vs ragged rows, %s drop %.1f: %d x %d tokens, loss rel %.2e, last hidden rel %.2e, worst gradient %s %.2e"
-          % (task, drop, B, L, rel_err(l1, l0), rel_err(s1, s0), worst[0], worst[1]))
+        ref = res["f32"][1][n]
+        if ref.norm() < 1e-7:
+            continue
+        e_p, e_r = rel_err(g1[n], ref), rel_err(g0[n], ref)
+        worst = max(worst, (n, e_p, e_r), key=lambda t: t[1])
+        assert e_p < 2.0 * e_r + 0.02, (n, e_p, e_r)
+    print("padded vs ragged rows, %s drop %.1f: %d x %d tokens, loss rel %.2e, last hidden rel %.2e, worst gradient %s: padded %.3g (ragged %.3g) vs fp32"
+          % (task, drop, B, L, rel_err(l1, l0), rel_err(s1, s0), worst[0], worst[1], worst[2]))
 
 
 def test_padded_rows_fp32_mode_is_untouched_and_retrieval_model_pads():
