@@ -727,6 +727,27 @@ def main():
                     "note": "the same window with UC2_ACCUM_OVERLAP=0: every forward and backward on one stream (rounds 1-5)"}
         finally:
             knobs.accum_overlap = ov_was
+        # ---- the same regime on RAGGED micro-batches: real batches of the reference have a new B x L every step (token-bucket
+        # sampler, data/sampler.py:11-59), not the tile-friendly 104 x 96 above.  104 pairs with text 10-60 / 10-36 regions, padded to
+        # the micro-batch's longest pair like the reference's collate does; the encoder then runs on B L rounded up to whole 256-row
+        # GEMM tiles (ops.padded_rows, UC2_PAD_ROWS) -- timed with that on (default) and off.
+        rag = [synth_batch_varlen(REF_MICRO, "itm", 9500 * (rank + 1) + i, dev)[0] for i in range(4 * REF_ACCUM)]
+        rag_tokens = [int(b_["attn_masks"].numel()) for b_ in rag]
+        pad_was = knobs.pad_rows
+        try:
+            for pad_on in (True, False):
+                knobs.pad_rows = pad_on
+                ops.gemm_fallbacks(reset=True)
+                d8, _ = timed(lambda i: opt_step(rag[(i % 4) * REF_ACCUM:(i % 4 + 1) * REF_ACCUM], "itm"), 8, k3)
+                workloads["reference_regime_itm_ragged" + ("" if pad_on else "_unpadded")] = {
+                    "pairs_per_s": round(REF_MICRO * REF_ACCUM * world * k3 / d8, 1), "ms_per_optimizer_step": round(d8 / k3 * 1e3, 2),
+                    "tokens_per_micro_batch": sorted(set(rag_tokens)), "gemm_fallbacks": ops.gemm_fallbacks(),
+                    "note": ("104-pair micro-batches x 3 with variable lengths (text 10-60, 10-36 regions; a different B x L per micro-batch), "
+                             + ("token rows rounded up to whole 256-row GEMM tiles inside the encoder (default)" if pad_on else
+                                "UC2_PAD_ROWS=0: the ragged token counts as they come (rounds 1-5)"))}
+        finally:
+            knobs.pad_rows = pad_was
+        del rag
         del rb
         # ---- BASELINE.json configs[2] as SURVEY.md 8(d) specifies it, on this GPU: the pretrain task mix itm : mlm : vmlm : tlm =
         # 9 : 12 : 9 : 3 (config/uc2_pretrain.json:72-76,100-102), one task per accumulation window like MetaLoader

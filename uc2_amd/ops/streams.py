@@ -3,6 +3,8 @@ consumer of gradients performs.  Part of uc2_amd.ops."""
 
 import torch
 
+from .. import _lib
+from .. import store as _store
 from ..config import cfg as knobs
 
 
@@ -91,6 +93,8 @@ class _AccumState:
         self.streams = (torch.cuda.Stream(device), torch.cuda.Stream(device))
         self.k = 0                         # eligible forwards since the last join
         self.used = [False, False]
+        self.raw = tuple(s_.cuda_stream for s_ in self.streams)
+        self.unjoined = False              # a backward pass was enqueued here that the caller's stream has not been ordered behind yet
         self.passes = 0                    # (statistics: passes that ran on the overlap streams)
 
 
@@ -112,6 +116,29 @@ def join_accum_streams():
                     cur.wait_stream(st.streams[i])
             st.used = [False, False]
         st.k = 0
+        st.unjoined = False
+    _store._GRAD_ACCESS[0] = None
+
+
+def _on_grad_access():
+    """ArenaParameter.grad was read or written from Python while a backward pass enqueued on an overlap stream may still be running:
+    the accessing stream waits for the passes in flight -- unless it IS one of the overlap streams (the library's own code inside a
+    pass: stream order covers it).  One wait per backward pass, whatever the number of parameters read."""
+    raw = _lib.stream()
+    pending = False
+    for st in _accum.values():
+        if not st.unjoined:
+            continue
+        if raw in st.raw:
+            pending = True                   # inside a pass: leave the hook armed for the caller's stream
+            continue
+        cur = torch.cuda.current_stream(st.device)
+        for i in (0, 1):
+            if st.used[i]:
+                cur.wait_stream(st.streams[i])
+        st.unjoined = False
+    if not pending:
+        _store._GRAD_ACCESS[0] = None
 
 
 class _AccumMarker(torch.autograd.Function):
@@ -128,6 +155,8 @@ class _AccumMarker(torch.autograd.Function):
         st, i = ctx.state, ctx.idx
         if st.used[1 - i]:
             st.streams[i].wait_stream(st.streams[1 - i])
+        st.unjoined = True                  # from here on .grad views are being written on this stream: store.ArenaParameter.grad
+        _store._GRAD_ACCESS[0] = _on_grad_access
         return g, None, None
 
 

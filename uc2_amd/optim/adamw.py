@@ -10,6 +10,8 @@ import ctypes
 
 import numpy as np
 import torch
+
+_tensor_grad = torch.Tensor.grad
 from torch.optim import Optimizer
 
 from .. import _lib
@@ -200,7 +202,7 @@ class AdamW(Optimizer):
             if zero_grad:
                 st.grad_epoch += 1
                 for p in st.params:
-                    p.grad = None
+                    _tensor_grad.__set__(p, None)
                     p._uc2_gepoch = st.grad_epoch
         return loss
 

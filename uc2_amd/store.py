@@ -22,6 +22,40 @@ _ALIGN = 64                      # elements; keeps every view 16-byte aligned in
 _ROW_TILE = 256                  # large tables are followed by zero rows up to a multiple of the GEMM tile (see padded())
 _PAD_MIN = 65536                 # ... when they have at least this many rows / elements (the 250 002-row vocabulary tables)
 _STORES = weakref.WeakSet()
+_GRAD_ACCESS = [None]            # hook run by ArenaParameter.grad (set by ops/streams.py: orders the caller's stream behind the
+                                 # accumulation-overlap passes still in flight); None = nothing pending, the attribute costs one check
+_tensor_grad = torch.Tensor.grad
+
+
+def raw_grad(p):
+    """p.grad without the ArenaParameter hook (library code that runs inside a pass or behind a join)"""
+    return _tensor_grad.__get__(p, type(p))
+
+
+class ArenaParameter(torch.nn.Parameter):
+    """nn.Parameter re-homed into a ParamStore.  Its gradient is a view of the gradient arena that the kernels of a backward pass
+    write directly -- and with the accumulation overlap (ops/streams.py::accum_pass) that pass may still be running on one of the
+    two overlap streams when `backward()` returns.  Every Python-level access to `.grad` from another stream therefore first makes
+    that stream wait for the passes in flight (torch.nn.utils.clip_grad_norm_, an optimizer of the caller's, logging code: no
+    caller has to know).  Same storage, same class hierarchy (`isinstance(p, nn.Parameter)`), same state_dict."""
+
+    @property
+    def grad(self):
+        h = _GRAD_ACCESS[0]
+        if h is not None:
+            h()
+        return _tensor_grad.__get__(self, type(self))
+
+    @grad.setter
+    def grad(self, value):
+        h = _GRAD_ACCESS[0]
+        if h is not None:
+            h()
+        _tensor_grad.__set__(self, value)
+
+    @grad.deleter
+    def grad(self):
+        _tensor_grad.__delete__(self)
 
 
 def _slot_numel(p):
@@ -97,9 +131,11 @@ class ParamStore:
                 v = self.view(self.data, p)
                 v.copy_(p.data)
                 p.data = v
+                if type(p) is torch.nn.Parameter:
+                    p.__class__ = ArenaParameter   # (reads of .grad wait for overlapped backward passes: see the class)
                 p._uc2_store = self
                 p._uc2_gepoch = -1
-                if p.grad is not None:            # keep an existing gradient (folded into the arena)
+                if raw_grad(p) is not None:       # keep an existing gradient (folded into the arena)
                     self.grad_buf(p)
         self.shadow = None
         self.version = 1
@@ -140,15 +176,15 @@ class ParamStore:
         """fp32 accumulation buffer for p (a view of the gradient arena), installed as p.grad"""
         self._ensure_grad()
         v = self.view(self.grad, p)
-        g = p.grad
+        g = raw_grad(p)
         if g is None:
             if p._uc2_gepoch != self.grad_epoch:      # slice not known to be zero
                 v.zero_()
-            p.grad = v
+            _tensor_grad.__set__(p, v)
             p._uc2_gepoch = -1
         elif g.data_ptr() != v.data_ptr():            # foreign gradient tensor: fold it in
             v.copy_(g)
-            p.grad = v
+            _tensor_grad.__set__(p, v)
             p._uc2_gepoch = -1
         return v
 
@@ -165,7 +201,7 @@ class ParamStore:
             self.grad.zero_()
         self.grad_epoch += 1
         for p in self.params:
-            p.grad = None
+            _tensor_grad.__set__(p, None)
             p._uc2_gepoch = self.grad_epoch
 
     def pin_grad_accumulators(self):
