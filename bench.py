@@ -734,6 +734,7 @@ def main():
         rag = [synth_batch_varlen(REF_MICRO, "itm", 9500 * (rank + 1) + i, dev)[0] for i in range(4 * REF_ACCUM)]
         rag_tokens = [int(b_["attn_masks"].numel()) for b_ in rag]
         pad_was = knobs.pad_rows
+        plans_was = dict(ops._TUNE)                  # (the unpadded leg tunes a plan per ragged shape: not left behind for the workloads below)
         try:
             for pad_on in (True, False):
                 knobs.pad_rows = pad_on
@@ -747,6 +748,8 @@ def main():
                                 "UC2_PAD_ROWS=0: the ragged token counts as they come (rounds 1-5)"))}
         finally:
             knobs.pad_rows = pad_was
+            ops._TUNE.clear()
+            ops._TUNE.update(plans_was)
         del rag
         del rb
         # ---- BASELINE.json configs[2] as SURVEY.md 8(d) specifies it, on this GPU: the pretrain task mix itm : mlm : vmlm : tlm =

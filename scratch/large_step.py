@@ -17,7 +17,7 @@ set_compute_dtype(model, torch.bfloat16)
 opt = AdamW(param_groups(model, 0.01), lr=2e-5, betas=(0.9, 0.98))
 st = store_of(model); st.sync_shadow(); st.auto_sync = False
 uc2_amd.set_fp8(model, sys.argv[1] == "fp8")
-b = bench.synth_batch(256, "itm", 3, dev, 80, 50)
+b = bench.synth_batch(int(os.environ.get("PAIRS", "1024")), "itm", 3, dev, 80, 50)      # (round 5 profiled 256 pairs)
 import time
 N = int(os.environ.get("STEPS", "8"))
 for i in range(N + 4):

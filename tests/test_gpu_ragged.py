@@ -136,3 +136,20 @@ def test_padded_rows_fp32_mode_is_untouched_and_retrieval_model_pads():
     # (the triplet gradient at initialisation is a difference of large cancelling terms; the padded run takes other GEMM kernels --
     #  other summation orders, other bf16 roundings: measured 8.4 %, the bf16 golden tests allow the ITM gradient 7 % against fp32)
     assert rel_err(out[True][1], out[False][1]) < 0.15 or out[False][1].norm() < 1e-7
+
+
+@pytest.mark.parametrize("M", [12000, 3077, 1024 + 255])
+def test_ragged_weight_gradient_runs_as_planned_bulk_plus_generic_tail(M):
+    """dW += dY^T X over a token count that is not a multiple of 64 (the image projection of a variable-length batch): whole 256-row
+    tiles on the planned kernel + the remaining rows on the generic one, both accumulating into the fp32 gradient -- against fp32
+    torch on the bf16 operands, with a non-zero dW to accumulate into; the bias gradient is the column sum over ALL rows."""
+    N, K = 768, 2048
+    dy = (synth.det_normal((M, N), 1) * 0.1).to(DEV).to(torch.bfloat16)
+    x = synth.det_normal((M, K), 2).to(DEV).to(torch.bfloat16)
+    dw0 = synth.det_normal((N, K), 3).to(DEV)
+    dw, db = dw0.clone(), torch.zeros(N, device=DEV)
+    ops._linear_wgrad_now(dy, x, dw, db)
+    torch.cuda.synchronize()
+    want = dw0 + dy.float().t() @ x.float()
+    assert rel_err(dw, want) < 2e-5, rel_err(dw, want)
+    assert rel_err(db, dy.float().sum(0)) < 1e-5

@@ -4,7 +4,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-R=${1:-5}
+R=${1:-6}
 O=gpurun_out/r0${R}p
 mkdir -p $O
 python3 bench.py --steps 10 --warmup 3 > $O/bench_n1.json 2> $O/bench_n1.err

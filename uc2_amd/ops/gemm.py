@@ -138,7 +138,9 @@ _BORROWED = {}            # shapes without a measured plan that run on the plan 
 def gemm_fallbacks(reset=False):
     """calls since load (or the last reset) whose plan named a ping-pong kernel but ran on another one (library counter)"""
     return int(_lib.load().uc2_gemm_fallback_count(int(bool(reset))))
-_MAX_TUNED = 256          # cap on tuned shapes (each tuning costs ~30 candidates x 7 launches + a host sync)
+_MAX_TUNED = 1024         # cap on tuned shapes (each tuning costs ~30 candidates x 7 launches + a host sync).  256 until round 6: a run
+                          # that met many ragged token counts filled the table and every LATER shape ran on the library default for
+                          # good (bench.py: uc2-large at 241.7 ms per step tuned, 331.1 ms after a ragged workload had filled the table)
 
 
 def _bucket_key(key):
@@ -221,8 +223,22 @@ def gemm_plan(dtype, ta, tb, M, N, K, wgrad=False):
     if hit is not None:
         return hit
     default = (-2, _wgrad_split(dtype, M, N, K) if wgrad else 1)
-    if (not knobs.autotune) or float(M) * N * K < 2.0 ** 31 or torch.cuda.is_current_stream_capturing():
+    if float(M) * N * K < 2.0 ** 31:
         return default
+    # what an untuned shape runs on (autotune off, table full, stream capture): from 16 384 tokens every committed plan is the
+    # ping-pong kernel on the 16x16x32 MFMA when the shape is made of whole tiles -- say so instead of leaving it to the library's
+    # default (a ring kernel); weight gradients with the split closest to one (tile, split) item per CU, like the tuner's candidates
+    fallback = default
+    if (K if wgrad else M) >= 16384:
+        if not wgrad and _plan_fits((12, 1), key):
+            fallback = (12, 1)
+        elif wgrad and M % 256 == 0 and N % 256 == 0:
+            valid = [s_ for s_ in range(1, 129) if s_ * 256 <= K and _plan_fits((12, s_), key)]
+            if valid:
+                tiles = (M // 256) * (N // 256)
+                fallback = (12, min(valid, key=lambda s_: (abs(tiles * s_ - 256), s_)))
+    if (not knobs.autotune) or torch.cuda.is_current_stream_capturing():
+        return fallback
     # The token dimension (M forward / dgrad, K for weight gradients) changes almost every step under the reference's
     # token-bucket batching (data/sampler.py:11-59): tune one representative per 512-token bucket and reuse its plan
     # if the kernel accepts the real shape (tile divisibility is re-checked by the library, which falls back to the
@@ -233,7 +249,7 @@ def gemm_plan(dtype, ta, tb, M, N, K, wgrad=False):
         _TUNE[key] = hit
         return hit
     if len(_TUNE) >= _MAX_TUNED:
-        return default
+        return fallback
     dev = torch.device("cuda", torch.cuda.current_device())
     a = torch.randn((K, M) if ta else (M, K), device=dev).to(torch.bfloat16)
     b = torch.randn((K, N) if tb else (N, K), device=dev).to(torch.bfloat16)

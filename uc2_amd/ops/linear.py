@@ -7,7 +7,7 @@ import torch
 from .. import _lib
 from .._lib import call, dt, ptr, stream
 from ..config import cfg as knobs, state
-from .base import EPI_ADD, EPI_DGELU, EPI_NONE
+from .base import EPI_ADD, EPI_DGELU, EPI_NONE, GEMM_GENERIC
 from .streams import _on_side_stream, _side_route
 from .gemm import _BORROWED, _TUNE, _bucket_key, _gemm_planned, _gemm_queue, _plan_fits, _splitk_workspace, gemm
 
@@ -89,7 +89,16 @@ def linear_dgrad(dy2, w, epi=EPI_NONE, aux_in=None, colsum_out=None, flags=0, wt
 def _linear_wgrad_now(dy2, x2, dw, db):
     M, N = dy2.shape
     K = x2.shape[1]
-    _gemm_planned(dy2, x2, N, K, M, True, True, wgrad=True, out=dw, accumulate=True, flags=(knobs.wgrad_spare & 7) << 28)
+    M0 = M // 256 * 256
+    if dy2.dtype == torch.bfloat16 and M0 >= 1024 and M0 != M and dy2.is_contiguous() and x2.is_contiguous():
+        # a ragged token count (the image projection of a variable-length batch: B x max(num_bb) rows; the encoder layers pad
+        # theirs, ops.padded_rows): the contraction runs over the tokens, so a count that is not a multiple of 64 sends the WHOLE
+        # weight gradient to the generic kernel -- and every new count is a new shape for the plan table.  Whole 256-row tiles on
+        # the planned kernel, the < 256 remaining rows on the generic one, both accumulating into dw.
+        _gemm_planned(dy2[:M0], x2[:M0], N, K, M0, True, True, wgrad=True, out=dw, accumulate=True, flags=(knobs.wgrad_spare & 7) << 28)
+        gemm(dy2[M0:], x2[M0:], N, K, M - M0, ta=True, tb=True, out=dw, accumulate=True, split_k=1, variant=GEMM_GENERIC)
+    else:
+        _gemm_planned(dy2, x2, N, K, M, True, True, wgrad=True, out=dw, accumulate=True, flags=(knobs.wgrad_spare & 7) << 28)
     if db is not None:
         colsum_accum(dy2, db)
 
