@@ -849,7 +849,7 @@ def main():
                        "peak_reserved_memory_GB": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1),
                        "dgrad_routes": {"%dx%dx%d epi %d" % k: v for k, v in sorted(ops.DGRAD_ROUTES.items())},
                        "gemm_plans": {"%s%s %dx%dx%d" % ("T" if k[0] else "N", "T" if k[1] else "N", k[2], k[3], k[4]):
-                                      "%s split %d" % ("generic" if v[0] == 99 else "ping-pong" if v[0] == 8 else "ping-pong 192" if v[0] == 9 else "ping-pong 16x16x32" if v[0] == 12 else "ring v%d" % v[0], v[1])
+                                      "%s split %d" % ("generic" if v[0] == 99 else "ping-pong" if v[0] == 8 else "ping-pong 192" if v[0] == 9 else "ping-pong 128" if v[0] == 5 else "ping-pong 16x16x32" if v[0] == 12 else "ring v%d" % v[0], v[1])
                                       for k, v in sorted(ops._TUNE.items())}},
             "mfma_frac_encoder": round(value * ENC_GFLOP_PER_PAIR * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": {"bound": "mfma", "kernel": kname,

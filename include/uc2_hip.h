@@ -52,7 +52,8 @@ int uc2_gemm(int dtype, int trans_a, int trans_b, int M, int N, int K, const voi
 /* Per-call plan -- the library keeps NO process-global kernel-selection state and reads no environment variables:
  *   variant    UC2_GEMM_AUTO = the library's default kernel for the shape; UC2_GEMM_GENERIC = the register-staged
  *              kernel (any shape/alignment); 0..12 = one specific kernel (0-2 LDS-DMA rings, 6/7 wave-specialised
- *              rings, 8 = persistent ping-pong 256x256 on v_mfma_f32_32x32x16_bf16, 9 = the same with 192-row tiles, 12 = the same
+ *              rings, 8 = persistent ping-pong 256x256 on v_mfma_f32_32x32x16_bf16, 9 = the same with 192-row tiles, 5 = with 128-row
+ *              tiles (bf16 X W^T / dY W with no or a +residual epilogue: the N = 768 shapes at ~10 k tokens), 12 = the same
  *              schedule on v_mfma_f32_16x16x32_bf16 (less energy per flop: +4..8 % on X W^T and dY W; calls 12 does not cover run as 8);
  *              10, 11, 13 and 14 were experiment kernels -- rolling epilogue, two phases per k-tile, one wave per SIMD with and without
  *              the epilogue in the next item's MFMA gaps: experiments/csrc/, built only by `make EXPERIMENTS=1` -- and are
@@ -98,7 +99,7 @@ int uc2_gemm_drop_residual(int M, int N, int K, const void* A, int lda, const vo
                            const void* residual, int ldres, float p_drop, const uint64_t* seed_ptr, uint64_t seed_imm, int flags,
                            void* queue, void* stream);
 /* Diagnostics: number of uc2_gemm / uc2_gemm_queued calls since load (or since the last reset != 0) that named a ping-pong kernel
- * (variant 8 / 9 / 12) and were run by another kernel because the shape, an alignment or the 32-bit staging-offset limit
+ * (variant 5 / 8 / 9 / 12) and were run by another kernel because the shape, an alignment or the 32-bit staging-offset limit
  * (an operand of 4 GiB or more) did not qualify.  bench.py prints it as config.gemm_fallbacks; nothing selects a kernel from it. */
 long long uc2_gemm_fallback_count(int reset);
 /* Diagnostics only: e4m3 GEMM calls (uc2_gemm_fp8 / uc2_gemm_fp8_q) since the last reset that ran on the ring kernel (which = 0:

@@ -993,6 +993,36 @@ def test_gemm_pingpong_192_row_tiles(tb, epi, M, N, K):
     assert rel_err(o1.float(), ref.float()) < 3e-3
 
 
+@pytest.mark.parametrize("tb,epi", [(False, "none"), (True, "none"), (True, "add")])
+@pytest.mark.parametrize("M,N,K", [(128, 256, 128), (768, 768, 768), (1536, 256, 3072), (9984, 768, 3072), (9984, 768, 2304), (49152 // 4 + 128, 768, 768)])
+def test_gemm_pingpong_128_row_tiles(tb, epi, M, N, K):
+    """variant 5 (round 6: 128-row tiles = 64 rows per wave row, no unit A1, 6 LDS-DMA instructions per k-tile; phases 2 and 3 of a
+    k-tile keep their barriers and run no MFMA): the N = 768 shapes of the reference's 104-pair micro-batch (9 984 tokens: 234 tiles
+    for 256 CUs instead of 117), one-item and many-item workgroups, odd tile counts -- bit for bit the 256-row variant 8 (same
+    accumulation order per output element: k-tile by k-tile, fp32 sums started at the bias) where M is a multiple of 256, against
+    the generic kernel everywhere, NaN-filled outputs, twice (race screen), and nothing re-routed."""
+    a = rnd((M, K), 1, dtype=torch.bfloat16)
+    b = rnd((K, N) if tb else (N, K), 2, 0.05, dtype=torch.bfloat16)
+    bias = None if tb else rnd((N,), 3)
+    aux = rnd((M, N), 4, dtype=torch.bfloat16) if epi == "add" else None
+    code = ops.EPI_ADD if epi == "add" else ops.EPI_NONE
+
+    def run(v):
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.gemm(a, b, M, N, K, tb=tb, bias=bias, epi=code, aux_in=aux, out=out, variant=v)
+        return out
+    ref = run(GENERIC)
+    ops.gemm_fallbacks(reset=True)
+    o1 = run(5)
+    o2 = run(5)
+    assert ops.gemm_fallbacks() == 0
+    assert torch.isfinite(o1.float()).all()
+    assert torch.equal(o1.view(torch.int16), o2.view(torch.int16))
+    assert rel_err(o1.float(), ref.float()) < 3e-3
+    if M % 256 == 0:
+        assert torch.equal(o1.view(torch.int16), run(8).view(torch.int16))
+
+
 @pytest.mark.parametrize("variant", [8, 12])
 @pytest.mark.parametrize("epi", ["none", "gelu", "gelu_d", "add", "tanh", "dgelu", "mul"])
 def test_gemm_pingpong_epilogues_with_second_streams(epi, variant):

@@ -411,7 +411,7 @@ extern "C" int uc2_gemm_wgrad_group(int dtype, int n, const Uc2WgradItem* items,
   return 0;
 }
 
-// Calls that named a ping-pong kernel (variant 8 / 9 / 12) and were run by another one because the shape, an alignment or the
+// Calls that named a ping-pong kernel (variant 5 / 8 / 9 / 12) and were run by another one because the shape, an alignment or the
 // 32-bit staging-offset limit (an operand of 4 GiB or more) did not qualify.  Diagnostics only: nothing reads it to select a kernel.
 #include <atomic>
 static std::atomic<long long> g_pp_fallbacks{0};
@@ -473,8 +473,8 @@ static int gemm_impl(int dtype, int trans_a, int trans_b, int M, int N, int K,
                     "variant / 4 GiB operand limit / workspace); nothing was launched");
       return -1;
     }
-    // diagnostic counter (uc2_gemm_fallback_count): an explicit ping-pong plan (variants 8 / 9 / 12) that another kernel ran
-    if ((variant == 8 || variant == 9 || variant == 12 || variant == 13 || variant == 14) && fast != 2) g_pp_fallbacks.fetch_add(1, std::memory_order_relaxed);
+    // diagnostic counter (uc2_gemm_fallback_count): an explicit ping-pong plan (variants 5 / 8 / 9 / 12) that another kernel ran
+    if ((variant == 5 || variant == 8 || variant == 9 || variant == 12 || variant == 13 || variant == 14) && fast != 2) g_pp_fallbacks.fetch_add(1, std::memory_order_relaxed);
     if (fast) {
       UC2_LAUNCH_CHECK();
       if (want_colsum && fast != 2) return uc2_colsum_accum(1, M, N, C, ldc, nullptr, reinterpret_cast<float*>(aux_out), stream);

@@ -464,10 +464,10 @@ static int fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st)
   const bool want_p1 = variant == 13;                // experiments build only (uc2_gemm rejects 13 / 14 otherwise): one wave per SIMD, falls back to 12
   const bool want_p2 = variant == 14;                // ... with the epilogue in the next item's MFMA gaps: falls back to 12
   if (want_pp16 || want_p1 || want_p2) variant = 8;
-  if (variant == 8 || variant == 9) {
-    // ping-pong kernel: whole 256x256 (variant 9: 192x256) tiles, >= 2 k-tiles per split, and (bf16 output) an epilogue
-    // made of whole 16-byte accesses; anything else runs on the ring kernels above / the generic kernel
-    const int rows = variant == 9 ? 192 : 256;
+  if (variant == 8 || variant == 9 || variant == 5) {
+    // ping-pong kernel: whole 256x256 (variant 9: 192x256, variant 5: 128x256) tiles, >= 2 k-tiles per split, and (bf16 output) an
+    // epilogue made of whole 16-byte accesses; anything else runs on the ring kernels above / the generic kernel
+    const int rows = variant == 9 ? 192 : (variant == 5 ? 128 : 256);
     const int ktiles = p.K / 64, per = ((ktiles + p.split_k - 1) / p.split_k + 1) & ~1;   // k-tiles per split: even, >= 2
     if ((ktiles & 1) || ktiles - (p.split_k - 1) * per < 2) return 0;
     if ((p.M % rows) || (p.N & 255)) return 0;
@@ -487,6 +487,7 @@ static int fast_try(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st)
   // skew is off unless the call asks for it: back-to-back launches of the double-store GELU GEMM gained 16 % from
   // de-phasing, inside the training step no kernel moved
   if (variant == 9) { uc2_gemm_pp_launch(pd, trans_a, trans_b, st, 192); return 2; }
+  if (variant == 5) { uc2_gemm_pp_launch(pd, trans_a, trans_b, st, 128); return 2; }
   if (variant == 8) {
     const size_t need = (size_t)p.split_k * p.M * p.N * sizeof(float);
     if (p.c_f32 && p.split_k > 1 && p.ws && need <= p.ws_bytes && (p.N & 3) == 0 && (p.ldc & 3) == 0 &&

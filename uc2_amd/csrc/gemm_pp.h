@@ -7,7 +7,7 @@
 
 template <int J, int HI> __device__ __forceinline__ int pp_map(int ur) {     // unit row -> row/column of the tile
   if (J == 0) return (ur >> 6) * (64 + 32 * HI) + (ur & 63);                        // A0: 64 rows per wave row
-  else if (J == 3) return HI == 2 ? (ur >> 6) * 128 + 64 + (ur & 63) : (ur >> 5) * 96 + 64 + (ur & 31);   // A1: 32*HI rows per wave row
+  else if (J == 3) return HI == 2 ? (ur >> 6) * 128 + 64 + (ur & 63) : (HI == 1 ? (ur >> 5) * 96 + 64 + (ur & 31) : 0);   // A1: 32*HI rows per wave row (HI = 0: no such unit)
   else return (ur >> 5) * 64 + (J == 2 ? 32 : 0) + (ur & 31);
 }
 

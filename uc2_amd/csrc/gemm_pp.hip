@@ -26,6 +26,10 @@
 // HI = 1 variant: tiles of 192 rows (96 per wave row: A0 = 64 rows, A1 = 32).  The N = 768 GEMMs of the encoder have
 // 576 tiles of 256 rows on 256 CUs (2.25 rounds, the last a quarter full); with 192 rows they are 768 = three full
 // rounds.  Unit A1 is then 8 KiB (one LDS-DMA per wave, 7 per k-tile instead of 8) and phases 2, 3 run 4 MFMAs.
+// HI = 0 variant (round 6): tiles of 128 rows (64 per wave row: A0 only, no unit A1, 6 LDS-DMA per k-tile; phases 2 and 3 keep
+// their barriers and issue slots but run no MFMA).  At the reference's 104-pair micro-batch (9 984 tokens) the N = 768 GEMMs
+// are 117 tiles of 256 rows = 46 % of the 256 CUs, 156 of 192 rows, 234 of 128 rows = 91 %: half the matrix work per k-tile
+// for the same B traffic, on twice the CUs (priced in profiles/r05_experiments.md section 3a, measured in r06_experiments.md).
 //
 // The kernel is persistent: one workgroup per CU walks over (output tile, k-split) work items, and the LDS-DMA stream
 // does not drain between them: the last six phases of an item's main loop (which have no unit of their own item left to
@@ -45,7 +49,7 @@
 template <bool TA, bool TB, bool TACC, int EPI, int HI>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
   constexpr int RW = 64 + 32 * HI, RT = 2 * RW;           // rows per wave row / per tile (128 / 256, or 96 / 192)
-  constexpr int GA1 = HI == 2 ? 2 : 1;                      // LDS-DMA instructions per wave for unit A1
+  constexpr int GA1 = HI;                                   // LDS-DMA instructions per wave for unit A1 (2 / 1 / none)
   constexpr int GKT = 6 + GA1;                             // ... per k-tile
   constexpr int NST = (2 + HI) * 4;                        // bf16 stores per wave in the direct epilogue
   constexpr bool GRP = EPI == EPI_GROUP;                  // grouped launch: operands, shapes and the partial-tile destination are per item
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
 #define PP_SYNC_L(ALLOW, P)                                                                                    \
   do {                                                                                                         \
     const int al_ = (ALLOW) > 4 ? 4 : ((ALLOW) < 0 ? 0 : (ALLOW));                                             \
-    pp_wait_small(2 * al_ - ((GA1 == 1 && al_ > ((4 - (P)) & 3)) ? 1 : 0));                                    \
+    pp_wait_small(2 * al_ - ((al_ > ((4 - (P)) & 3)) ? 2 - GA1 : 0));                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                         \
     __builtin_amdgcn_s_barrier();                                                                              \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
@@ -348,9 +352,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp_kernel(GemmArgs p) {
     };
     // units 0 and 1 of this item: this wave's part has landed, then publish
     auto item_barrier = [&]() __attribute__((always_inline)) {
-      if (younger == GKT) { if (HI == 2) wait_vmcnt<8>(); else wait_vmcnt<7>(); }
-      else if (younger == GKT + NST) { if (HI == 2) wait_vmcnt<24>(); else wait_vmcnt<19>(); }
-      else if (younger == GKT + 2 * NST) { if (HI == 2) wait_vmcnt<40>(); else wait_vmcnt<31>(); }
+      // (the six units of a prologue are 10 + GA1 operations, the first two units 4: GKT = 6 + GA1 may stay in flight -- 8 / 7 / 6)
+      if (younger == GKT) wait_vmcnt<GKT>();
+      else if (younger == GKT + NST) wait_vmcnt<GKT + NST>();
+      else if (younger == GKT + 2 * NST) wait_vmcnt<GKT + 2 * NST>();
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
     };
@@ -485,7 +490,7 @@ static int pp_num_cus() {
 
 template <bool TA, bool TB, bool TACC, int EPI, int HI = 2>
 static void pp_launch0(const GemmArgs& p, hipStream_t st) {
-  static_assert(HI == 2 || TACC, "the 192-row variant exists for the bf16-output epilogue only");
+  static_assert(HI == 2 || TACC, "the 192- and 128-row variants exist for the bf16-output epilogue only");
   constexpr int smem = 131072 + 8 * 4096;            // the ring + one 4 KiB transposition buffer per wave = all 160 KiB
   auto kern = gemm_bf16_pp_kernel<TA, TB, TACC, EPI, HI>;
   static bool attr = false;
@@ -499,9 +504,9 @@ static void pp_launch0(const GemmArgs& p, hipStream_t st) {
 
 // The epilogue kind is a template parameter; only the combinations the encoder uses are instantiated:
 //   X*W^T (forward): none, GELU, +residual, tanh;  dY*W (input gradient): none, dGELU, +residual;  everything else: none.
-// tile_rows = 192 (the N = 768 shapes, see the header comment): forward none, input gradient none / +residual.
+// tile_rows = 192 / 128 (the N = 768 shapes, see the header comment): forward none, input gradient none / +residual.
 bool uc2_gemm_pp_supported(int trans_a, int trans_b, int c_f32, int epi, int tile_rows) {
-  if (tile_rows == 192) {
+  if (tile_rows == 192 || tile_rows == 128) {
     if (c_f32 || trans_a) return false;
     return trans_b ? (epi == EPI_NONE || epi == EPI_ADD) : (epi == EPI_NONE);
   }
@@ -515,6 +520,12 @@ bool uc2_gemm_pp_supported(int trans_a, int trans_b, int c_f32, int epi, int til
 void uc2_gemm_pp_group_launch(const GemmArgs& p, hipStream_t st) { pp_launch0<true, true, true, EPI_GROUP>(p, st); }
 
 void uc2_gemm_pp_launch(const GemmArgs& p, int trans_a, int trans_b, hipStream_t st, int tile_rows) {
+  if (tile_rows == 128) {
+    if (!trans_b) pp_launch0<false, false, true, EPI_NONE, 0>(p, st);
+    else if (p.epi == EPI_ADD) pp_launch0<false, true, true, EPI_ADD, 0>(p, st);
+    else pp_launch0<false, true, true, EPI_NONE, 0>(p, st);
+    return;
+  }
   if (tile_rows == 192) {
     if (!trans_b) pp_launch0<false, false, true, EPI_NONE, 1>(p, st);
     else if (p.epi == EPI_ADD) pp_launch0<false, true, true, EPI_ADD, 1>(p, st);

@@ -39,8 +39,8 @@ class GemmTimer:
         tacc = b(not atomic)
         if variant == 12:
             return "gemm_bf16_pp16_kernel<%s, %s, true, %d, 2>" % (b(ta), b(tb), epi)
-        if variant in (8, 9):
-            return "gemm_bf16_pp_kernel<%s, %s, %s, %d, %d>" % (b(ta), b(tb), b(not atomic), epi, 2 if variant == 8 else 1)
+        if variant in (5, 8, 9):
+            return "gemm_bf16_pp_kernel<%s, %s, %s, %d, %d>" % (b(ta), b(tb), b(not atomic), epi, {8: 2, 9: 1, 5: 0}[variant])
         if variant == 99:
             return "gemm_bf16_kernel<%s, %s, %s>" % (b(ta), b(tb), tacc)
         if variant in (6, 7):

@@ -87,7 +87,7 @@ def gemm(a, b, M, N, K, *, ta=False, tb=False, out=None, out_f32=False, bias=Non
         else:
             call("uc2_gemm_splitk_reduce", M, N, ptr(out), ldc, split_k, int(accumulate), ptr(ws), ws.numel(), stream())
     if e0 is not None:
-        if variant in (8, 9, 12):  # ping-pong kernels: transposed accumulators unless fp32 atomics; the epilogue kind is a template argument
+        if variant in (5, 8, 9, 12):  # ping-pong kernels: transposed accumulators unless fp32 atomics; the epilogue kind is a template argument
             epi_t = int(epi) + 4 if (flags & GEMM_AUX_DERIV and epi in (EPI_GELU, EPI_DGELU)) else int(epi)   # EPI_GELU_D = 5, EPI_MUL = 6
             key = (bool(ta), bool(tb), variant, bool(c_f32 and not two_stage), epi_t)
         else:
@@ -153,8 +153,8 @@ def _plan_fits(plan, key):
     """can the kernel of `plan` run the shape `key` (else the library would silently take its generic kernel)"""
     v, sp = plan
     ta, tb, M, N, K, wgrad = key
-    if v in (8, 9, 12, 13):
-        rows = 192 if v == 9 else 256
+    if v in (5, 8, 9, 12):
+        rows = 192 if v == 9 else (128 if v == 5 else 256)
         kt = K // 64
         per = ((kt + sp - 1) // sp + 1) & ~1
         # 32-bit staging offsets: an operand of 4 GiB or more does not run on the ping-pong kernels (gemm_fast.hip); contiguous
@@ -258,6 +258,8 @@ def gemm_plan(dtype, ta, tb, M, N, K, wgrad=False):
     cands = [(v, s) for v in (99, 1, 0, 6) for s in _WGRAD_SPLITS if s * 1024 <= K] if wgrad else list(_FWD_CANDIDATES)
     if (not wgrad) and M % 192 == 0 and N % 256 == 0 and not ta:
         cands.append((9, 1))                      # ping-pong kernel with 192-row tiles (tile-count quantisation at N = 768)
+    if (not wgrad) and M % 128 == 0 and N % 256 == 0 and not ta and (M // 256) * (N // 256) < 256:
+        cands.append((5, 1))                      # ... with 128-row tiles: fewer than one 256-row tile per CU (N = 768 at ~10 k tokens)
     if wgrad and M % 256 == 0 and N % 256 == 0:
         # persistent ping-pong kernel: one (tile, split) item per CU, or two
         # (a split must leave every slice an even number >= 2 of k-tiles -- _plan_fits -- so the candidates are the valid
@@ -291,6 +293,6 @@ def _gemm_planned(a, b, M, N, K, ta, tb, wgrad=False, **kw):
     """one GEMM with its tuned (variant, split_k) plan, passed to the library with the call"""
     v, sp = gemm_plan(a.dtype, ta, tb, M, N, K, wgrad)
     flags = kw.pop("flags", 0)
-    if knobs.pp_skew and v in (8, 9, 12):
+    if knobs.pp_skew and v in (5, 8, 9, 12):
         flags |= (knobs.pp_skew.get(kw.get("epi", EPI_NONE), 0) & 15) << 4
     return gemm(a, b, M, N, K, ta=ta, tb=tb, split_k=sp, variant=v, flags=flags, **kw)
