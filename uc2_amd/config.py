@@ -61,7 +61,9 @@ class Config:
         self.ln_reduce_batch = _flag(env, "UC2_LN_REDUCE_BATCH", True)   # ... or batched into one launch per backward pass (small token counts)
         # gradient accumulation overlapped inside the top-level models (ops/streams.py accum_pass): forward i+1 beside backward i
         self.accum_overlap = _flag(env, "UC2_ACCUM_OVERLAP", True)
-        self.accum_overlap_max_rows = int(env.get("UC2_ACCUM_OVERLAP_MAX_ROWS", "16384"))
+        # up to this many tokens per micro-batch (r06_experiments.md section 1: +3.9 % at 9 984 tokens, +7 % on the ragged 18 k-token
+        # windows of the retrieval finetune, +1.7 % at 20 k, +0.8 % at 40 k, -0.6 % at 80 k, -1.8 % at 160 k)
+        self.accum_overlap_max_rows = int(env.get("UC2_ACCUM_OVERLAP_MAX_ROWS", "49152"))
         # ---------------------------------------------------------------- fp8 mode
         self.fp8_delayed = _flag(env, "UC2_FP8_DELAYED", True)           # delayed (one-pass, producer-fused) activation scaling
         self.fp8_weight_batch = _flag(env, "UC2_FP8_WEIGHT_BATCH", True)  # all e4m3 weight copies of a store from one call per optimizer step
