@@ -391,3 +391,73 @@ def test_timeline_tool_attributes_overlap_and_gaps(tmp_path):
     # per window (ns -> ms columns print 0.000; check the ratios through the avg-us column and the calls column)
     assert float(lines["kernel_a"][1]) == 1.0 and float(lines["kernel_b"][1]) == 1.0 and float(lines["kernel_c"][1]) == 1.0
     assert "kernel_c -> marker_kernel" in out and "marker_kernel -> kernel_a" in out and "kernel_b -> kernel_c" in out
+
+
+# ------------------------------------------------------------------------------------------ round 6: host logic without a GPU
+def test_config_object_reads_the_environment_once():
+    """uc2_amd.config.Config: every UC2_* knob of the Python layer in one object (the ops modules read cfg.<knob> at call time,
+    tests assign it); defaults, parsing of the structured values, and no knob left in os.environ reads inside the ops package"""
+    from uc2_amd.config import Config, cfg
+    c = Config(env={})
+    assert (c.ln_fuse, c.wgrad_side_stream, c.accum_overlap, c.pad_rows, c.allreduce_tail, c.gemm_queue, c.gemm_queue_allowed) == \
+        (3, True, True, True, "fp32", False, True)
+    assert c.accum_overlap_max_rows == 49152 and c.wgrad_side_min_rows == 16384 and c.lib_path.endswith("libuc2_hip.so")
+    c = Config(env={"UC2_WGRAD_SIDE": "1:2", "UC2_PP_SKEW": "1:2,2:3", "UC2_GEMM_QUEUE": "0", "UC2_ALLREDUCE_TAIL": "bf16",
+                    "UC2_ACCUM_OVERLAP": "0", "UC2_PAD_ROWS": "0", "UC2_GEMM_EXTRA_FLAGS": "0x40000000", "UC2_LIB_PATH": "/x/y.so",
+                    "UC2_AUTOTUNE": "0", "UC2_CHECK_HINTS": "1"})
+    assert (c.wgrad_side_stream, c.wgrad_spare, c.pp_skew, c.gemm_queue_allowed, c.allreduce_tail) == (True, 2, {1: 2, 2: 3}, False, "bf16")
+    assert (c.accum_overlap, c.pad_rows, c.gemm_extra_flags, c.lib_path, c.autotune, c.check_hints) == (False, False, 0x40000000, "/x/y.so", False, True)
+    assert _lib.LIB_PATH == cfg.lib_path
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "uc2_amd", "ops", "*.py")) + [os.path.join(ROOT, "uc2_amd", "store.py")]:
+        assert "os.environ" not in open(f).read(), f
+
+
+def test_padded_rows_rule_and_row_padding_functions_on_the_host():
+    """ops.padded_rows: bf16 token counts from 1 024 rows are rounded up to whole 256-row GEMM tiles, fp32 (parity mode) never;
+    PadRowsFn / UnpadRowsFn (pure tensor movement: they run on CPU tensors too) are each other's inverse and their backward pads /
+    drops the same rows with zeros"""
+    from uc2_amd import ops
+    from uc2_amd.config import cfg as knobs
+    assert ops.padded_rows(9048, torch.bfloat16) == 9216 and ops.padded_rows(9984, torch.bfloat16) == 9984
+    assert ops.padded_rows(9048, torch.float32) == 9048 and ops.padded_rows(1000, torch.bfloat16) == 1000
+    was, knobs.pad_rows = knobs.pad_rows, False
+    try:
+        assert ops.padded_rows(9048, torch.bfloat16) == 9048
+    finally:
+        knobs.pad_rows = was
+    x = torch.randn(3, 5, 8, requires_grad=True)
+    xp = ops.PadRowsFn.apply(x, 20)
+    assert xp.shape == (20, 8) and torch.equal(xp[:15], x.detach().reshape(15, 8)) and float(xp[15:].detach().abs().sum()) == 0.0
+    y = ops.UnpadRowsFn.apply(xp * 2.0, 3, 5)
+    assert y.shape == (3, 5, 8) and torch.equal(y, x.detach() * 2.0)
+    g = torch.randn(3, 5, 8)
+    y.backward(g)
+    assert torch.equal(x.grad, 2.0 * g)
+
+
+def test_arena_parameter_grad_access_runs_the_pending_pass_hook():
+    """store.ArenaParameter: parameters re-homed into a ParamStore keep their class hierarchy and state_dict, and every Python-level
+    read or write of .grad first runs the hook ops/streams.py arms while an overlapped backward pass may still be in flight
+    (torch.nn.utils.clip_grad_norm_, a foreign optimizer, logging code need no change); library code uses raw_grad()"""
+    from uc2_amd import store
+    m = torch.nn.Linear(6, 4)
+    st = store.ParamStore(m)
+    assert all(type(p) is store.ArenaParameter and isinstance(p, torch.nn.Parameter) for p in m.parameters())
+    assert set(m.state_dict()) == {"weight", "bias"} and all(type(v) is torch.Tensor for v in m.state_dict().values())
+    calls = []
+    store._GRAD_ACCESS[0] = lambda: calls.append(1)
+    try:
+        assert m.weight.grad is None and len(calls) == 1
+        st.grad_buf(m.weight)                                   # library path: no hook
+        assert len(calls) == 1 and store.raw_grad(m.weight) is not None and len(calls) == 1
+        m.weight.grad.fill_(2.0)                                # a read
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)     # reads .grad of every parameter
+        m.bias.grad = None                                      # a write
+        assert len(calls) >= 5
+    finally:
+        store._GRAD_ACCESS[0] = None
+    n = len(calls)
+    assert m.weight.grad is not None and len(calls) == n        # nothing pending: the attribute costs one check
+    import copy
+    assert type(copy.deepcopy(m).weight) is store.ArenaParameter

@@ -1137,8 +1137,8 @@ def test_bf16_bench_path_trains_like_the_fp32_parity_mode():
         assert abs(a - c) <= 0.01 * abs(a) + 0.005, (s_, a, c)          # (measured: at most 0.3 % apart, step 3)
 
 
-@pytest.mark.parametrize("task", ["itm", "mlm"])
-def test_accumulation_overlap_equals_the_sequential_loop(task):
+@pytest.mark.parametrize("task,pairs", [("itm", 24), ("mlm", 24), ("itm", 176)])
+def test_accumulation_overlap_equals_the_sequential_loop(task, pairs):
     """ops.accum_pass (round 6): the reference's accumulation loop AS WRITTEN (pretrain.py:514-566: forward, backward, forward,
     backward, ...) with each training forward on one of the two overlap streams, so that forward i+1 runs beside backward i,
     against the same loop on one stream (knobs.accum_overlap off).  Same kernels, same accumulation order: identical losses, gradients
@@ -1146,7 +1146,13 @@ def test_accumulation_overlap_equals_the_sequential_loop(task):
     behind both streams; with dropout on, the three forwards draw distinct masks and equal the one-stream loop's."""
     from uc2_amd.store import store_of
     geom = dict(O.BASE, num_hidden_layers=2, vocab_size=2000)
-    batches = [to_dev(synth.make_batch(2000, 24, 40, 20, task=task, seed=90 + i, variable_len=(i == 1))) for i in range(3)]
+    if pairs == 24:
+        batches = [to_dev(synth.make_batch(2000, 24, 40, 20, task=task, seed=90 + i, variable_len=(i == 1))) for i in range(3)]
+    else:
+        # 176 x 96 = 16 896 tokens: above the side-stream / fused-tail / W^T thresholds and below the overlap's (49 152) -- the passes
+        # then also share the weight-gradient side stream (the retrieval finetune's 18 k-token windows run this combination)
+        batches = [to_dev(synth.make_batch(2000, pairs, 60, 36, task=task, seed=90 + i)) for i in range(3)]
+        assert knobs.wgrad_side_min_rows <= pairs * 96 < knobs.accum_overlap_max_rows
 
     def loop(model, bs):
         losses = []

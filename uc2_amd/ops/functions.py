@@ -292,7 +292,9 @@ def padded_rows(M, dtype):
     1 024 tokens, UC2_PAD_ROWS=0 off), else M.  The reference's token-bucket batches have a new B x L every step
     (data/sampler.py:11-59); a ragged M used to push every GEMM of the step off the ping-pong kernels' plans (bench.py
     itm_rank_finetune: 612 re-routed calls per 8 steps) and to tune a new shape per step."""
-    if dtype != torch.bfloat16 or not knobs.pad_rows or M < 1024 or M % 256 == 0 or torch.cuda.is_current_stream_capturing():
+    if dtype != torch.bfloat16 or not knobs.pad_rows or M < 1024 or M % 256 == 0:
+        return M
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
         return M
     return (M + 255) // 256 * 256
 
