@@ -46,6 +46,9 @@ class Config:
         # bf16 encoder passes over a ragged token count B L run on B L rounded up to whole 256-row GEMM tiles (zero rows appended
         # once in VLXLMREncoder.forward: ops.PadRowsFn), so that every GEMM stays on its planned ping-pong kernel
         self.pad_rows = _flag(env, "UC2_PAD_ROWS", True)
+        # MLM head: dz = dlogits E reads a k-contiguous copy E^T of the tied decoder table (store.table_t, 384 MB) instead of E
+        # through the transposing LDS read
+        self.decoder_wt = _flag(env, "UC2_DECODER_WT", True)
         # ---------------------------------------------------------------- streams
         # weight-gradient GEMMs on a second HIP stream (round 3, 1024-pair step on one box: 63.1-63.3 ms against 63.8-64.4);
         # UC2_WGRAD_SIDE = "0" | "1" | "1:<n>" (n: they leave 8 n CUs free -- measured slower, 65.5 ms at 16-24 CUs)

@@ -686,7 +686,13 @@ class DecoderCEFn(torch.autograd.Function):
                     # m x H is only (m/256) x 3 tiles (96 at 8192 rows) under a contraction of 250 112: split it over the
                     # vocabulary like a weight gradient (fp32 partial tiles + one reduction pass), then round once
                     dz32 = torch.zeros((m, H), dtype=torch.float32, device=z.device)
-                    _gemm_planned(dlog, Wp, m, H, Vp, False, True, wgrad=True, out=dz32, accumulate=True, lda=Vp)
+                    Et = st.table_t(weight) if (knobs.decoder_wt and in_arena) else None
+                    if Et is not None:
+                        # k-contiguous E^T [H, Vp]: the layout of a forward GEMM (both operands read with plain ds_read_b128; round 6:
+                        # 3 032 -> see profiles/r06_experiments.md us per 7 680-row chunk against the transposing read of E)
+                        _gemm_planned(dlog, Et, m, H, Vp, False, False, wgrad=True, out=dz32, accumulate=True, lda=Vp)
+                    else:
+                        _gemm_planned(dlog, Wp, m, H, Vp, False, True, wgrad=True, out=dz32, accumulate=True, lda=Vp)
                     call("uc2_cast", dt(torch.float32), dt(dtype), m * H, ptr(dz32), ptr(dz[r0:r1]), stream())
                 else:
                     _gemm_planned(dlog, Wp, m, H, Vp, False, True, out=dz[r0:r1], lda=Vp)

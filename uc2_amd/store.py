@@ -314,6 +314,33 @@ class ParamStore:
         wt = self._ilv_wt[slot * H3 * cols:(slot + 1) * H3 * cols].view(cols, H3) if (want_t and H3 % 64 == 0 and cols % 64 == 0) else None
         return w, wt, self._ilv_b[slot * H3:(slot + 1) * H3]
 
+    def table_t(self, p):
+        """bf16 [cols, rows_padded] transpose of a padded vocabulary table (the word embeddings = the tied MLM decoder weight
+        [250 112, H]): the k-contiguous operand of the decoder's input-gradient GEMM dz = dlogits E (contraction over the
+        vocabulary), which otherwise reads E through the transposing LDS read.  Its own buffer (384 MB for uc2-base -- the encoder's
+        W^T arena deliberately leaves the vocabulary tables out), allocated at first use, refreshed by one transpose launch when the
+        weights changed; None when the slot is not made of whole 64 x 64 tiles."""
+        import ctypes
+        self.sync_shadow()
+        o = self.offsets[id(p)]
+        n = _slot_numel(p)
+        cols = p.numel() // p.shape[0]
+        rows = n // cols
+        if rows % 64 or cols % 64:
+            return None
+        tabs = self.__dict__.setdefault("_tab_t", {})
+        ent = tabs.get(o)
+        if ent is None:
+            ent = tabs[o] = [torch.empty(rows * cols, dtype=torch.bfloat16, device=self.device), -1]
+        if ent[1] != self.version:
+            class _Item(ctypes.Structure):
+                _fields_ = [("offset", ctypes.c_size_t), ("rows", ctypes.c_int), ("cols", ctypes.c_int)]
+            arr = (_Item * 1)(_Item(o, rows, cols))
+            # (the kernel addresses source and destination with the same element offset: the destination base is shifted by it)
+            _lib.call("uc2_transpose_batch", 1, arr, _lib.ptr(self.shadow), _lib.ptr(ent[0]) - 2 * o, _lib.stream())
+            ent[1] = self.version
+        return ent[0].view(cols, rows)
+
     def prepare_t(self):
         """allocate the W^T arena: the slice of the parameter arena from the first to the last 2-D parameter of the encoder
         layers (names containing 'encoder.layer.' / 'layer.<i>.'; a bare BertLayer: all its 2-D parameters)"""
