@@ -688,8 +688,9 @@ class DecoderCEFn(torch.autograd.Function):
                     dz32 = torch.zeros((m, H), dtype=torch.float32, device=z.device)
                     Et = st.table_t(weight) if (knobs.decoder_wt and in_arena) else None
                     if Et is not None:
-                        # k-contiguous E^T [H, Vp]: the layout of a forward GEMM (both operands read with plain ds_read_b128; round 6:
-                        # 3 032 -> see profiles/r06_experiments.md us per 7 680-row chunk against the transposing read of E)
+                        # k-contiguous E^T [H, Vp]: the layout of a forward GEMM (both operands read with plain ds_read_b128; the NT form
+                        # ran 3 032 us per 7 680-row chunk = 0.97 PF/s).  Same box, alternating: 385.5 / 385.9 -> 382.9 / 383.1 ms per
+                        # 6144-pair MLM step (profiles/r06_experiments.md section 6)
                         _gemm_planned(dlog, Et, m, H, Vp, False, False, wgrad=True, out=dz32, accumulate=True, lda=Vp)
                     else:
                         _gemm_planned(dlog, Wp, m, H, Vp, False, True, wgrad=True, out=dz32, accumulate=True, lda=Vp)
