@@ -16,12 +16,16 @@ Prints ONE JSON line on rank 0 (metric contract in the task description) with ex
   roofline      -- the dominant kernel (a bf16 MFMA GEMM instantiation) timed live with HIP events on its launch
                    stream over the timed steps, against the dense bf16 MFMA peak; `traffic` is carried from the
                    committed rocprofv3 PMC passes (profiles/), `hbm_kernels` are the HBM-bound kernels' GB/s
-  workloads     -- the same step on the MLM task and at the 1024 / 2048 pairs per step of earlier rounds; the reference's own regime:
-                   104-pair micro-batches x 3 accumulation micro-steps per optimizer step (config/uc2_pretrain.json:17-19), ITM
-                   and MLM windows, the pretrain task mix itm:mlm:vmlm:tlm = 9:12:9:3 of BASELINE.json configs[2]
-                   (config/uc2_pretrain.json:72-102) and one window each of the MRM heads (mrfr, mrc-kl); at N = 1 also the
-                   other BASELINE.json configs on one GPU: retrieval inference (forward-only), the hard-negative finetune step
-                   (configs[3]) and the uc2-large geometry in bf16 and with fp8 GEMMs (configs[4])
+  workloads     -- the same step on the MLM task, at the 1024 / 2048 pairs per step of earlier rounds and on variable-length pairs
+                   (text 10-60, 10-36 regions: the reference's padding / key-mask / gather contract); the reference's own regime:
+                   104-pair micro-batches x 3 accumulation micro-steps per optimizer step (config/uc2_pretrain.json:17-19), the loop
+                   as the reference writes it -- ITM and MLM windows (each also with the accumulation overlap off: in-run A/B), ragged
+                   micro-batches with the row padding on / off, the pretrain task mix itm:mlm:vmlm:tlm = 9:12:9:3 of BASELINE.json
+                   configs[2] (config/uc2_pretrain.json:72-102) and one window each of the MRM heads (mrfr, mrc-kl); at N = 1 also the
+                   other BASELINE.json configs on one GPU: retrieval inference (forward-only), the in-model hard-negative step, the
+                   itm.py finetune window of configs[3] (40 triplets -> 120 sequences x 8 accumulation steps, num_bb in [10, 100],
+                   config/uc2_mscoco_itm.json:10-31) and the uc2-large geometry at 1024 pairs per step in bf16 and with fp8 GEMMs
+                   (configs[4])
   cpu_baseline  -- the CPU oracle (oracle/uc2_oracle.py, kind "port") timed on the host cores per BASELINE.md
                    section 3: B = 32, median of 3 after one warm-up, ITM and MLM (rank 0, N = 1 only)
 """
