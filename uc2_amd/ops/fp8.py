@@ -166,11 +166,10 @@ def gemm_fp8_q(a8, sa, b8, sb, q_key, bias=None, epi=EPI_NONE, aux_in=None, aux_
 class _Fp8WeightItem(ctypes.Structure):          # Uc2Fp8WeightItem
     _fields_ = [("w", ctypes.c_void_p), ("rows", ctypes.c_int), ("cols", ctypes.c_int), ("out", ctypes.c_void_p), ("out_t", ctypes.c_void_p),
                 ("amax", ctypes.c_void_p), ("scale", ctypes.c_void_p)]
-# attention kernels write the e4m3 copies of ctx / dqkv themselves (uc2_attn_fwd_q / uc2_attn_bwd_q): OFF -- measured break-even on
-# uc2-large (63.5-63.8 ms per step without, 63.9-64.4 with: the copies leave as 16-byte pieces of 32 different rows per wave
-# instruction, +59 us forward / +31 us backward per launch against a 53 us stand-alone pass; profiles/r05_experiments.md section 2)
 
 
+# (knobs.fp8_attn_fused -- the attention kernels write the e4m3 copies of ctx / dqkv themselves, uc2_attn_fwd_q / uc2_attn_bwd_q -- is
+#  OFF: measured break-even on uc2-large, config.py)
 def _fp8_weight(st, p_first, p_last, shape, transpose):
     """e4m3 copy (+ scale) of a weight span, re-quantised when the parameters change (AdamW step, load_state_dict).
     Every span a forward / backward has asked for is remembered; when the store's version moves, ALL of them are quantised again,

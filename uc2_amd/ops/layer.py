@@ -51,9 +51,7 @@ def _ilv_wgrad_plan(n_out, n_in, rows, device):
 # One C call per layer and direction (include/uc2_hip.h: uc2_bert_layer_fwd / _bwd) for the plain route -- no fp8, no head-interleaved
 # q|k|v, no fused dropout-residual tails, no k-contiguous W^T copies, i.e. the reference's micro-batch sizes: the same kernels with
 # the same arguments in the same order as the per-kernel calls of BertLayerFn below, so the same bits; what it saves is host time
-# (~20 ctypes calls, their argument marshalling and the timing hooks per layer).
-
-
+# (~20 ctypes calls, their argument marshalling and the timing hooks per layer).  knobs.native_layer; _native_layer_ok says when.
 class _GemmPlanC(ctypes.Structure):
     _fields_ = [("variant", ctypes.c_int), ("split_k", ctypes.c_int), ("flags", ctypes.c_int)]
 

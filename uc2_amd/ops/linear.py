@@ -19,9 +19,10 @@ def linear_fwd(x2, w, bias, epi=EPI_NONE, aux_out=None, flags=0):
 
 
 EPI_DROPADD = 10                 # internal to the ping-pong kernel (uc2_gemm_drop_residual)
-# dropout + residual of the dense -> dropout -> LayerNorm tails in the GEMM epilogue: bit 0 = the attention-output tail, bit 1 = the FFN tail
 
 
+# knobs.ln_fuse: dropout + residual of the dense -> dropout -> LayerNorm tails in the GEMM epilogue (bit 0 = the attention-output
+# tail, bit 1 = the FFN tail), from knobs.ln_fuse_min_rows tokens
 def linear_drop_residual(x2, w, bias, res2, drop_p, seed, seed_imm):
     """s = dropout(x2 w^T + bias) + res2 (model/layer.py:111-115, :152-156 up to the LayerNorm) from one GEMM launch, with the mask
     ln_fwd / ln_bwd derive from (seed, seed_imm); None (nothing launched) when the ping-pong kernel does not take the shape"""
@@ -113,8 +114,7 @@ def linear_wgrad(dy2, x2, dw, db):
 # Below WGRAD_SIDE_MIN_ROWS tokens a layer's four weight gradients are too small to fill the chip one by one (9-36 output tiles
 # each at ~10 k tokens = a single round on half of the 256 CUs): BertLayerFn.backward hands them to ONE launch of the persistent
 # ping-pong kernel (uc2_gemm_wgrad_group) at the end of the layer's backward.  104-pair micro-batch: 215 -> 136 us per layer.
-
-
+# (knobs.wgrad_group; knobs.wgrad_group_side puts that launch on the side stream)
 class _WgradItem(ctypes.Structure):             # include/uc2_hip.h: Uc2WgradItem
     _fields_ = [("dy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("lddy", ctypes.c_int),
                 ("ldx", ctypes.c_int), ("lddw", ctypes.c_int), ("n_out", ctypes.c_int), ("n_in", ctypes.c_int),
