@@ -146,18 +146,24 @@ class _AccumMarker(torch.autograd.Function):
     orders that stream behind the other one, i.e. behind the previous micro-batch's backward"""
 
     @staticmethod
-    def forward(ctx, x, state, idx):
-        ctx.state, ctx.idx = state, idx
+    def forward(ctx, x, state, idx, main):
+        ctx.state, ctx.idx, ctx.main = state, idx, main
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
         st, i = ctx.state, ctx.idx
+        S = st.streams[i]
+        # behind everything the caller's stream holds NOW: `loss = model(b); optimizer.zero_grad(); loss.backward()` zeroes the arena
+        # on the caller's stream between this pass's forward and its backward, a gradient consumer may have joined (and reset `used`)
+        # in between, the root gradient may come from the caller -- all of it is ordered before the first += of this pass.  (The
+        # caller's stream never holds a backward pass: waiting for it costs the overlap nothing.)
+        S.wait_stream(ctx.main)
         if st.used[1 - i]:
-            st.streams[i].wait_stream(st.streams[1 - i])
+            S.wait_stream(st.streams[1 - i])
         st.unjoined = True                  # from here on .grad views are being written on this stream: store.ArenaParameter.grad
         _store._GRAD_ACCESS[0] = _on_grad_access
-        return g, None, None
+        return g, None, None, None
 
 
 class accum_pass:
@@ -202,7 +208,7 @@ class accum_pass:
             if not torch.is_tensor(t):
                 return t
             if t.requires_grad:
-                t = _AccumMarker.apply(t, st, self.idx)
+                t = _AccumMarker.apply(t, st, self.idx, self.main)
             if t.is_cuda:
                 t.record_stream(self.main)
             return t
