@@ -1200,42 +1200,44 @@ def test_accumulation_overlap_equals_the_sequential_loop(task, pairs):
 
 
 def test_accumulation_overlap_with_zero_grad_between_forward_and_backward():
-    """the common loop `loss = model(b); optimizer.zero_grad(); loss.backward(); clip; optimizer.step()` with the overlap on: the arena is
-    zeroed on the CALLER's stream after the pass's forward was enqueued on an overlap stream -- the pass's backward must be ordered
-    behind it (ops._AccumMarker waits for the caller's stream).  Six optimizer steps, losses and final weights against the same loop
-    with the overlap off."""
+    """the common loop `loss = model(b); optimizer.zero_grad(); loss.backward()` with the overlap on: the arena is zeroed on the
+    CALLER's stream after the pass's forward was enqueued on an overlap stream -- the pass's backward must be ordered behind that
+    (ops._AccumMarker waits for the caller's stream).  The arena holds another batch's gradients before; afterwards it must hold
+    exactly this batch's (not the sum, not a partly zeroed mix): compared with the same sequence with the overlap off, three rounds."""
     from uc2_amd.store import store_of
     geom = dict(O.BASE, num_hidden_layers=2, vocab_size=2000)
-    batches = [to_dev(synth.make_batch(2000, 24, 40, 20, task="itm", seed=60 + i)) for i in range(3)]
+    b0 = to_dev(synth.make_batch(2000, 24, 40, 20, task="itm", seed=60))
+    b1 = to_dev(synth.make_batch(2000, 24, 40, 20, task="itm", seed=61))
+    model = build_pretrain(geom, torch.bfloat16)
+    st = store_of(model)
+    st.sync_shadow()
+    st.auto_sync = False
+
+    def fwd(b):
+        l = model(b, "itm", compute_loss=True)
+        return (l[0] if isinstance(l, tuple) else l).mean()
     was = knobs.accum_overlap
     res = {}
     try:
-        for overlap in (False, True):
+        for overlap in (False, True, True, True):
             knobs.accum_overlap = overlap
-            model = build_pretrain(geom, torch.bfloat16)
-            st = store_of(model)
-            st.sync_shadow()
-            st.auto_sync = False
-            opt = AdamW(param_groups(model, 0.01), lr=1e-3, betas=(0.9, 0.98))
+            model.zero_grad()
+            fwd(b0).backward()                                # the arena now holds b0's gradients (on an overlap stream when on)
             before = sum(s_.passes for s_ in ops._accum.values())
-            losses = []
-            for step in range(6):
-                l = model(batches[step % 3], "itm", compute_loss=True)
-                l = (l[0] if isinstance(l, tuple) else l).mean()
-                opt.zero_grad()                                   # AFTER the forward, on the caller's stream
-                l.backward()
-                clip_grad_norm_([p for p in model.parameters() if p.grad is not None], 5.0)
-                opt.step()
-                losses.append(float(l.detach()))
+            l = fwd(b1)
+            model.zero_grad()                                 # AFTER the forward, on the caller's stream
+            l.backward()
+            assert (sum(s_.passes for s_ in ops._accum.values()) - before) == (1 if overlap else 0)
+            g = OrderedDict((n, p.grad.detach().clone()) for n, p in model.named_parameters() if p.grad is not None)    # (.grad: waits for the pass)
             torch.cuda.synchronize()
-            assert (sum(s_.passes for s_ in ops._accum.values()) - before) == (6 if overlap else 0)
-            res[overlap] = (losses, st.data.detach().double().sum().item(), st.data.detach().clone())
-            del model, opt
+            if not overlap:
+                res = g
+                continue
+            assert set(g) == set(res)
+            for n in res:
+                assert rel_err(g[n], res[n]) < 2e-5 or res[n].norm() < 1e-7, n
     finally:
         knobs.accum_overlap = was
-    (l0, c0, w0), (l1, c1, w1) = res[False], res[True]
-    assert all(abs(a - b) <= 1e-4 * abs(a) + 1e-6 for a, b in zip(l0, l1)), (l0, l1)
-    assert rel_err(w1, w0) < 1e-5, rel_err(w1, w0)
 
 
 def test_accumulation_overlap_stays_off_where_it_must():
