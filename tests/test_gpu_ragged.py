@@ -153,3 +153,36 @@ def test_ragged_weight_gradient_runs_as_planned_bulk_plus_generic_tail(M):
     want = dw0 + dy.float().t() @ x.float()
     assert rel_err(dw, want) < 2e-5, rel_err(dw, want)
     assert rel_err(db, dy.float().sum(0)) < 1e-5
+
+
+def test_padded_rows_with_fp8_gemms():
+    """fp8 mode on a ragged token count (10 pairs x 130 positions = 1 300 tokens -> 1 536 rows): with the rows padded every e4m3 GEMM of
+    the layers takes the ping-pong kernel (uc2_gemm_fp8_route_count: ring = 0; unpadded, 1 300 rows are not whole tiles and all of them
+    run on the ring kernel), losses stay at fp8 distance from the bf16 run of the same model, gradients are finite."""
+    import uc2_amd
+    lib = uc2_amd._lib.load()
+    geom = dict(O.LARGE, num_hidden_layers=2, vocab_size=2000)
+    batch = _dev(synth.make_batch(2000, 10, 80, 50, task="itm", seed=8))
+    assert batch["attn_masks"].numel() == 1300
+    model = VLXLMRForPretraining(_cfg(geom, 0.0), img_dim=2048, img_label_dim=1601)
+    synth.det_init_(model)
+    model.to(DEV).train()
+    set_compute_dtype(model, torch.bfloat16)
+    out = {}
+    for mode in ("bf16", "fp8"):
+        uc2_amd.set_fp8(model, mode == "fp8")
+        model.zero_grad()
+        lib.uc2_gemm_fp8_route_count(0, 1), lib.uc2_gemm_fp8_route_count(1, 1)
+        for _ in range(2):                                       # second pass: delayed scaling
+            model.zero_grad()
+            loss = model(batch, "itm", compute_loss=True)
+            loss = loss[0] if isinstance(loss, tuple) else loss
+            loss.mean().backward()
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        ring, pp = int(lib.uc2_gemm_fp8_route_count(0, 0)), int(lib.uc2_gemm_fp8_route_count(1, 0))
+        assert (ring, pp > 0) == ((0, True) if mode == "fp8" else (0, False)), (mode, ring, pp)
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+        out[mode] = loss.detach().float().clone()
+    uc2_amd.set_fp8(model, False)
+    assert rel_err(out["fp8"], out["bf16"]) < 3e-2, rel_err(out["fp8"], out["bf16"])
