@@ -12,6 +12,10 @@ import numpy as np
 import torch
 
 _tensor_grad = torch.Tensor.grad
+
+
+def _raw_grad(p):
+    return _tensor_grad.__get__(p, type(p))
 from torch.optim import Optimizer
 
 from .. import _lib
@@ -159,8 +163,8 @@ class AdamW(Optimizer):
         active = [0] * plan["n_params"]
         any_active = False
         for (p, gi, pi, m, v, st) in plan["recs"]:
-            if p.grad is None:                            # parameters without a gradient are skipped (adamw.py:52-53)
-                continue
+            if _raw_grad(p) is None:                      # parameters without a gradient are skipped (adamw.py:52-53); (raw: the
+                continue                                  #  streams were joined above, the .grad hook has nothing left to do)
             active[pi] = 1
             any_active = True
             self.state[p]['step'] += 1
@@ -227,19 +231,21 @@ def clip_grad_norm_(parameters, max_norm, fused=False):
     gradients (one reduction per contiguous arena span) and scaling by min(1, max_norm/(norm+1e-6)).
     fused=False scales the gradients in place and returns the norm (0-d device tensor);
     fused=True leaves them untouched and returns (norm, coef) for AdamW.step(grad_scale=coef)."""
-    params = [p for p in parameters if p.grad is not None]
+    from .. import ops
+    parameters = list(parameters)
+    if parameters and parameters[0].is_cuda:
+        ops.join_side_streams()                               # (before the gradients are looked at: overlapped passes, side streams)
+    params = [p for p in parameters if _raw_grad(p) is not None]
     if not params:
         return torch.tensor(0.0)
-    from .. import ops
-    ops.join_side_streams()
-    dev = params[0].grad.device
+    dev = _raw_grad(params[0]).device
     arenas = []
     for p in params:
         st = getattr(p, "_uc2_store", None)
         if st is not None and st.grad is not None and all(a is not st for a in arenas):
             arenas.append(st)
     spans = []
-    for g in sorted((p.grad for p in params), key=lambda t: t.data_ptr()):
+    for g in sorted((_raw_grad(p) for p in params), key=lambda t: t.data_ptr()):
         if g.dtype != torch.float32 or not g.is_contiguous():
             raise _lib.Uc2Error("clip_grad_norm_ expects contiguous fp32 gradients")
         b, e = g.data_ptr(), g.data_ptr() + 4 * g.numel()
