@@ -19,7 +19,8 @@ st = store_of(model)
 opt = AdamW(param_groups(model, 0.01), lr=4e-5, betas=(0.9, 0.98))
 st.sync_shadow(); st.auto_sync = False
 PAIRS = int(os.environ.get("PAIRS", str(bench.REF_MICRO)))            # micro-batch size (default: the reference's 104)
-rb = [bench.synth_batch(PAIRS, task, 9000 + i, dev) for i in range(bench.REF_ACCUM)]
+ACCUM = int(os.environ.get("ACCUM", str(bench.REF_ACCUM)))          # micro-batches per optimizer step (default: the reference's 3)
+rb = [bench.synth_batch(PAIRS, task, 9000 + i, dev) for i in range(ACCUM)]
 def step():
     for b in rb:
         loss = model(b, task, compute_loss=True)
@@ -36,7 +37,7 @@ th = (time.perf_counter() - t0) / nsteps          # host enqueue time (the loop 
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / nsteps
 print("host enqueue %.2f ms per optimizer step" % (th * 1e3))
-n = PAIRS * bench.REF_ACCUM
+n = PAIRS * ACCUM
 from uc2_amd.config import cfg as knobs
 print("%s regime, %d-pair micro-batches x %d, overlap %s (max rows %d): %.2f ms per optimizer step, %.0f pairs/s, mfma %.4f, overlap passes %d"
-      % (task, PAIRS, bench.REF_ACCUM, knobs.accum_overlap, knobs.accum_overlap_max_rows, dt * 1e3, n / dt, n / dt * 49.94e9 / 2.5e15, sum(s.passes for s in ops._accum.values())))
+      % (task, PAIRS, ACCUM, knobs.accum_overlap, knobs.accum_overlap_max_rows, dt * 1e3, n / dt, n / dt * 49.94e9 / 2.5e15, sum(s.passes for s in ops._accum.values())))

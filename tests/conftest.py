@@ -29,3 +29,13 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _fresh_accumulation_window():
+    """the accumulation overlap (ops/streams.py) skips the first forward of a window when the PREVIOUS window had a single forward:
+    process-wide history, reset so that no test depends on what ran before it"""
+    m = sys.modules.get("uc2_amd.ops.streams")
+    if m is not None:
+        m.forget_accum_history()
+    yield

@@ -1291,6 +1291,44 @@ def test_accumulation_overlap_stays_off_where_it_must():
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
 
+def test_accumulation_overlap_adapts_to_loops_without_accumulation():
+    """one forward per optimizer step (retrieval loops, plain fine-tuning): nothing to run beside, the stream hops only cost
+    (profiles/r06_experiments.md section 1) -- after ONE such window the passes stay on the caller's stream; the second forward of a
+    later window switches the overlap back on, and from the window after that every pass is overlapped again.  Gradients are the
+    same either way (compared with the overlap off)."""
+    from uc2_amd.store import store_of
+    geom = dict(O.BASE, num_hidden_layers=2, vocab_size=2000)
+    model = build_pretrain(geom, torch.bfloat16)
+    st = store_of(model)
+    st.sync_shadow()
+    st.auto_sync = False
+    bs = [to_dev(synth.make_batch(2000, 16, 40, 20, task="itm", seed=70 + i)) for i in range(3)]
+
+    def passes():
+        return sum(s_.passes for s_ in ops._accum.values())
+
+    def window(n):
+        model.zero_grad()
+        before = passes()
+        for b in bs[:n]:
+            l = model(b, "itm", compute_loss=True)
+            (l[0] if isinstance(l, tuple) else l).mean().backward()
+        norm = clip_grad_norm_([p for p in model.parameters() if p.grad is not None], 1e9)       # the consumer that ends the window
+        return passes() - before, float(norm)
+    was = knobs.accum_overlap
+    try:
+        knobs.accum_overlap = False
+        want = {n: window(n)[1] for n in (1, 3)}
+        knobs.accum_overlap = True
+        ops.forget_accum_history()
+        got = [window(n) for n in (1, 1, 1, 3, 3, 1, 1)]
+        assert [g[0] for g in got] == [1, 0, 0, 2, 3, 1, 0], got
+        for n, (_, norm) in zip((1, 1, 1, 3, 3, 1, 1), got):
+            assert abs(norm - want[n]) <= 2e-5 * want[n], (n, norm, want[n])
+    finally:
+        knobs.accum_overlap = was
+
+
 def test_adamw_bf16_shadow_and_fused_clip():
     model = build_pretrain(O.TINY, torch.bfloat16)
     opt = AdamW(param_groups(model, 0.01), lr=1e-3, betas=(0.9, 0.98))

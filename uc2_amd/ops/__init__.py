@@ -22,7 +22,7 @@ from .base import (  # noqa: F401
 )
 from .streams import (  # noqa: F401
     _AccumMarker, _AccumState, _accum, _accum_state, _end_of_backward_join, _join_queued, _on_side_stream,
-    _queue_pass_callback, _side_dirty, _side_keep, _side_route, _side_stream, _side_streams, accum_pass, join_accum_streams,
+    _queue_pass_callback, _side_dirty, _side_keep, _side_route, _side_stream, _side_streams, accum_pass, forget_accum_history, join_accum_streams,
     join_side_streams, pending_side_stream,
 )
 from .gemm import (  # noqa: F401

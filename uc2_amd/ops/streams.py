@@ -83,7 +83,8 @@ def pending_side_stream(device):
 # the float atomics (what two runs on one stream differ by).
 # Off for: eval / no-grad forwards, fp8 stores (delayed-scaling histories assume one in-order stream), stores whose bf16 copies
 # are re-cast at every forward (store.auto_sync: the re-cast would race with the backward beside it; AdamW.step turns auto_sync
-# off), stream capture, UC2_ACCUM_OVERLAP=0.  Measured: profiles/r06_experiments.md.
+# off), stream capture, UC2_ACCUM_OVERLAP=0, and for the first forward of a window when the previous window had only one (no
+# accumulation: nothing to run beside).  Measured: profiles/r06_experiments.md.
 _accum = {}
 
 
@@ -96,6 +97,7 @@ class _AccumState:
         self.raw = tuple(s_.cuda_stream for s_ in self.streams)
         self.unjoined = False              # a backward pass was enqueued here that the caller's stream has not been ordered behind yet
         self.passes = 0                    # (statistics: passes that ran on the overlap streams)
+        self.last_window = 0               # eligible forwards of the previous window (between two gradient consumers); 0 = not known yet
 
 
 def _accum_state(device):
@@ -104,6 +106,13 @@ def _accum_state(device):
     if st is None:
         st = _accum[key] = _AccumState(device)
     return st
+
+
+def forget_accum_history():
+    """the next window's first forward is overlapped again whatever the previous window looked like (tests; a caller that switches
+    from single-batch steps to accumulation and does not want to give away one window)"""
+    for st in _accum.values():
+        st.last_window = 0
 
 
 def join_accum_streams():
@@ -115,6 +124,8 @@ def join_accum_streams():
                 if st.used[i]:
                     cur.wait_stream(st.streams[i])
             st.used = [False, False]
+        if st.k:
+            st.last_window = st.k          # (a window = the eligible forwards between two joins that saw any)
         st.k = 0
         st.unjoined = False
     _store._GRAD_ACCESS[0] = None
@@ -176,7 +187,14 @@ class accum_pass:
         if not (knobs.accum_overlap and t0 is not None and torch.is_grad_enabled() and 0 < rows < knobs.accum_overlap_max_rows and not fp8
                 and not (bf16 and store.auto_sync) and not torch.cuda.is_current_stream_capturing()):
             return
-        self.state = _accum_state(t0.device)
+        st = _accum_state(t0.device)
+        if st.last_window == 1 and st.k == 0:
+            # No accumulation in the previous window (one forward per optimizer step: the retrieval loops, plain fine-tuning): the
+            # stream hops then buy nothing and cost 1.4 % at 104 pairs, 3 % at 32 (profiles/r06_experiments.md section 1).  The pass
+            # runs on the caller's stream but is counted, so a second forward in this window switches the overlap back on.
+            st.k = 1
+            return
+        self.state = st
         self.store = store
         self.tensors = [t for t in tensors if torch.is_tensor(t) and t.is_cuda]
 
