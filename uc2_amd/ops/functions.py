@@ -132,7 +132,7 @@ class FusedQKVFn(torch.autograd.Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         wqkv = st.compute_span(qw, vw, (3 * qw.shape[0], H), dtype)
-        bqkv = st.span(st.data, qb, vb, (3 * qw.shape[0],))
+        bqkv = st.span_view(st.data, qb, vb, (3 * qw.shape[0],))
         qkv = linear_fwd(x2, wqkv, bqkv)
         ctx.save_for_backward(x2)
         ctx.owner, ctx.ps, ctx.shp = owner, (qw, qb, kw, kb, vw, vb), x.shape

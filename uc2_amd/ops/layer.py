@@ -124,7 +124,7 @@ class BertLayerFn(torch.autograd.Function):
         s_attn, s_ln1, s_ln2 = rng.site(sid + 1), rng.site(sid + 2), rng.site(sid + 3)      # dropout sites of this layer
 
         wqkv = st.compute_span(P["qw"], P["vw"], (3 * H, H), dtype)
-        bqkv = st.span(st.data, P["qb"], P["vb"], (3 * H,))
+        bqkv = st.span_view(st.data, P["qb"], P["vb"], (3 * H,))
         # Head-interleaved q|k|v (round 4): the QKV GEMM runs on a row-permuted copy of [Wq; Wk; Wv] (store.qkv_interleaved), so a
         # head's q | k | v is ONE 384-byte segment per token instead of three 128-byte segments 1536 bytes apart -- the attention
         # kernels' access pattern is what bounds them (forward 4.2 -> 4.7 TB/s).  Same dot products in the same order: qkv, dqkv,

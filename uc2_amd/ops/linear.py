@@ -1,6 +1,7 @@
 """Linear-layer building blocks on the planned GEMMs: forward, fused dropout + residual tail, input gradients (W or W^T), weight
 gradients (side stream / grouped launch).  Part of uc2_amd.ops."""
 import ctypes
+import functools
 
 import torch
 
@@ -131,6 +132,7 @@ def _num_cus(device):
     return _CUS[key]
 
 
+@functools.lru_cache(maxsize=256)
 def _group_split(tiles, ktiles, cus):
     """common split-K factor of a grouped weight-gradient launch: fewest rounds of equal items, counting ~8 k-tile times per
     round for the partial-tile epilogue, the next item's first fetch and the reduction's share (measured at 108 tiles x 156

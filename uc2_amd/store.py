@@ -138,6 +138,7 @@ class ParamStore:
                 if raw_grad(p) is not None:       # keep an existing gradient (folded into the arena)
                     self.grad_buf(p)
         self.shadow = None
+        self._gviews, self._cviews, self._spans = {}, {}, {}      # cached views of the gradient / bf16 arenas (host time: see grad_buf)
         self.version = 1
         self.shadow_version = 0
         self.auto_sync = True         # re-cast the bf16 copies at every top-level forward (safe default)
@@ -173,9 +174,17 @@ class ParamStore:
                 p._uc2_gepoch = self.grad_epoch
 
     def grad_buf(self, p):
-        """fp32 accumulation buffer for p (a view of the gradient arena), installed as p.grad"""
-        self._ensure_grad()
-        v = self.view(self.grad, p)
+        """fp32 accumulation buffer for p (a view of the gradient arena), installed as p.grad.  The view objects are cached (a
+        BertLayer backward asks for 16 of them, 3 us each to build: a third of its host time at the reference's micro-batch size);
+        a cached view is re-validated by its address, since it has been handed out as p.grad and `p.grad.data = t` would re-point it."""
+        if self.grad is None:
+            self._ensure_grad()
+        c = self._gviews.get(id(p))
+        if c is None or c[0].data_ptr() != c[1] or c[2] is not self.grad:
+            v = self.view(self.grad, p)
+            self._gviews[id(p)] = (v, v.data_ptr(), self.grad)
+        else:
+            v = c[0]
         g = raw_grad(p)
         if g is None:
             if p._uc2_gepoch != self.grad_epoch:      # slice not known to be zero
@@ -188,10 +197,18 @@ class ParamStore:
             p._uc2_gepoch = -1
         return v
 
+    def span_view(self, flat, p_first, p_last, shape):
+        key = (id(p_first), id(p_last), tuple(shape), flat.dtype)
+        c = self._spans.get(key)
+        if c is None or c[1] is not flat or c[0].data_ptr() != c[2]:
+            v = self.span(flat, p_first, p_last, shape)
+            self._spans[key] = c = (v, flat, v.data_ptr())
+        return c[0]
+
     def grad_span(self, p_first, p_last, shape):
         for p in self.params[self.pos[id(p_first)]: self.pos[id(p_last)] + 1]:
             self.grad_buf(p)
-        return self.span(self.grad, p_first, p_last, shape)
+        return self.span_view(self.grad, p_first, p_last, shape)
 
     def zero_grad(self):
         if self.grad is not None:
@@ -232,10 +249,14 @@ class ParamStore:
     def compute(self, p, dtype):
         if dtype == torch.float32:
             return p.data
-        return self.view(self.shadow, p)
+        c = self._cviews.get(id(p))
+        if c is None or c[1] is not self.shadow or c[0].data_ptr() != c[2]:
+            v = self.view(self.shadow, p)
+            self._cviews[id(p)] = c = (v, self.shadow, v.data_ptr())
+        return c[0]
 
     def compute_span(self, p_first, p_last, shape, dtype):
-        return self.span(self.data if dtype == torch.float32 else self.shadow, p_first, p_last, shape)
+        return self.span_view(self.data if dtype == torch.float32 else self.shadow, p_first, p_last, shape)
 
     # ---- k-contiguous copies W^T of the layer weights (bf16), for the input-gradient GEMMs dX = dY W ----
     def compute_t(self, p_first, p_last=None, shape=None):
