@@ -461,3 +461,32 @@ def test_arena_parameter_grad_access_runs_the_pending_pass_hook():
     assert m.weight.grad is not None and len(calls) == n        # nothing pending: the attribute costs one check
     import copy
     assert type(copy.deepcopy(m).weight) is store.ArenaParameter
+
+
+def test_param_store_cached_views_survive_what_callers_do_to_grad():
+    """ParamStore hands out cached view objects of its arenas (a BertLayer backward asks for 16 gradient views: host time) -- a
+    cached gradient view IS p.grad, so it is re-validated by address: `p.grad.data = t` re-points it, `p.grad = None` and
+    zero_grad() drop it, a foreign tensor assigned as p.grad is folded into the arena, as before the cache"""
+    from uc2_amd import store
+    m = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.Linear(4, 4))
+    st = store.ParamStore(m)
+    w, b = m[0].weight, m[0].bias
+    g = st.grad_buf(w)
+    assert st.grad_buf(w) is g and store.raw_grad(w) is g and g.data_ptr() == st.grad.data_ptr() + 4 * st.offsets[id(w)]
+    g.fill_(3.0)
+    w.grad = None                                              # (set_to_none style)
+    g2 = st.grad_buf(w)
+    assert g2.data_ptr() == g.data_ptr() and float(g2.abs().sum()) == 0.0          # a dropped gradient comes back as zeros
+    st.zero_grad()
+    assert store.raw_grad(w) is None and float(st.grad_buf(w).abs().sum()) == 0.0
+    foreign = torch.full_like(w, 0.5)
+    w.grad.data = foreign                                      # re-points the tensor object the cache holds
+    g3 = st.grad_buf(w)
+    assert g3.data_ptr() == st.grad.data_ptr() + 4 * st.offsets[id(w)] and torch.equal(g3, foreign) and store.raw_grad(w) is g3
+    b.grad = torch.ones_like(b)                                # a foreign gradient tensor
+    assert torch.equal(st.grad_buf(b), torch.ones_like(b)) and store.raw_grad(b).data_ptr() == st.grad.data_ptr() + 4 * st.offsets[id(b)]
+    # spans over adjacent parameters and the compute views
+    s1 = st.grad_span(m[0].weight, m[0].weight, (4, 6))
+    assert st.grad_span(m[0].weight, m[0].weight, (4, 6)) is s1 and s1.data_ptr() == g3.data_ptr()
+    assert st.compute(w, torch.float32).data_ptr() == w.data_ptr()
+    assert st.span_view(st.data, w, w, (24,)) is st.span_view(st.data, w, w, (24,))
