@@ -272,6 +272,14 @@ def gemm_plan(dtype, ta, tb, M, N, K, wgrad=False):
                 sp_t = min(valid, key=lambda s: (abs(tiles * s - target), s))
                 cands.append((8, sp_t))
                 cands.append((12, sp_t))              # the same schedule on the 16x16x32 MFMA (within a few % of 8 either way here)
+        if tiles < cus:
+            # few output tiles under a long contraction (the MLM head's dz = dlogits E: 90 tiles x 3 908 k-tiles per 7 680-row chunk):
+            # whole ROUNDS of items count, not the item count -- 540 items = 2.11 rounds ran 2 565 us, 990 = 3.87 rounds 2 144 us
+            # (tools/bench_decoder_dz.py).  The largest valid split at or below r rounds, r = 2 .. 8, while an item keeps >= 32 k-tiles
+            for r_ in range(2, 9):
+                fit = [s for s in valid if tiles * s <= r_ * cus and K // 64 // s >= 32]
+                if fit:
+                    cands.append((12, fit[-1]))
         cands = list(dict.fromkeys(cands))
     best, best_t = default, None
     timer_was, state.gemm_timer = state.gemm_timer, None          # tuning launches are not part of anybody's timed region
