@@ -1471,6 +1471,35 @@ def test_fp8_weight_copies_in_one_batch():
     assert lib.uc2_fp8_quant_weights_batch(1, bad, None) == -2
 
 
+def test_fp8_delayed_quantisation_dense_kernel_equals_the_strided_one():
+    """uc2_fp8_quant_delayed takes dense bf16 tensors (ldx == ldo == cols, cols % 16 == 0) through a 16-values-per-thread kernel: the
+    same e4m3 bytes, the same recorded maximum and scale as the general kernel on a strided copy of the same values; ragged tail of
+    the flat index included (rows x cols not a multiple of the grid's stride)"""
+    from uc2_amd import _lib
+    lib = _lib.load()
+    C = ops.AMAX_CELLS
+    for rows, cols in ((300, 512), (1031, 1024), (7, 48)):
+        x = rnd((rows, cols), 11, 2.0, dtype=torch.bfloat16)
+        x[rows // 2, cols // 3] = 17.0
+        xs = torch.zeros((rows, cols + 16), dtype=torch.bfloat16, device=DEV)
+        xs[:, :cols].copy_(x)
+        res = []
+        for src, ldx, ldo in ((x, cols, cols), (xs, cols + 16, cols + 16)):
+            cells = torch.zeros(3 * C, dtype=torch.int32, device=DEV)
+            cells[0] = torch.tensor([6.0], device=DEV).view(torch.int32)[0]           # previous maximum 6.0 -> scale 2^6 / 2
+            cells[2 * C:] = 7                                                            # the group to clear
+            out = torch.zeros((rows, ldo), dtype=torch.uint8, device=DEV)
+            scale = torch.zeros(1, device=DEV)
+            _lib.check(lib.uc2_fp8_quant_delayed(1, rows, cols, src.data_ptr(), ldx, cells[:C].data_ptr(), cells[C:2 * C].data_ptr(),
+                                                 cells[2 * C:].data_ptr(), scale.data_ptr(), out.data_ptr(), ldo, _lib.stream()))
+            torch.cuda.synchronize()
+            res.append((out[:, :cols].clone(), float(scale), int(cells[C:2 * C].max()), int(cells[2 * C:].abs().max())))
+        (o0, s0, m0, c0), (o1, s1, m1, c1) = res
+        assert torch.equal(o0, o1) and s0 == s1 == 32.0 and m0 == m1 and c0 == c1 == 0
+        assert m0 == int(torch.tensor([17.0]).view(torch.int32)[0])
+        assert rel_err(o0.view(torch.float8_e4m3fn).float() / s0, x.float().clamp(-448.0 / s0, 448.0 / s0)) < 0.04
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_fp8_delayed_scaling_quantisation_one_pass(dtype):
     """uc2_fp8_quant_delayed through ops.fp8_quantize_act: the first use of a tensor role takes the just-in-time route and starts the

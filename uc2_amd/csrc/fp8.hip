@@ -103,6 +103,36 @@ __global__ __launch_bounds__(256) void fp8_quant_delayed_kernel(int rows, int co
   __syncthreads();
   if (threadIdx.x == 0) atomicMax(amax_next + (blockIdx.x & (UC2_AMAX_CELLS - 1)), __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
 }
+// the same pass for a dense bf16 tensor (ldx == ldo == cols, cols % 16 == 0, 16-byte aligned): 16 values per thread and step (two
+// 16-byte loads, one 16-byte store) on a flat index -- the general kernel above moves 8 / 4 bytes per lane and divides a 64-bit index
+// per step: 150 us for the 133 120 x 1024 activations of a uc2-large layer = 2.7 TB/s (profiles/r06_experiments.md section 5)
+__global__ __launch_bounds__(256) void fp8_quant_delayed16_kernel(size_t n16, const bf16* __restrict__ x, const unsigned* __restrict__ amax_prev,
+                                                                  unsigned* __restrict__ amax_next, unsigned* __restrict__ amax_clear,
+                                                                  float* __restrict__ scale_out, uint8_t* __restrict__ out) {
+  const float s = fp8_delayed_scale(amax_prev);
+  if (blockIdx.x == 0 && threadIdx.x < UC2_AMAX_CELLS) { amax_clear[threadIdx.x] = 0u; if (threadIdx.x == 0) *scale_out = s; }
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+    const bf16x8 a = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(x) + 2 * i);
+    const bf16x8 b = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(x) + 2 * i + 1);
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[e] = (float)a[e]; v[8 + e] = (float)b[e]; }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) m = fmaxf(m, fabsf(v[e]));
+    uint4 o;
+    o.x = fp8_pack4_sat(v[0] * s, v[1] * s, v[2] * s, v[3] * s);
+    o.y = fp8_pack4_sat(v[4] * s, v[5] * s, v[6] * s, v[7] * s);
+    o.z = fp8_pack4_sat(v[8] * s, v[9] * s, v[10] * s, v[11] * s);
+    o.w = fp8_pack4_sat(v[12] * s, v[13] * s, v[14] * s, v[15] * s);
+    reinterpret_cast<uint4*>(out)[i] = o;
+  }
+  __shared__ float wm[4];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(amax_next + (blockIdx.x & (UC2_AMAX_CELLS - 1)), __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+}
 extern "C" int uc2_fp8_quant_delayed(int dtype, int rows, int cols, const void* x, int ldx, const void* amax_prev, void* amax_next,
                                      void* amax_clear, float* scale_out, void* out, int ldo, void* stream) {
   UC2_CHECK_ARG(dtype == 0 || dtype == 1);
@@ -113,6 +143,13 @@ extern "C" int uc2_fp8_quant_delayed(int dtype, int rows, int cols, const void* 
   const size_t blocks = ((size_t)rows * (cols / 4) + 255) / 256;
   const int grid = (int)(blocks > 2048 ? 2048 : blocks);
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == 1 && ldx == cols && ldo == cols && (cols & 15) == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
+    const size_t n16 = (size_t)rows * cols / 16, b16 = (n16 + 255) / 256;
+    hipLaunchKernelGGL(fp8_quant_delayed16_kernel, dim3((int)(b16 > 2048 ? 2048 : b16)), dim3(256), 0, st, n16, (const bf16*)x, (const unsigned*)amax_prev,
+                       (unsigned*)amax_next, (unsigned*)amax_clear, scale_out, (uint8_t*)out);
+    UC2_LAUNCH_CHECK();
+    return 0;
+  }
   if (dtype == 0) hipLaunchKernelGGL(fp8_quant_delayed_kernel<float>, dim3(grid), dim3(256), 0, st, rows, cols, (const float*)x, ldx, (const unsigned*)amax_prev, (unsigned*)amax_next, (unsigned*)amax_clear, scale_out, (uint8_t*)out, ldo);
   else hipLaunchKernelGGL(fp8_quant_delayed_kernel<bf16>, dim3(grid), dim3(256), 0, st, rows, cols, (const bf16*)x, ldx, (const unsigned*)amax_prev, (unsigned*)amax_next, (unsigned*)amax_clear, scale_out, (uint8_t*)out, ldo);
   UC2_LAUNCH_CHECK();
