@@ -162,6 +162,14 @@ int uc2_gemm_fp8_q(int M, int N, int K, const void* A8, int lda, const void* B8,
 int uc2_gemm_fp8(int M, int N, int K, const void* A8, int lda, const void* B8, int ldb, const float* scale_a,
                  const float* scale_b, void* C, int ldc, const float* bias, int epilogue, const void* aux_in, void* aux_out,
                  int ldaux, int flags, void* stream);
+/* The e4m3 form of uc2_gemm_drop_residual (model/layer.py:111-115, :152-156 in fp8 mode): C (bf16) = dropout_p(A8 W8^T / (*scale_a
+ * *scale_w) + bias) + residual, the same counter-based mask (seed_imm + *seed_ptr, row, column) as uc2_ln_fwd / uc2_ln_bwd, so the caller
+ * follows with uc2_ln_fwd_q(x = C, residual = NULL, drop_p = 0) and uc2_ln_bwd_partial_q(..., drop_after = 2) in the backward.
+ * Ping-pong e4m3 kernel only: -2 (nothing launched) unless M % 256 == 0, N % 256 == 0, K % 256 == 0, 16-byte aligned pointers and
+ * operands below 4 GiB; the caller then keeps uc2_gemm_fp8 + the LayerNorm kernel's own dropout / residual. */
+int uc2_gemm_fp8_drop_residual(int M, int N, int K, const void* A8, int lda, const void* W8, int ldw, const float* scale_a,
+                               const float* scale_w, void* C, int ldc, const float* bias, const void* residual, int ldres,
+                               float p_drop, const uint64_t* seed_ptr, uint64_t seed_imm, void* stream);
 
 /* ---- One BertLayer per call (model/layer.py:159-170: BertAttention -> BertIntermediate -> BertOutput) ---------------------------
  * The launch sequence of uc2_amd/ops/layer.py BertLayerFn -- 7 launches forward, 8 backward -- enqueued by one C call per direction: the same

@@ -1296,6 +1296,69 @@ def test_gemm_fp8_pingpong_vs_dequantised_reference_and_ring_kernel(M, N, K, epi
         assert rel_err(second.float(), want2) < (4e-3 if epi == "gelu_d" else 2e-2)
 
 
+@pytest.mark.parametrize("M,N,K,p", [(512, 768, 768, 0.1), (16640, 1024, 4096, 0.1), (16640, 1024, 1024, 0.25), (768, 1024, 1024, 0.0)])
+def test_gemm_fp8_drop_residual_epilogue_vs_dequantised_reference(M, N, K, p):
+    """uc2_gemm_fp8_drop_residual (EPI_DROPADD in gemm_pp8.hip): s = dropout(x8 w8^T / (sx sw) + b) + residual against a float matmul
+    of the dequantised operands with the LayerNorm kernels' keep mask for the same (seed, site); dropped elements are the residual bit
+    for bit; the LayerNorm of the sum and ln_bwd(drop_after=2) through it agree with the unfused fp8 chain gemm_fp8 -> ln_fwd(o, res, p);
+    two launches are bit-identical; shapes off the ping-pong kernel are refused with nothing launched"""
+    from uc2_amd import _lib
+    x = rnd((M, K), 1, 1.3, dtype=torch.bfloat16)
+    w = rnd((N, K), 2, 0.03, dtype=torch.bfloat16)
+    bias = rnd((N,), 3, 0.1)
+    res = rnd((M, N), 4, 1.0, dtype=torch.bfloat16)
+    x8, sx = ops.fp8_quantize(x)
+    w8, sw = ops.fp8_quantize(w)
+    seed = torch.tensor([977], dtype=torch.int64, device=DEV)
+    site = 51
+    lib = _lib.load()
+
+    def fused():
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        _lib.check(lib.uc2_gemm_fp8_drop_residual(M, N, K, x8.data_ptr(), x8.stride(0), w8.data_ptr(), w8.stride(0), sx.data_ptr(), sw.data_ptr(),
+                                                  out.data_ptr(), N, bias.data_ptr(), res.data_ptr(), N, p, seed.data_ptr() if p else None, site,
+                                                  _lib.stream()))
+        return out
+    s = fused()
+    assert torch.equal(s.view(torch.int16), fused().view(torch.int16)) and torch.isfinite(s.float()).all()
+    if p:
+        probe = rnd((M, N), 7) + 3.0
+        yk, _, _ = ops.ln_fwd(probe, None, torch.ones(N, device=DEV), torch.full((N,), 10.0, device=DEV), 1e-5, p, seed, site, drop_after=True)
+        keep = yk != 0
+        assert abs(1.0 - keep.float().mean().item() - p) < 0.01
+    else:
+        keep = torch.ones((M, N), dtype=torch.bool, device=DEV)
+    o32 = (x8.view(torch.float8_e4m3fn).float() / sx) @ (w8.view(torch.float8_e4m3fn).float() / sw).t() + bias
+    ref = torch.where(keep, o32 / (1 - p), torch.zeros_like(o32)) + res.float()
+    assert torch.equal(s[~keep], res[~keep])
+    assert rel_err(s.float(), ref) < 4e-3
+    assert (s.float() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()          # one bf16 rounding of the sum
+    # against the unfused e4m3 chain (the dense output rounded to bf16 before the LayerNorm kernel's dropout + residual)
+    g, b = (1 + 0.1 * rnd((N,), 5)), rnd((N,), 6, 0.1)
+    o = ops.gemm_fp8(x8, sx, w8, sw, bias=bias)
+    y0, mean0, rstd0 = ops.ln_fwd(o, res, g, b, 1e-12, p, seed if p else None, site)
+    y1, mean1, rstd1 = ops.ln_fwd(s, None, g, b, 1e-12)
+    assert rel_err(y1.float(), y0.float()) < 8e-3
+    dy = rnd((M, N), 8, 0.1, torch.bfloat16)
+    dg0, db0, dbi0 = [torch.zeros(N, device=DEV) for _ in range(3)]
+    dg1, db1, dbi1 = [torch.zeros(N, device=DEV) for _ in range(3)]
+    dx0, dr0 = ops.ln_bwd(dy, o, res, g, mean0, rstd0, dg0, db0, p, seed if p else None, site, dbias=dbi0)
+    dx1, dr1 = ops.ln_bwd(dy, s, None, g, mean1, rstd1, dg1, db1, p, seed if p else None, site, dbias=dbi1, drop_after=2)
+    ops.join_side_streams()
+    torch.cuda.synchronize()
+    assert torch.equal(dx1 == 0, dx0 == 0)
+    assert rel_err(dx1.float(), dx0.float()) < 1e-2 and rel_err(dr1.float(), dr0.float()) < 1e-2
+    for a_, b_ in ((dg1, dg0), (db1, db0), (dbi1, dbi0)):
+        assert rel_err(a_, b_) < 1e-2
+    # refused: a token count that is not made of whole tiles, p = 1
+    out = torch.empty((200, N), dtype=torch.bfloat16, device=DEV)
+    assert lib.uc2_gemm_fp8_drop_residual(200, N, K, x8.data_ptr(), x8.stride(0), w8.data_ptr(), w8.stride(0), sx.data_ptr(), sw.data_ptr(),
+                                          out.data_ptr(), N, None, res.data_ptr(), N, 0.1, None, 3, _lib.stream()) == -2
+    rc = lib.uc2_gemm_fp8_drop_residual(M, N, K, x8.data_ptr(), x8.stride(0), w8.data_ptr(), w8.stride(0), sx.data_ptr(), sw.data_ptr(),
+                                        s.data_ptr(), N, None, res.data_ptr(), N, 1.0, None, 3, _lib.stream())
+    assert rc != 0 and rc != -2
+
+
 @pytest.mark.parametrize("M,N,K", [(512, 512, 256), (16640, 4096, 1024), (16640, 1024, 4096)])
 @pytest.mark.parametrize("epi", ["gelu_d", "mul"])
 def test_gemm_fp8_fused_e4m3_output_stream(M, N, K, epi):

@@ -15,7 +15,7 @@ from .config import cfg
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = cfg.lib_path      # (UC2_LIB_PATH: A/B of two builds on one box)
 _lib = None
-ABI_VERSION = 12         # include/uc2_hip.h; bumped whenever a signature changes
+ABI_VERSION = 13         # include/uc2_hip.h; bumped whenever a signature changes
 
 P, I, F, U64, I64, SZ = c_void_p, c_int, c_float, c_uint64, c_int64, c_size_t
 
@@ -43,6 +43,7 @@ SIGNATURES = {
     "uc2_fp8_quant_amax": (I, [I, I, I, P, I, P, P, P, I, I, P]),
     "uc2_fp8_quant_delayed": (I, [I, I, I, P, I, P, P, P, P, P, I, P]),
     "uc2_gemm_fp8_q": (I, [I, I, I, P, I, P, I, P, P, P, I, P, I, P, P, I, I, P, I, P, P, P, P, P]),
+    "uc2_gemm_fp8_drop_residual": (I, [I, I, I, P, I, P, I, P, P, P, I, P, P, I, F, P, U64, P]),
     "uc2_gemm_fp8": (I, [I, I, I, P, I, P, I, P, P, P, I, P, I, P, P, I, I, P]),
     "uc2_ln_fwd": (I, [I, I, I, P, P, P, P, F, F, I, P, U64, P, P, P, P]),
     "uc2_ln_bwd_workspace": (SZ, [I, I]),

@@ -130,7 +130,7 @@ __device__ __forceinline__ void attn_q_amax(const AttnQ& aq, float qmax, float* 
     float m = wm[0];
 #pragma unroll
     for (int i = 1; i < NW; ++i) m = fmaxf(m, wm[i]);
-    atomicMax(aq.next + (blockIdx.x & (UC2_AMAX_CELLS - 1)), __float_as_uint(m));
+    amax_cell_raise(aq.next + (blockIdx.x & (UC2_AMAX_CELLS - 1)), m);
   }
 }
 __device__ __forceinline__ void store_acc_block(bf16* __restrict__ row_ptr, const f32x16& a, float scale, int h, bool ok,

@@ -10,7 +10,7 @@ extern "C" void uc2_set_error(const char* file, int line, const char* what) {
   snprintf(g_err, sizeof(g_err), "%s:%d: %s", file, line, what);
 }
 extern "C" const char* uc2_last_error(void) { return g_err; }
-extern "C" int uc2_abi_version(void) { return 12; }
+extern "C" int uc2_abi_version(void) { return 13; }
 
 // number of compute units / arch string of the current device (diagnostics for bench.py)
 extern "C" int uc2_device_info(int* cu_count, int* clock_khz, char* arch, int arch_len) {

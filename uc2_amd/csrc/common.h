@@ -182,6 +182,14 @@ __device__ __forceinline__ unsigned amax_cells_read(const unsigned* __restrict__
   for (int i = 0; i < UC2_AMAX_CELLS; ++i) m = max(m, cells[i]);
   return m;
 }
+// max-accumulate a workgroup's |value| maximum into a cell: the atomic only if it would raise the cell.  The 16 cells of a group share
+// one 64-byte line, and same-line atomics serialise in the L2 whatever their address: the 16 640 workgroups of a LayerNorm forward over
+// 133 120 rows spent 118 of their 209 us queueing on that line (profiles/r06_experiments.md section 5).  A stale (lower) read only costs
+// an atomic that was not needed; the cells of a group are never lowered while the group is being accumulated (common protocol above).
+__device__ __forceinline__ void amax_cell_raise(unsigned* cell, float m) {
+  const unsigned b = __float_as_uint(m);                       // non-negative floats order like their bit patterns
+  if (b > __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(cell, b);
+}
 // the power-of-two scale that maps `amax` just below the e4m3 maximum (448)
 __device__ __forceinline__ float fp8_scale_of(unsigned amax_bits) {
   const float a = __uint_as_float(amax_bits);

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void fp8_amax_kernel(size_t n, const T* __rest
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0)
-    atomicMax(amax_bits, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));   // non-negative floats order like their bit patterns
+    amax_cell_raise(amax_bits, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
 }
 __global__ void fp8_scale_kernel(const unsigned* __restrict__ amax_bits, float* __restrict__ scale) { *scale = fp8_scale_of(*amax_bits); }
 __device__ __forceinline__ unsigned pack4_e4m3(const float (&v)[4]) {
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void fp8_quant_delayed_kernel(int rows, int co
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) atomicMax(amax_next + (blockIdx.x & (UC2_AMAX_CELLS - 1)), __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+  if (threadIdx.x == 0) amax_cell_raise(amax_next + (blockIdx.x & (UC2_AMAX_CELLS - 1)), fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
 }
 // the same pass for a dense bf16 tensor (ldx == ldo == cols, cols % 16 == 0, 16-byte aligned): 16 values per thread and step (two
 // 16-byte loads, one 16-byte store) on a flat index -- the general kernel above moves 8 / 4 bytes per lane and divides a 64-bit index
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void fp8_quant_delayed16_kernel(size_t n16, co
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) atomicMax(amax_next + (blockIdx.x & (UC2_AMAX_CELLS - 1)), __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+  if (threadIdx.x == 0) amax_cell_raise(amax_next + (blockIdx.x & (UC2_AMAX_CELLS - 1)), fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
 }
 extern "C" int uc2_fp8_quant_delayed(int dtype, int rows, int cols, const void* x, int ldx, const void* amax_prev, void* amax_next,
                                      void* amax_clear, float* scale_out, void* out, int ldo, void* stream) {
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void fp8_wb_amax_kernel(Fp8WBatch b) {
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) atomicMax(b.amax[i], __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+  if (threadIdx.x == 0) amax_cell_raise(b.amax[i], fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
 }
 __global__ __launch_bounds__(256) void fp8_wb_quant_kernel(Fp8WBatch b) {
   __shared__ float tile[64][65];
@@ -322,6 +322,31 @@ extern "C" int uc2_gemm_fp8(int M, int N, int K, const void* A8, int lda, const 
   if (epilogue == EPI_DGELU && aux_out != nullptr && route != 2) {       // (the ping-pong kernel's epilogue produced the column sums)
     return uc2_colsum_accum(1, M, N, C, ldc, nullptr, reinterpret_cast<float*>(aux_out), stream);
   }
+  return 0;
+}
+
+// The e4m3 form of uc2_gemm_drop_residual: C (bf16) = dropout_p(A8 W8^T / (scale_a scale_w) + bias) + residual, the pre-LayerNorm sum
+// of the encoder's dense -> dropout -> add tails, mask = the LayerNorm kernels' counter-based mask (common.h drop_keep4) for
+// (seed, row, column).  Only the ping-pong kernel has this epilogue: -2 (nothing launched) for shapes it does not take -- the caller
+// then runs uc2_gemm_fp8 and leaves dropout + residual to uc2_ln_fwd.  p_drop == 0: the plain residual add.
+extern "C" int uc2_gemm_fp8_drop_residual(int M, int N, int K, const void* A8, int lda, const void* W8, int ldw, const float* scale_a,
+                                          const float* scale_w, void* C, int ldc, const float* bias, const void* residual, int ldres,
+                                          float p_drop, const uint64_t* seed_ptr, uint64_t seed_imm, void* stream) {
+  UC2_CHECK_ARG(M >= 0 && N >= 0 && K > 0 && (K % 128) == 0);
+  UC2_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f);
+  if (M == 0 || N == 0) return 0;
+  UC2_CHECK_ARG(A8 && W8 && C && residual && scale_a && scale_w);
+  UC2_CHECK_ARG((lda % 16) == 0 && (ldw % 16) == 0 && (((uintptr_t)A8 | (uintptr_t)W8) & 15) == 0);
+  GemmArgs p{};
+  p.A = A8; p.B = W8; p.C = C; p.bias = bias; p.aux_in = residual; p.aux_out = nullptr;
+  p.M = M; p.N = N; p.K = K / 2; p.lda = lda / 2; p.ldb = ldw / 2; p.ldc = ldc; p.ldaux = ldres;
+  p.epi = p_drop > 0.f ? EPI_DROPADD : EPI_ADD; p.split_k = 1; p.a_vec = 1; p.b_vec = 1; p.alpha = 1.0f;
+  p.alpha_dev = scale_a; p.alpha_dev2 = scale_w;
+  p.drop_thresh = drop_thresh(p_drop); p.drop_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  p.drop_seed_ptr = seed_ptr; p.drop_seed_imm = seed_imm;
+  if (!uc2_gemm_pp8_supported(p)) return -2;
+  uc2_gemm_pp8_launch(p, (hipStream_t)stream);
+  UC2_LAUNCH_CHECK();
   return 0;
 }
 

@@ -28,11 +28,20 @@ template <int EPI, bool QOUT = false>
 __device__ __forceinline__ void pp8_epi_compute_q(const GemmArgs& p, const f32x4 (&acc)[2][4][4], PpOut& out, int mb0, int nb0,
                                                   int lane, const TpAddr& ta, float alpha, float qs, float& qmax) {
   const int g = lane >> 4, r15 = lane & 15, lr = lane >> 3, lc = lane & 7;
-  constexpr bool has_aux = (EPI == EPI_DGELU || EPI == EPI_ADD || EPI == EPI_MUL);
+  constexpr bool has_aux = (EPI == EPI_DGELU || EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_DROPADD);
   constexpr bool two = (EPI == EPI_GELU || EPI == EPI_GELU_D);
   const bool want_cs = (EPI == EPI_DGELU || EPI == EPI_MUL) && p.aux_out != nullptr;
   const unsigned tb = ta.line - (unsigned)(lr * 128 + ((lc ^ lr) << 4));
   const unsigned q0 = tb + (unsigned)r15 * 128u + ((unsigned)((g >> 1) ^ (r15 & 7)) << 4) + 8u * (unsigned)(g & 1);
+  // EPI_DROPADD (as in gemm_pp16.h): the column part of the dropout variate for the lane's four pieces of the tile; p == 0 is routed
+  // to EPI_ADD by the launcher
+  uint32_t hcol[4];
+  uint64_t dseed = 0;
+  if (EPI == EPI_DROPADD) {
+    dseed = p.drop_seed_imm + (p.drop_seed_ptr ? *p.drop_seed_ptr : 0ull);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) hcol[nb] = drop_col_hash(dseed, (uint32_t)((nb0 >> 2) + 4 * nb + g));
+  }
   float cs[16];
 #pragma unroll
   for (int v = 0; v < 16; ++v) cs[v] = 0.f;
@@ -67,6 +76,11 @@ __device__ __forceinline__ void pp8_epi_compute_q(const GemmArgs& p, const f32x4
       }
       bf16x4 pre[8];
       unsigned qv[8];
+      uint32_t hrow[2];
+      if (EPI == EPI_DROPADD) {
+        hrow[0] = drop_row_hash(dseed, (uint32_t)(mb0 + hh * 64 + i * 32 + r15));
+        hrow[1] = drop_row_hash(dseed, (uint32_t)(mb0 + hh * 64 + i * 32 + 16 + r15));
+      }
 #pragma unroll
       for (int mbl = 0; mbl < 2; ++mbl)
 #pragma unroll
@@ -118,6 +132,12 @@ __device__ __forceinline__ void pp8_epi_compute_q(const GemmArgs& p, const f32x4
           } else if (EPI == EPI_ADD) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += (float)axq[k][e];
+          } else if (EPI == EPI_DROPADD) {
+            // dropout(dense output) + residual, the mask of element (row, column) exactly as ln_fwd / ln_bwd derive it
+            bool kp[4];
+            drop_keep4(hrow[mbl], hcol[nb], p.drop_thresh, kp);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (kp[e] ? v[e] * p.drop_scale : 0.f) + (float)axq[k][e];
           } else if (EPI == EPI_TANH) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = tanh_bf(v[e]);

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_pp8_kernel(GemmArgs p) {
   // main-loop diagnostics (with 0x800): 0x100 = no LDS-DMA issue (stale LDS contents), 0x200 = no fragment reads after the first k-tile
   const bool dg_nodma = UC2_PP8_DIAG && (p.atomic & 0x100) != 0, dg_nord = UC2_PP8_DIAG && (p.atomic & 0x200) != 0;     // (make EXTRA=-DUC2_PP8_DIAG=1)
   bool more = false;                                   // another item follows the current one
-  constexpr bool AUXK = TACC && (EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_DGELU);     // epilogues that read an aux_in tile
+  constexpr bool AUXK = TACC && (EPI == EPI_ADD || EPI == EPI_MUL || EPI == EPI_DGELU || EPI == EPI_DROPADD);     // epilogues that read an aux_in tile
   unsigned aux_t0 = 0, aux_t1 = 0;                     // (PP16_AUX_TOUCH) destinations of the line-touching loads
   const bool aux_touch = AUXK && (size_t)p.M * (size_t)p.N <= ((size_t)32 << 20);
   auto body = [&](auto tail_c, auto swap_c, int kt) __attribute__((always_inline)) {
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_pp8_kernel(GemmArgs p) {
       float mm = red[0];
 #pragma unroll
       for (int i = 1; i < 8; ++i) mm = fmaxf(mm, red[i]);
-      atomicMax(p.q_amax_next + (blockIdx.x & (UC2_AMAX_CELLS - 1)), __float_as_uint(mm));
+      amax_cell_raise(p.q_amax_next + (blockIdx.x & (UC2_AMAX_CELLS - 1)), mm);
     }
   }
   if (dbg) {
@@ -523,7 +523,7 @@ bool uc2_gemm_pp8_supported(const GemmArgs& p) {
       ((uintptr_t)p.aux_out & 15) || ((uintptr_t)p.bias & 15)) return false;
   if (p.epi == EPI_GELU) return p.aux_deriv && p.aux_out != nullptr;
   if (p.epi == EPI_DGELU) return p.aux_deriv != 0;
-  return p.epi == EPI_NONE || p.epi == EPI_ADD;
+  return p.epi == EPI_NONE || p.epi == EPI_ADD || p.epi == EPI_DROPADD;
 }
 
 void uc2_gemm_pp8_launch(const GemmArgs& p0, hipStream_t st) {
@@ -543,5 +543,6 @@ void uc2_gemm_pp8_launch(const GemmArgs& p0, hipStream_t st) {
   if (p.epi == EPI_GELU) pp8_launch0<EPI_GELU_D>(p, st);
   else if (p.epi == EPI_DGELU) pp8_launch0<EPI_MUL>(p, st);
   else if (p.epi == EPI_ADD) pp8_launch0<EPI_ADD>(p, st);
+  else if (p.epi == EPI_DROPADD) pp8_launch0<EPI_DROPADD>(p, st);
   else pp8_launch0<EPI_NONE>(p, st);
 }

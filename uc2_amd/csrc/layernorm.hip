@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int M, int H, const T* __re
     if (lane == 0) red[0][wv] = qmax;
     __syncthreads();
     if (threadIdx.x == 0)
-      atomicMax(q_next + (blockIdx.x & (UC2_AMAX_CELLS - 1)), __float_as_uint(fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]))));
+      amax_cell_raise(q_next + (blockIdx.x & (UC2_AMAX_CELLS - 1)), fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3])));
   }
 }
 
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void ln_fwd16_kernel(int M, int H, const bf16*
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = qmax;
     __syncthreads();
     if (threadIdx.x == 0)
-      atomicMax(lq.amax_next + (blockIdx.x & (UC2_AMAX_CELLS - 1)), __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+      amax_cell_raise(lq.amax_next + (blockIdx.x & (UC2_AMAX_CELLS - 1)), fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
   }
 }
 

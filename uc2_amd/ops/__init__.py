@@ -32,7 +32,7 @@ from .gemm import (  # noqa: F401
 )
 from .fp8 import (  # noqa: F401
     AMAX_CELLS, _FP8_CELLS, _FP8_HIST, _FP8_PREQ, _Fp8WeightItem, _ST_UID, _fp8_cell, _fp8_hist_for, _fp8_rotate, _fp8_weight,
-    _st_uid, fp8_amax, fp8_new_forward, fp8_quantize, fp8_quantize_act, gemm_fp8, gemm_fp8_q, linear_dgrad_fp8, linear_fwd_fp8,
+    _st_uid, fp8_amax, fp8_new_forward, fp8_quantize, fp8_quantize_act, gemm_fp8, gemm_fp8_q, linear_dgrad_fp8, linear_drop_residual_fp8, linear_fwd_fp8,
 )
 from .linear import (  # noqa: F401
     DGRAD_ROUTES, EPI_DROPADD, _CUS, _WgradItem, _group_split, _linear_wgrad_now, _num_cus, colsum_accum, linear_dgrad,

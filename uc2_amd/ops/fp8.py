@@ -229,6 +229,34 @@ def linear_fwd_fp8(x2, st, p_first, p_last, shape, bias, epi=EPI_NONE, aux_out=N
     return gemm_fp8(x8, sx, w8, sw, bias=bias, epi=epi, aux_out=aux_out, flags=flags)
 
 
+def linear_drop_residual_fp8(x2, st, p_first, p_last, shape, bias, res2, drop_p, seed, seed_imm, role=None, tag=None, pre_q=None):
+    """-> (s, None) with s = dropout(x2 w^T + bias) + res2 from ONE e4m3 GEMM launch (uc2_gemm_fp8_drop_residual: the fp8 form of
+    linear.linear_drop_residual, same mask as ln_fwd / ln_bwd), or (None, (x8, scale) or pre_q) with nothing launched when the ping-pong
+    e4m3 kernel does not take the shape: the caller keeps linear_fwd_fp8 (handing it that e4m3 copy, so the activation's history
+    advances once) + the LayerNorm kernel's own dropout / residual"""
+    M, K = x2.shape
+    N = shape[0]
+    if M % 256 or N % 256 or K % 256 or x2.dtype != torch.bfloat16:
+        return None, pre_q
+    w8, sw = _fp8_weight(st, p_first, p_last, shape, False)
+    x8, sx = pre_q if pre_q is not None else fp8_quantize_act(x2, None if role is None else (_st_uid(st), st.offsets[id(p_first)], "fwd", role, tag))
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=x2.device)
+    timer = state.gemm_timer
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _lib.load().uc2_gemm_fp8_drop_residual(M, N, K, ptr(x8), x8.stride(0), ptr(w8), w8.stride(0), ptr(sx), ptr(sw), ptr(out), N,
+                                                ptr(bias), ptr(res2), res2.stride(0), float(drop_p), ptr(seed), seed_imm, stream())
+    if rc == -2:
+        # (the activation was quantised above with its role's history advanced exactly as linear_fwd_fp8 would have: hand the copy on)
+        return None, (x8, sx)
+    _lib.check(rc)
+    if timer is not None:
+        e1.record()
+        timer.add(("fp8", 10), 2.0 * M * N * K, e0, e1)
+    return out, None
+
+
 def linear_dgrad_fp8(dy2, st, p_first, p_last, shape, epi=EPI_NONE, aux_in=None, colsum_out=None, flags=0, role=None, tag=None, pre_q=None, q_key=None):
     """dX = epi(dY W): the k-contiguous operand is the transposed e4m3 copy of W ([in, out])"""
     wt8, sw = _fp8_weight(st, p_first, p_last, shape, True)

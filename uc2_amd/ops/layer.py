@@ -11,7 +11,7 @@ from ..store import store_of
 from .base import EPI_ADD, EPI_DGELU, EPI_GELU, EPI_NONE, GEMM_AUX_DERIV, _FORCED, rng
 from .streams import _on_side_stream, _side_route
 from .gemm import _gemm_queue, _plan_fits, gemm, gemm_plan
-from .fp8 import _FP8_PREQ, _fp8_weight, _st_uid, fp8_quantize_act, gemm_fp8, linear_dgrad_fp8, linear_fwd_fp8
+from .fp8 import _FP8_PREQ, _fp8_weight, _st_uid, fp8_quantize_act, gemm_fp8, linear_dgrad_fp8, linear_drop_residual_fp8, linear_fwd_fp8
 from .linear import _num_cus, linear_dgrad, linear_drop_residual, linear_fwd, linear_wgrad, wgrad_group
 from .kernels import _ln_bwd_second_stage, attn_bwd, attn_fwd, flush_ln_reductions, ln_bwd, ln_fwd
 
@@ -205,12 +205,25 @@ class BertLayerFn(torch.autograd.Function):
             qkv = gemm_fp8(x8_, sx_, w8_, sw_, bias=bqkv)
             # (the attention kernel writes the e4m3 copy of ctx the output projection reads; same role key as the stand-alone pass)
             ctxv, lse, cq = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn, q_key=(_st_uid(st), st.offsets[id(P["ow"])], "fwd", "ctx", state.fp8_tag), rows=M)
-            o1 = linear_fwd_fp8(ctxv, st, P["ow"], P["ow"], (H, H), P["ob"].data, role="ctx", tag=state.fp8_tag, pre_q=cq)
-            a, mean1, rstd1, aq = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, s_ln1, q_key=ka)
+            # the dense -> dropout -> + residual tails as in the bf16 branch below: from LN_FUSE_MIN_ROWS tokens the e4m3 GEMM writes the
+            # pre-LayerNorm sum (uc2_gemm_fp8_drop_residual), the LayerNorm reads one tensor and hashes no mask
+            fuse = int(knobs.ln_fuse) if M >= knobs.ln_fuse_min_rows else 0
+            o1, cq = (linear_drop_residual_fp8(ctxv, st, P["ow"], P["ow"], (H, H), P["ob"].data, x2, p_h, seed, s_ln1, role="ctx", tag=state.fp8_tag,
+                                               pre_q=cq) if fuse & 1 else (None, cq))
+            fused1 = o1 is not None
+            if fused1:
+                a, mean1, rstd1, aq = ln_fwd(o1, None, P["g1"].data, P["b1"].data, 1e-12, q_key=ka)
+            else:
+                o1 = linear_fwd_fp8(ctxv, st, P["ow"], P["ow"], (H, H), P["ob"].data, role="ctx", tag=state.fp8_tag, pre_q=cq)
+                a, mean1, rstd1, aq = ln_fwd(o1, x2, P["g1"].data, P["b1"].data, 1e-12, p_h, seed, s_ln1, q_key=ka)
             # (the FFN1 GEMM's epilogue writes the e4m3 copy of u that FFN2 reads: no quantisation pass over [tokens, 4H])
             u, uq = linear_fwd_fp8(a, st, P["iw"], P["iw"], (I_, H), P["ib"].data, EPI_GELU, pre, flags=GEMM_AUX_DERIV, role="a", tag=state.fp8_tag,
                                    pre_q=aq, q_key=(_st_uid(st), st.offsets[id(P["fw"])], "fwd", "u", state.fp8_tag))
-            o2 = linear_fwd_fp8(u, st, P["fw"], P["fw"], (H, I_), P["fb"].data, role="u", tag=state.fp8_tag, pre_q=uq)
+            o2, uq = (linear_drop_residual_fp8(u, st, P["fw"], P["fw"], (H, I_), P["fb"].data, a, p_h, seed, s_ln2, role="u", tag=state.fp8_tag,
+                                               pre_q=uq) if fuse & 2 else (None, uq))
+            fused2 = o2 is not None
+            if not fused2:
+                o2 = linear_fwd_fp8(u, st, P["fw"], P["fw"], (H, I_), P["fb"].data, role="u", tag=state.fp8_tag, pre_q=uq)
         else:
             qkv = linear_fwd(x2, wqkv, bqkv)
             ctxv, lse = attn_fwd(qkv, mask2d, B, L, nh, D, p_a, seed, s_attn, ilv=ilv is not None, rows=M)
@@ -235,8 +248,10 @@ class BertLayerFn(torch.autograd.Function):
         if native:
             pass
         elif fp8:
-            fused1 = fused2 = False
-            y, mean2, rstd2, yq = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, s_ln2, q_key=ky)
+            if fused2:
+                y, mean2, rstd2, yq = ln_fwd(o2, None, P["g2"].data, P["b2"].data, 1e-12, q_key=ky)
+            else:
+                y, mean2, rstd2, yq = ln_fwd(o2, a, P["g2"].data, P["b2"].data, 1e-12, p_h, seed, s_ln2, q_key=ky)
             _FP8_PREQ.clear()                          # (at most one hand-over alive: the last layer's copy has no fp8 consumer)
             if yq is not None:
                 _FP8_PREQ[y.data_ptr()] = (cfg["layer_id"] + 1, yq)
@@ -307,7 +322,8 @@ class BertLayerFn(torch.autograd.Function):
         if nat is not None:
             pass
         elif fp8:
-            d_o2, dz2, dq2 = ln_bwd(dy2, o2, a, P["g2"].data, mean2, rstd2, G(P["g2"]), G(P["b2"]), p_h, seed, s_ln2, dbias=G(P["fb"]),
+            d_o2, dz2, dq2 = ln_bwd(dy2, o2, None if ctx.ln_fused[1] else a, P["g2"].data, mean2, rstd2, G(P["g2"]), G(P["b2"]), p_h, seed, s_ln2,
+                                    dbias=G(P["fb"]), drop_after=2 if ctx.ln_fused[1] else False,
                                     q_key=(_st_uid(st), st.offsets[id(P["fw"])], "bwd", "d_o2", ctx.fp8_tag))
         else:
             d_o2, dz2 = ln_bwd(dy2, o2, None if ctx.ln_fused[1] else a, P["g2"].data, mean2, rstd2, G(P["g2"]), G(P["b2"]), p_h, seed, s_ln2,
@@ -340,7 +356,8 @@ class BertLayerFn(torch.autograd.Function):
         if nat is not None:
             pass
         elif fp8:
-            d_o1, dz1, dq1 = ln_bwd(da, o1, x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, s_ln1, dbias=G(P["ob"]),
+            d_o1, dz1, dq1 = ln_bwd(da, o1, None if ctx.ln_fused[0] else x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, s_ln1,
+                                    dbias=G(P["ob"]), drop_after=2 if ctx.ln_fused[0] else False,
                                     q_key=(_st_uid(st), st.offsets[id(P["ow"])], "bwd", "d_o1", ctx.fp8_tag))
         else:
             d_o1, dz1 = ln_bwd(da, o1, None if ctx.ln_fused[0] else x2, P["g1"].data, mean1, rstd1, G(P["g1"]), G(P["b1"]), p_h, seed, s_ln1,
