@@ -78,6 +78,11 @@ def test_argument_errors_do_not_need_a_gpu():
     # argument error up front (it used to fail at launch); every pointer is a dummy, nothing is dereferenced before the check
     rc = lib.uc2_ot_fwd(1, 1, 256, 128, 128, 64, 16, 16, 16, 16, 0.5, 50, 16, 16, 16, None)
     assert rc == -1 and b"LDS" in lib.uc2_last_error()
+    # the e4m3 dropout-residual GEMM: p = 1 is an argument error; a token count off the 256-row tiles is refused (-2) with nothing launched
+    rc = lib.uc2_gemm_fp8_drop_residual(256, 256, 256, 16, 256, 16, 256, 16, 16, 16, 256, None, 16, 256, 1.0, None, 0, None)
+    assert rc == -1
+    rc = lib.uc2_gemm_fp8_drop_residual(200, 256, 256, 16, 256, 16, 256, 16, 16, 16, 256, None, 16, 256, 0.1, None, 0, None)
+    assert rc == -2
 
 
 # ------------------------------------------------------------------------------------------ module surface
